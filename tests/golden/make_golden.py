@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REFERENCE's own code.
+
+Run in the dev container only (``/root/reference`` does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What it does: imports the reference's ``cgan/models.py`` and ``cgan/losses.py`` unmodified (they
+need only torch + yaml), loads deterministic weights (``synth.py``) into the reference modules,
+and runs the training-step order of ``cgan/cgan_train_enhanced.py:304-369`` (that file itself
+imports torchvision/wandb, which are not installed, so its loop body is driven from here) with
+``torch.optim.Adam`` / ``clip_grad_norm_`` exactly as the reference calls them.  Randomness is
+pinned: alpha (cgan/losses.py:199) and the three Dropout(0.5) masks are fixture inputs.
+``get_refined_patch_batch`` (host PIL stage, :37-137) is replaced by fixture tensors with no
+autograd edge to delta.
+
+Outputs are DATA ONLY (inputs + expected outputs, .npz); weights are regenerated from the seed
+by ``synth.py`` and pinned by checksums stored in each fixture.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.dont_write_bytecode = True
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, "/root/reference/cgan")
+import models as ref_models    # noqa: E402  (reference, read-only)
+import losses as ref_losses    # noqa: E402
+
+synth = importlib.import_module("gan-calibrated-semi-supervised-learning_amd.synth")
+torch.set_num_threads(8)
+T = torch.from_numpy
+
+
+class FixedDropout(nn.Module):
+    """nn.Dropout(0.5) with the keep-mask supplied: x * keep / (1-p)."""
+
+    def __init__(self):
+        super().__init__()
+        self.mask = None
+
+    def forward(self, x):
+        if not self.training or self.mask is None:
+            return x
+        return x * (self.mask.to(x.dtype) * 2.0)
+
+
+def build_nets(seed: int):
+    G = ref_models.GeneratorUNet(delta_scale=0.3)
+    D = ref_models.Discriminator(spectral_norm=True)
+    G.load_state_dict({k: T(v) for k, v in synth.generator_state(seed).items()})
+    D.load_state_dict({k: T(v) for k, v in synth.discriminator_state(seed).items()})
+    drops = [FixedDropout(), FixedDropout(), FixedDropout()]
+    assert isinstance(G.down4.model[3], nn.Dropout) and isinstance(G.up1.model[3], nn.Dropout)
+    G.down4.model[3], G.up1.model[3], G.up2.model[3] = drops
+    return G, D, drops
+
+
+def checksum(sd: dict) -> np.ndarray:
+    return np.array([float(np.asarray(v, dtype=np.float64).sum()) for _, v in sorted(sd.items())]
+                    + [float(np.abs(np.asarray(v, dtype=np.float64)).sum()) for _, v in sorted(sd.items())])
+
+
+def sample(t: torch.Tensor, count: int = 256) -> np.ndarray:
+    f = t.detach().reshape(-1)
+    return f[T(synth.sample_indices(f.numel(), count))].numpy().copy()
+
+
+def pin(out: dict, name: str, t: torch.Tensor, full_limit: int = 70000):
+    """Store a tensor fully when small, else its L2 norm, sum and a strided sample."""
+    t = t.detach()
+    if t.numel() <= full_limit:
+        out[name] = t.numpy().copy()
+    else:
+        out[name + "@norm"] = np.array(float(t.double().norm()))
+        out[name + "@sum"] = np.array(float(t.double().sum()))
+        out[name + "@sample"] = sample(t)
+
+
+def run_case(name: str, seed: int, B: int, S: int, n_critic: int, iters: int, taps_full: bool,
+             gray28: bool = False):
+    G, D, drops = build_nets(seed)
+    G.train(); D.train()
+    opt_g = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    opt_d = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    crit = ref_losses.HybridLoss(lambda_iou=1.0)
+    out = {"meta": np.array([seed, B, S, n_critic, iters, int(gray28)]),
+           "wsum_g": checksum(synth.generator_state(seed)),
+           "wsum_d": checksum(synth.discriminator_state(seed))}
+    lambda_gp = 1.0
+    orig_rand = torch.rand
+    for it in range(iters):
+        inp = synth.step_inputs(seed + 1000 * it, B, S, n_critic, tag=name)
+        if gray28:  # MNIST-shaped plumbing case: 28x28 gray, zero-padded to 32, 3 channels
+            for key in ("pred", "gt"):
+                g = inp[key][:, :1, 2:30, 2:30]
+                z = np.zeros_like(inp[key]); z[:, :, 2:30, 2:30] = g
+                inp[key] = z
+        pred, gt = T(inp["pred"]), T(inp["gt"])
+        pred_box, delta_true = T(inp["pred_box"]), T(inp["delta_true"])
+        P = f"it{it}."
+        for c in range(n_critic):
+            Pc = f"{P}c{c}."
+            opt_d.zero_grad()
+            real_validity = D(pred, gt)
+            if it == 0 and c == 0:
+                for i in (0, 2, 5, 8):
+                    out[f"{Pc}u_after_real.{i}"] = D.model[i].weight_u.numpy().copy()
+            for d, m in zip(drops, inp["masks"][c]):
+                d.mask = T(m)
+            with torch.no_grad():
+                delta_det = G(pred)
+            refined = T(inp["refined"][c])
+            fake_validity = D(pred, refined)
+            alpha = T(inp["alpha"][c])
+            grabbed = {}
+            if taps_full and it == 0 and c == 0:   # capture the first-order input grads too
+                orig_grad = torch.autograd.grad
+
+                def spy(*a, **k):
+                    g = orig_grad(*a, **k)
+                    grabbed["g"] = [x.detach().clone() for x in g]
+                    grabbed["d_i"] = k["outputs"].detach().clone()
+                    return g
+                torch.autograd.grad = spy
+            torch.rand = lambda *a, **k: alpha.clone()
+            try:
+                gp = ref_losses.compute_gradient_penalty(D, (pred, gt), (pred, refined), torch.device("cpu"))
+            finally:
+                torch.rand = orig_rand
+                if grabbed:
+                    torch.autograd.grad = orig_grad
+            wd = torch.mean(real_validity) - torch.mean(fake_validity)
+            d_loss = -wd + lambda_gp * gp
+            d_loss.backward()
+            if taps_full and it == 0 and c == 0:
+                for k, p in D.named_parameters():
+                    pin(out, f"{Pc}dgrad.{k}", p.grad)
+                pin(out, f"{Pc}gp_grad_pred", grabbed["g"][0])
+                pin(out, f"{Pc}gp_grad_other", grabbed["g"][1])
+                out[f"{Pc}d_interp"] = grabbed["d_i"].numpy().copy()
+            total = torch.nn.utils.clip_grad_norm_(D.parameters(), max_norm=1.0)
+            opt_d.step()
+            out[f"{Pc}real_validity"] = real_validity.detach().numpy().copy()
+            out[f"{Pc}fake_validity"] = fake_validity.detach().numpy().copy()
+            out[f"{Pc}delta_detached"] = delta_det.numpy().copy()
+            out[f"{Pc}scalars"] = np.array([float(d_loss), float(gp), float(wd), float(total)])
+        # ---- generator update ----
+        opt_g.zero_grad()
+        for d, m in zip(drops, inp["masks"][n_critic]):
+            d.mask = T(m)
+        delta_pred = G(pred)
+        cal = ref_losses.apply_delta_to_bbox(pred_box, delta_pred, training=True)
+        gtb = ref_losses.apply_delta_to_bbox(pred_box, delta_true, training=True)
+        loss_reg, loss_iou = crit(delta_pred, delta_true, cal, gtb)
+        refined_g = T(inp["refined"][n_critic])
+        fake_g = D(pred, refined_g)
+        loss_wgan = -torch.mean(fake_g)
+        loss_g = loss_reg + loss_wgan
+        loss_g.backward()
+        if taps_full and it == 0:
+            for k, p in G.named_parameters():
+                pin(out, f"{P}ggrad.{k}", p.grad)
+        total_g = torch.nn.utils.clip_grad_norm_(G.parameters(), max_norm=1.0)
+        opt_g.step()
+        out[f"{P}delta_pred"] = delta_pred.detach().numpy().copy()
+        out[f"{P}calibrated"] = cal.detach().numpy().copy()
+        out[f"{P}fake_validity_for_G"] = fake_g.detach().numpy().copy()
+        out[f"{P}gscalars"] = np.array([float(loss_g), float(loss_iou), float(loss_wgan), float(total_g)])
+        # state after this iteration
+        for k, v in D.state_dict().items():
+            pin(out, f"{P}D.{k}", v, full_limit=5000)
+        for k, v in G.state_dict().items():
+            pin(out, f"{P}G.{k}", v, full_limit=5000)
+    # Adam moments of two representative tensors after the last iteration
+    st = opt_d.state[D.model[2].weight_orig]
+    pin(out, "final.adam_m.D.model.2.weight_orig", st["exp_avg"], 5000)
+    pin(out, "final.adam_v.D.model.2.weight_orig", st["exp_avg_sq"], 5000)
+    st = opt_g.state[G.up4[0].weight]
+    pin(out, "final.adam_m.G.up4.0.weight", st["exp_avg"], 5000)
+    pin(out, "final.adam_v.G.up4.0.weight", st["exp_avg_sq"], 5000)
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"{name}: {len(out)} arrays, {os.path.getsize(HERE / (name + '.npz')) / 1024:.0f} KiB")
+
+
+def forward_case(name: str, seed: int, B: int, S: int):
+    """Per-layer activations (train and eval mode), single forward of D and G."""
+    G, D, drops = build_nets(seed)
+    inp = synth.step_inputs(seed, B, S, 1, tag=name)
+    pred, gt = T(inp["pred"]), T(inp["gt"])
+    out = {"meta": np.array([seed, B, S]), "wsum_g": checksum(synth.generator_state(seed)),
+           "wsum_d": checksum(synth.discriminator_state(seed))}
+    acts = {}
+
+    def hook(key):
+        def fn(_m, _i, o):
+            acts[key] = o.detach().clone()
+        return fn
+    hs = [D.model[i].register_forward_hook(hook(f"d.act{j}")) for j, i in enumerate((1, 4, 7, 10), 1)]
+    hs += [getattr(G, n).register_forward_hook(hook(f"g.{n}")) for n in
+           ("down1", "down2", "down3", "down4", "up1", "up2", "up3", "up4")]
+    for mode in ("eval", "train"):
+        G.train(mode == "train"); D.train(mode == "train")
+        for d, m in zip(drops, inp["masks"][0]):
+            d.mask = T(m)
+        with torch.no_grad():
+            score = D(pred, gt)
+            delta = G(pred)
+        out[f"{mode}.d_out"] = score.numpy().copy()
+        out[f"{mode}.g_delta"] = delta.numpy().copy()
+        for k, v in acts.items():
+            pin(out, f"{mode}.{k}", v, full_limit=40000)
+        for i in (0, 2, 5, 8):
+            out[f"{mode}.u.{i}"] = D.model[i].weight_u.numpy().copy()
+            out[f"{mode}.v.{i}"] = D.model[i].weight_v.numpy().copy()
+    for h in hs:
+        h.remove()
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"{name}: {len(out)} arrays, {os.path.getsize(HERE / (name + '.npz')) / 1024:.0f} KiB")
+
+
+def loss_vectors():
+    """Known-answer vectors for cgan/losses.py:10-183 incl. edge cases."""
+    bbox = T(np.concatenate([synth.uniform("kv.c", 7, (16, 2), 0.05, 0.95),
+                             synth.uniform("kv.s", 7, (16, 2), 0.02, 0.8)], 1))
+    delta = T(synth.normal("kv.d", 7, (16, 4), 1.2))
+    delta[0] = torch.tensor([5.0, -5.0, 3.0, -3.0])       # saturating branches
+    delta[1] = 0.0
+    tb = bbox.clone()
+    tb[2] = torch.tensor([0.9, 0.9, 0.05, 0.05]); bbox[2] = torch.tensor([0.1, 0.1, 0.05, 0.05])  # disjoint
+    tb[3] = bbox[3]                                         # identical boxes
+    out = {"bbox": bbox.numpy(), "delta": delta.numpy(), "target": tb.numpy()}
+    out["apply_train"] = ref_losses.apply_delta_to_bbox(bbox, delta, training=True).numpy()
+    out["apply_eval"] = ref_losses.apply_delta_to_bbox(bbox, delta, training=False).numpy()
+    x = T(synth.normal("kv.x", 7, (64,), 2.0))
+    out["x"] = x.numpy()
+    out["smooth_clamp"] = ref_losses.smooth_clamp(x, -1.5, 1.5).numpy()
+    out["smooth_clamp_t1"] = ref_losses.smooth_clamp(x, 0.02, 0.8, temperature=1.0).numpy()
+    out["iou"] = ref_losses.iou_metric(bbox, tb).numpy()
+    out["eiou"] = np.array(float(ref_losses.EIoULoss()(bbox, tb)))
+    # gradient of the G regression loss w.r.t. delta (the only gradient source of G)
+    d = delta.clone().requires_grad_(True)
+    crit = ref_losses.HybridLoss(lambda_iou=1.0)
+    cal = ref_losses.apply_delta_to_bbox(bbox, d, training=True)
+    gtb = ref_losses.apply_delta_to_bbox(bbox, T(synth.normal("kv.dt", 7, (16, 4), 0.1)), training=True)
+    tot, li = crit(d, None, cal, gtb)
+    tot.backward()
+    out["hybrid_total"] = np.array(float(tot)); out["hybrid_grad_delta"] = d.grad.numpy()
+    out["hybrid_gtb"] = gtb.numpy()
+    np.savez_compressed(HERE / "loss_vectors.npz", **out)
+    print("loss_vectors:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    loss_vectors()
+    forward_case("fwd_B2_S32", 42, 2, 32)
+    forward_case("fwd_B2_S64", 42, 2, 64)
+    run_case("step_B4_S32", 42, 4, 32, n_critic=2, iters=2, taps_full=True)
+    run_case("step_B2_S64", 43, 2, 64, n_critic=2, iters=1, taps_full=True)
+    run_case("step_B2_S128", 44, 2, 128, n_critic=1, iters=1, taps_full=False)
+    run_case("step_mnist_B4_S32", 45, 4, 32, n_critic=2, iters=1, taps_full=False, gray28=True)
