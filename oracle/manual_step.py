@@ -1,0 +1,383 @@
+"""CPU ORACLE (part 2) -- TEST INFRASTRUCTURE ONLY.
+
+The same training step as ``cgan_oracle.StepOracle`` but with every derivative written out by
+hand (no autograd): this is the executable specification of the kernel schedule the HIP engine
+(``gan-calibrated-semi-supervised-learning_amd/engine.py``) launches.  ``tests/test_manual_math.py``
+checks it against the autograd oracle, which in turn is pinned to the reference's golden vectors.
+
+Primitive linear maps are taken from torch CPU (conv2d / conv_transpose2d / conv2d_weight) inside
+``torch.no_grad()``; everything non-linear (InstanceNorm backward and double backward, LeakyReLU
+masks, spectral-norm quotient rule, gradient-penalty norm, EIoU/box analytic gradient, clip, Adam)
+is explicit.
+
+Reference lines restated: cgan/cgan_train_enhanced.py:304-369, cgan/losses.py:10-150,185-233,
+cgan/models.py:54-141,222-258.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch.nn.grad import conv2d_weight
+
+Tensor = torch.Tensor
+EPS = 1e-5
+SLOPE = 0.2
+D_IDX = (0, 2, 5, 8)
+
+
+# ------------------------------------------------------------------ InstanceNorm pieces
+def in_stats(z: Tensor):
+    mu = z.mean(dim=(2, 3), keepdim=True)
+    var = ((z - mu) ** 2).mean(dim=(2, 3), keepdim=True)
+    r = 1.0 / torch.sqrt(var + EPS)
+    return mu, r
+
+
+def _m(x: Tensor) -> Tensor:
+    return x.mean(dim=(2, 3), keepdim=True)
+
+
+def in_bwd(xhat: Tensor, r: Tensor, dn: Tensor) -> Tensor:
+    """dz = r (dn - mean(dn) - xhat mean(dn xhat))."""
+    return r * (dn - _m(dn) - xhat * _m(dn * xhat))
+
+
+def in_bwd_bwd(xhat: Tensor, r: Tensor, dn: Tensor, q: Tensor):
+    """Adjoint of ``dz = in_bwd(xhat(z), r(z), dn)`` for an incoming adjoint ``q`` of dz.
+
+    Returns (adjoint w.r.t. dn, adjoint w.r.t. z):
+      dn~ = r P(q)                      (the Jacobian of IN is symmetric)
+      z~  = r^2 [ -xhat (mqd - mq m1 - 3 mqx m2) - m2 (q - mq) - mqx (dn - m1) ]
+    with m1=mean(dn), m2=mean(dn xhat), mq=mean(q), mqx=mean(q xhat), mqd=mean(q dn).
+    """
+    m1, m2, mq, mqx, mqd = _m(dn), _m(dn * xhat), _m(q), _m(q * xhat), _m(q * dn)
+    dn_t = r * (q - mq - xhat * mqx)
+    z_t = r * r * (-xhat * (mqd - mq * m1 - 3.0 * mqx * m2) - m2 * (q - mq) - mqx * (dn - m1))
+    return dn_t, z_t
+
+
+def lrelu(x):
+    return torch.where(x > 0, x, SLOPE * x)
+
+
+def lrelu_grad(a):       # from the OUTPUT a (slope>0 so sign(a)==sign(pre-activation))
+    return torch.where(a > 0, torch.ones_like(a), torch.full_like(a, SLOPE))
+
+
+# ------------------------------------------------------------------ spectral norm
+def sn_power_iter(w: Tensor, u: Tensor, v: Tensor):
+    """One power iteration; returns new (u, v, sigma).  legacy spectral_norm, eps 1e-12."""
+    wm = w.reshape(w.shape[0], -1)
+    vn = wm.t().mv(u)
+    vn = vn / vn.norm().clamp_min(1e-12)
+    un = wm.mv(vn)
+    un = un / un.norm().clamp_min(1e-12)
+    return un, vn, torch.dot(un, wm.mv(vn))
+
+
+# ------------------------------------------------------------------ D step
+@torch.no_grad()
+def d_step_grads(sd: Dict[str, Tensor], pred: Tensor, gt: Tensor, refined: Tensor, alpha: Tensor,
+                 lambda_gp: float = 1.0):
+    """Forward of the three critic passes (batched), GP, and all parameter gradients of
+    d_loss = -(mean(real) - mean(fake)) + lambda_gp * gp.   Mutates sd's u,v three times
+    (cgan/cgan_train_enhanced.py:308,316 and cgan/losses.py:210).
+    Returns (grads dict keyed like the state_dict, log dict)."""
+    B = pred.shape[0]
+    W = [sd[f"model.{i}.weight_orig"] for i in D_IDX]
+    bias = [sd[f"model.{i}.bias"] for i in D_IDX]
+    W5 = sd["model.11.weight"]
+    # -- three consecutive power iterations per layer (real, fake, interp forwards)
+    U = [[None] * 3 for _ in range(4)]; V = [[None] * 3 for _ in range(4)]
+    sig = torch.zeros(4, 3)
+    for l, i in enumerate(D_IDX):
+        u, v = sd[f"model.{i}.weight_u"], sd[f"model.{i}.weight_v"]
+        for k in range(3):
+            u, v, s = sn_power_iter(W[l], u, v)
+            U[l][k], V[l][k], sig[l, k] = u, v, s
+        sd[f"model.{i}.weight_u"].copy_(u); sd[f"model.{i}.weight_v"].copy_(v)
+    isig = 1.0 / sig                                                   # [layer][group]
+    grp = torch.arange(3).repeat_interleave(B)                         # group of each of the 3B rows
+
+    def gscale(l):                                                     # (3B,1,1,1) per-sample 1/sigma
+        return isig[l][grp].view(-1, 1, 1, 1)
+
+    # -- batched input: real | fake | interp   (cgan/losses.py:203-204: both halves interpolated)
+    a = alpha.expand_as(pred)
+    x_real = torch.cat([pred, gt], 1)
+    x_fake = torch.cat([pred, refined], 1)
+    x_int = torch.cat([a * pred + (1 - a) * pred, a * gt + (1 - a) * refined], 1)
+    x0 = torch.cat([x_real, x_fake, x_int], 0)
+    # -- forward
+    acts = [x0]; zs = []; stats = []
+    for l in range(4):
+        z = F.conv2d(acts[-1], W[l], None, 2, 1) * gscale(l) + bias[l].view(1, -1, 1, 1)
+        zs.append(z)
+        if l == 0:
+            stats.append(None)
+            acts.append(lrelu(z))
+        else:
+            mu, r = in_stats(z)
+            stats.append((mu, r))
+            acts.append(lrelu((z - mu) * r))
+    out = F.conv2d(acts[4], W5, None, 1, 1)                            # (3B,1,h,w)
+    hw = out.shape[2] * out.shape[3]
+    real, fake, d_int = out[:B], out[B:2 * B], out[2 * B:]
+    wd = real.mean() - fake.mean()
+
+    # -- GP first-order chain (interp group only), grad_outputs = ones
+    I = slice(2 * B, 3 * B)
+    ones = torch.ones_like(d_int)
+    gb_a = F.conv_transpose2d(ones, W5, None, 1, 1)                    # d out / d a4
+    gb_n = [None] * 4; gb_z = [None] * 4; gb_a_in = [None] * 4
+    for l in (3, 2, 1):
+        mu, r = stats[l]
+        xh = (zs[l][I] - mu[I]) * r[I]
+        gb_n[l] = lrelu_grad(acts[l + 1][I]) * gb_a
+        gb_z[l] = in_bwd(xh, r[I], gb_n[l])
+        gb_a = F.conv_transpose2d(gb_z[l], W[l], None, 2, 1) * isig[l, 2]
+    gb_z[0] = lrelu_grad(acts[1][I]) * gb_a
+    gb_x0 = F.conv_transpose2d(gb_z[0], W[0], None, 2, 1) * isig[0, 2]
+    nrm = torch.sqrt((gb_x0.reshape(B, -1) ** 2).sum(1) + 1e-12)
+    gp = ((nrm - 1) ** 2).mean()
+    d_loss = -wd + lambda_gp * gp
+
+    # -- reverse of the chain: adjoints gt_* of the gb_* quantities
+    gW = [torch.zeros_like(w) for w in W]       # sum_k G_k / sigma_k  (pre-scaled dy)
+    cdot = torch.zeros(4, 3)                    # sum <dy, conv(x, W_orig)> / sigma_k  per group
+    coef = (lambda_gp * 2.0 / B) * (nrm - 1) / nrm
+    gt_x = coef.view(-1, 1, 1, 1) * gb_x0
+    zt = [None] * 4                             # IN double-backward terms entering dz of interp
+    gt_in = gt_x
+    for l in range(4):
+        gt_z = F.conv2d(gt_in, W[l], None, 2, 1) * isig[l, 2]
+        gW[l] += conv2d_weight(gt_in, W[l].shape, gb_z[l] * isig[l, 2], 2, 1)
+        cdot[l, 2] += (gb_z[l] * gt_z).sum()
+        if l == 0:
+            gt_in = lrelu_grad(acts[1][I]) * gt_z
+        else:
+            mu, r = stats[l]
+            xh = (zs[l][I] - mu[I]) * r[I]
+            gt_n, zt[l] = in_bwd_bwd(xh, r[I], gb_n[l], gt_z)
+            gt_in = lrelu_grad(acts[l + 1][I]) * gt_n
+    gW5 = conv2d_weight(gt_in, W5.shape, ones, 1, 1)
+
+    # -- backward of the three forwards, batched
+    d_out = torch.zeros_like(out)
+    d_out[:B] = -1.0 / (B * hw)
+    d_out[B:2 * B] = 1.0 / (B * hw)
+    gW5 += conv2d_weight(acts[4], W5.shape, d_out, 1, 1)
+    da = F.conv_transpose2d(d_out, W5, None, 1, 1)
+    gb = [None] * 4
+    for l in (3, 2, 1, 0):
+        if l == 0:
+            dz = lrelu_grad(acts[1]) * da
+        else:
+            mu, r = stats[l]
+            xh = (zs[l] - mu) * r
+            dz = in_bwd(xh, r, lrelu_grad(acts[l + 1]) * da)
+            dz[I] += zt[l]
+        gb[l] = dz.sum(dim=(0, 2, 3))
+        zc = zs[l] - bias[l].view(1, -1, 1, 1)                         # = conv(x, W_orig) / sigma_k
+        for k in range(3):
+            sl = slice(k * B, (k + 1) * B)
+            cdot[l, k] += (dz[sl] * zc[sl]).sum()
+        dzs = dz * gscale(l)
+        gW[l] += conv2d_weight(acts[l], W[l].shape, dzs, 2, 1)
+        if l > 0:
+            da = F.conv_transpose2d(dzs, W[l], None, 2, 1)
+    # -- spectral-norm quotient rule: dW_orig = sum_k G_k/sigma_k - sum_k c_k u_k v_k^T,
+    #    c_k = <G_k, W_orig>/sigma_k^2 = cdot[l,k]/sigma_k   (<G_k,W_orig> = sigma_k * cdot[l,k] because
+    #    z - b = conv(x, W_orig)/sigma_k and gt_z = conv(gt_a, W_orig)/sigma_2)
+    grads = {}
+    for l, i in enumerate(D_IDX):
+        g = gW[l]
+        for k in range(3):
+            g = g - (cdot[l, k] * isig[l, k]) * torch.outer(U[l][k], V[l][k]).view_as(g)
+        grads[f"model.{i}.weight_orig"] = g
+        grads[f"model.{i}.bias"] = gb[l]
+    grads["model.11.weight"] = gW5
+    log = dict(real=real.clone(), fake=fake.clone(), d_interp=d_int.clone(), gp=float(gp), wd=float(wd),
+               d_loss=float(d_loss), gp_grad=gb_x0.clone(), sigma=sig.clone())
+    return grads, log
+
+
+# ------------------------------------------------------------------ box math + EIoU, analytic gradient
+def _sig(x):
+    return 1.0 / (1.0 + torch.exp(-x))
+
+
+@torch.no_grad()
+def eiou_box_loss_and_grad(pred_box: Tensor, delta: Tensor, delta_true: Tensor, eps: float = 1e-6):
+    """loss = 1 - mean(EIoU(apply_delta(pred_box, delta), apply_delta(pred_box, delta_true)))  (train mode)
+    and d loss / d delta, written out (cgan/losses.py:19-73,99-150)."""
+    B = delta.shape[0]
+
+    def sclamp(x, lo, hi):                       # value and derivative of smooth_clamp (T=0.5)
+        s = _sig((x - (lo + hi) / 2) / 0.5)
+        return lo + (hi - lo) * s, (hi - lo) * s * (1 - s) / 0.5
+
+    def apply(d):
+        dc, ddc = sclamp(d, -1.5, 1.5)
+        bx, by, bw, bh = pred_box.unbind(1)
+        cx0 = bx + dc[:, 0] * bw; cy0 = by + dc[:, 1] * bh
+        e2 = torch.clamp(dc[:, 2], -1.0, 1.0); e3 = torch.clamp(dc[:, 3], -1.0, 1.0)
+        in2 = ((dc[:, 2] >= -1.0) & (dc[:, 2] <= 1.0)).float(); in3 = ((dc[:, 3] >= -1.0) & (dc[:, 3] <= 1.0)).float()
+        w0 = bw * torch.exp(e2); h0 = bh * torch.exp(e3)
+        cx, dcx = sclamp(cx0, 0.05, 0.95); cy, dcy = sclamp(cy0, 0.05, 0.95)
+        w, dw = sclamp(w0, 0.02, 0.8); h, dh = sclamp(h0, 0.02, 0.8)
+        jac = torch.stack([dcx * bw * ddc[:, 0], dcy * bh * ddc[:, 1],
+                           dw * w0 * in2 * ddc[:, 2], dh * h0 * in3 * ddc[:, 3]], 1)   # diagonal d box / d delta
+        return torch.stack([cx, cy, w, h], 1), jac
+
+    p, jac = apply(delta)
+    t, _ = apply(delta_true)
+    px, py, pw, ph = p.unbind(1); tx, ty, tw, th = t.unbind(1)
+    px1, px2, py1, py2 = px - pw / 2, px + pw / 2, py - ph / 2, py + ph / 2
+    tx1, tx2, ty1, ty2 = tx - tw / 2, tx + tw / 2, ty - th / 2, ty + th / 2
+    ix1, ix2 = torch.max(px1, tx1), torch.min(px2, tx2)
+    iy1, iy2 = torch.max(py1, ty1), torch.min(py2, ty2)
+    iw_raw, ih_raw = ix2 - ix1, iy2 - iy1
+    iw, ih = iw_raw.clamp(min=0), ih_raw.clamp(min=0)
+    inter = iw * ih
+    union = pw * ph + tw * th - inter + eps
+    iou = inter / union
+    ex1, ex2 = torch.min(px1, tx1), torch.max(px2, tx2)
+    ey1, ey2 = torch.min(py1, ty1), torch.max(py2, ty2)
+    ew, eh = ex2 - ex1, ey2 - ey1
+    c2 = ew * ew + eh * eh + eps
+    rho2 = (px - tx) ** 2 + (py - ty) ** 2
+    dw2, dh2 = (pw - tw) ** 2, (ph - th) ** 2
+    eiou = iou - rho2 / c2 - dw2 / (ew * ew + eps) - dh2 / (eh * eh + eps)
+    loss = 1 - eiou.mean()
+    # ---- gradient of eiou w.r.t. (px1,px2,py1,py2) then to (px,py,pw,ph)
+    # torch.max/min route the gradient to the first arg when strictly larger/smaller, split 0.5/0.5 on ties
+    def sel_max(a, b):   # d max(a,b) / d a
+        return (a > b).float() + 0.5 * (a == b).float()
+
+    def sel_min(a, b):
+        return (a < b).float() + 0.5 * (a == b).float()
+    g_iw = ih * (iw_raw > 0).float(); g_ih = iw * (ih_raw > 0).float()          # d inter / d iw_raw, ih_raw  (clamp(min=0): grad 1 at >=0? see below)
+    # torch.clamp(min=0) passes gradient where x >= 0
+    g_iw = ih * (iw_raw >= 0).float(); g_ih = iw * (ih_raw >= 0).float()
+    d_iou_dinter = 1 / union + inter / union ** 2                                   # via inter and -inter in union
+    d_iou_dparea = -inter / union ** 2
+    # accumulate d eiou / d corners
+    g_px1 = d_iou_dinter * g_iw * (-sel_max(px1, tx1)); g_px2 = d_iou_dinter * g_iw * sel_min(px2, tx2)
+    g_py1 = d_iou_dinter * g_ih * (-sel_max(py1, ty1)); g_py2 = d_iou_dinter * g_ih * sel_min(py2, ty2)
+    # pred_area = (px2-px1)*(py2-py1)
+    g_px1 += d_iou_dparea * (-(py2 - py1)); g_px2 += d_iou_dparea * (py2 - py1)
+    g_py1 += d_iou_dparea * (-(px2 - px1)); g_py2 += d_iou_dparea * (px2 - px1)
+    # enclosing box terms
+    g_ew = rho2 / c2 ** 2 * 2 * ew + dw2 / (ew * ew + eps) ** 2 * 2 * ew
+    g_eh = rho2 / c2 ** 2 * 2 * eh + dh2 / (eh * eh + eps) ** 2 * 2 * eh
+    g_px1 += g_ew * (-sel_min(px1, tx1)); g_px2 += g_ew * sel_max(px2, tx2)
+    g_py1 += g_eh * (-sel_min(py1, ty1)); g_py2 += g_eh * sel_max(py2, ty2)
+    # corners -> centre/size, plus the direct terms
+    g_px = g_px1 + g_px2 - 2 * (px - tx) / c2
+    g_py = g_py1 + g_py2 - 2 * (py - ty) / c2
+    g_pw = 0.5 * (g_px2 - g_px1) - 2 * (pw - tw) / (ew * ew + eps)
+    g_ph = 0.5 * (g_py2 - g_py1) - 2 * (ph - th) / (eh * eh + eps)
+    g_box = torch.stack([g_px, g_py, g_pw, g_ph], 1) * (-1.0 / B)                  # loss = 1 - mean
+    return loss, g_box * jac, p
+
+
+# ------------------------------------------------------------------ G forward/backward
+@torch.no_grad()
+def g_forward_backward(sd: Dict[str, Tensor], x: Tensor, delta_scale: float, masks: Sequence[Tensor],
+                       pred_box: Tensor, delta_true: Tensor, lambda_iou: float = 1.0):
+    """GeneratorUNet train-mode forward + hand-written backward of lambda_iou*EIoU (cgan/models.py:125-141,
+    cgan/cgan_train_enhanced.py:348-366)."""
+    Wd = [sd[f"down{k}.model.0.weight"] for k in (1, 2, 3, 4)]
+    Wu = [sd["up1.model.0.weight"], sd["up2.model.0.weight"], sd["up3.model.0.weight"], sd["up4.0.weight"]]
+    mk = [m.to(x.dtype) * 2.0 for m in masks]
+    # forward
+    dz_, dst, da_ = [], [], []
+    h = x
+    for k in range(4):
+        z = F.conv2d(h, Wd[k], None, 2, 1)
+        if k == 0:
+            st = None; a = lrelu(z)
+        else:
+            st = in_stats(z); a = lrelu((z - st[0]) * st[1])
+        if k == 3:
+            a = a * mk[0]
+        dz_.append(z); dst.append(st); da_.append(a); h = a
+    skips = [da_[2], da_[1], da_[0], None]
+    uz, ust, ua, uin = [], [], [], []
+    for k in range(4):
+        uin.append(h)
+        z = F.conv_transpose2d(h, Wu[k], None, 2, 1)
+        st = in_stats(z)
+        a = torch.relu((z - st[0]) * st[1])
+        if k < 2:
+            a = a * mk[k + 1]
+        uz.append(z); ust.append(st); ua.append(a)
+        h = torch.cat((a, skips[k]), 1) if skips[k] is not None else a
+    pooled = h.mean(dim=(2, 3))
+    y = pooled @ sd["fc_delta.1.weight"].t() + sd["fc_delta.1.bias"]
+    t = torch.tanh(y)
+    delta = t * delta_scale
+    loss_iou, g_delta, cal = eiou_box_loss_and_grad(pred_box, delta, delta_true)
+    g_delta = g_delta * lambda_iou
+    # backward
+    grads = {}
+    dy = g_delta * delta_scale * (1 - t * t)
+    grads["fc_delta.1.weight"] = dy.t() @ pooled
+    grads["fc_delta.1.bias"] = dy.sum(0)
+    dpool = dy @ sd["fc_delta.1.weight"]
+    S2 = h.shape[2] * h.shape[3]
+    dh = (dpool / S2).view(*dpool.shape, 1, 1).expand_as(h)
+    dskip = [None, None, None]          # gradient flowing into d1, d2, d3 from the concats
+    for k in (3, 2, 1, 0):
+        if skips[k] is not None:
+            c = ua[k].shape[1]
+            dskip[2 - k] = dh[:, c:]
+            da = dh[:, :c]
+        else:
+            da = dh
+        if k < 2:
+            da = da * mk[k + 1]
+        mu, r = ust[k]
+        xh = (uz[k] - mu) * r
+        dn = da * (xh > 0).float()
+        dzk = in_bwd(xh, r, dn)
+        key = f"up{k + 1}.model.0.weight" if k < 3 else "up4.0.weight"
+        grads[key] = conv2d_weight(dzk, Wu[k].shape, uin[k], 2, 1)     # roles swapped for ConvTranspose
+        dh = F.conv2d(dzk, Wu[k], None, 2, 1)
+    # dh is now the gradient w.r.t. d4 (after dropout)
+    for k in (3, 2, 1, 0):
+        da = dh
+        if k == 3:
+            da = da * mk[0]
+        else:
+            da = da + dskip[k]          # d1<-dskip[0], d2<-dskip[1], d3<-dskip[2]
+        if k == 0:
+            dzk = lrelu_grad(lrelu(dz_[0])) * da
+        else:
+            mu, r = dst[k]
+            xh = (dz_[k] - mu) * r
+            dzk = in_bwd(xh, r, lrelu_grad(xh) * da)
+        inp = x if k == 0 else da_[k - 1]
+        grads[f"down{k + 1}.model.0.weight"] = conv2d_weight(inp, Wd[k].shape, dzk, 2, 1)
+        if k > 0:
+            dh = F.conv_transpose2d(dzk, Wd[k], None, 2, 1)
+    return delta, float(loss_iou), grads
+
+
+# ------------------------------------------------------------------ clip + Adam on flat lists
+@torch.no_grad()
+def clip_and_adam(params: List[Tensor], grads: List[Tensor], m: List[Tensor], v: List[Tensor], t: int,
+                  lr: float = 2e-4, b1: float = 0.5, b2: float = 0.999, eps: float = 1e-8, max_norm: float = 1.0):
+    total = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads))
+    coef = min(1.0, max_norm / (total + 1e-6))
+    bc1 = 1 - b1 ** t; bc2s = math.sqrt(1 - b2 ** t)
+    for p, g, mi, vi in zip(params, grads, m, v):
+        g = g * coef
+        mi.mul_(b1).add_(g, alpha=1 - b1)
+        vi.mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.addcdiv_(mi, vi.sqrt() / bc2s + eps, value=-lr / bc1)
+    return total
