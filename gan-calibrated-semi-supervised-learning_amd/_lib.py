@@ -1,0 +1,127 @@
+"""ctypes binding of libgcssl_hip.so (the C ABI declared in include/gcssl.h).
+
+The prototypes are parsed from the header itself, so Python can never drift from the ABI.  There is NO
+fallback: if the library is missing or a call fails, a RuntimeError is raised (the product path never
+routes through the CPU oracle).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import subprocess
+from pathlib import Path
+
+import torch
+
+PKG_DIR = Path(__file__).resolve().parent
+ROOT = PKG_DIR.parent
+HEADER = ROOT / "include" / "gcssl.h"
+CSRC = PKG_DIR / "csrc"
+LIB_PATH = PKG_DIR / "libgcssl_hip.so"
+SOURCES = ["igemm.hip", "norm.hip", "misc.hip"]
+
+F32, BF16 = 0, 1
+ERRORS = {-1: "GCSSL_EBADSHAPE", -2: "GCSSL_EBADDTYPE", -3: "GCSSL_EALIGN", -4: "GCSSL_ENULL"}
+
+_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
+       "unsigned long long": ctypes.c_ulonglong}
+
+
+def parse_header(path: Path = HEADER):
+    """-> {name: (restype, [argtypes])} for every `gcssl_*` function declared in the header."""
+    text = re.sub(r"/\*.*?\*/", "", path.read_text(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(const char\*|int)\s+(gcssl_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    ty = re.sub(r"\s+\w+$", "", a).replace("const ", "").strip()
+                    argtypes.append(_CT[ty])
+        protos[name] = (ctypes.c_char_p if ret.startswith("const char") else ctypes.c_int, argtypes)
+    return protos
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the HIP sources for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU)."""
+    srcs = [CSRC / s for s in SOURCES]
+    deps = srcs + [CSRC / "common.h"]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           "-o", str(LIB_PATH)] + [str(s) for s in srcs]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed:\n{r.stderr}")
+    return LIB_PATH
+
+
+_lib = None
+_protos = None
+
+
+def lib():
+    global _lib, _protos
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               f"(there is no CPU fallback for the HIP path)")
+        _lib = ctypes.CDLL(str(LIB_PATH))
+        _protos = parse_header()
+        for name, (ret, argtypes) in _protos.items():
+            fn = getattr(_lib, name)          # AttributeError here == header/ABI mismatch: fail loudly
+            fn.restype, fn.argtypes = ret, argtypes
+    return _lib
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _conv(a):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    return a
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point with tensors/None/scalars; the current torch stream is appended."""
+    fn = getattr(lib(), name)
+    rc = fn(*[_conv(a) for a in args], stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {ERRORS.get(rc, 'hipError ' + str(rc))}")
+
+
+def call_nostream(name: str, *args):
+    return getattr(lib(), name)(*[_conv(a) for a in args])
+
+
+def ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def int_array(vals):
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+def dtype_code(dt) -> int:
+    if dt in (F32, "fp32", "f32", torch.float32):
+        return F32
+    if dt in (BF16, "bf16", torch.bfloat16):
+        return BF16
+    raise ValueError(f"unsupported compute dtype {dt!r}")
+
+
+def torch_dtype(code: int):
+    return torch.float32 if code == F32 else torch.bfloat16

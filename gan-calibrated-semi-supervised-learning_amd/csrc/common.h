@@ -1,0 +1,93 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the cGAN WGAN-GP step.
+// Wave = 64 lanes everywhere in this tree; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GCSSL_OK 0
+#define GCSSL_EBADSHAPE (-1)
+#define GCSSL_EBADDTYPE (-2)
+#define GCSSL_EALIGN (-3)
+#define GCSSL_ENULL (-4)
+
+#define GCSSL_F32 0
+#define GCSSL_BF16 1
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+static inline int gcssl_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GCSSL_OK : (int)e;
+}
+static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- element traits: T is the storage/operand type of activations (float or bf16)
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int KV = 4;                       // elements per 16-byte vector
+    __device__ static float ld(const float* p) { return *p; }
+    __device__ static void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int KV = 8;
+    __device__ static float ld(const bf16_t* p) { return (float)*p; }
+    __device__ static void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    bf16_t h = (bf16_t)f;                              // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+    return (uint32_t)__builtin_bit_cast(uint16_t, h);
+}
+
+// 16-byte vector of elements <-> floats
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    float4 v;
+    __device__ static Vec16 zero() { Vec16 r; r.v = make_float4(0.f, 0.f, 0.f, 0.f); return r; }
+    __device__ static Vec16 load(const float* p) { Vec16 r; r.v = *reinterpret_cast<const float4*>(p); return r; }
+    __device__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    __device__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+    __device__ void set(int i, float f) { if (i == 0) v.x = f; else if (i == 1) v.y = f; else if (i == 2) v.z = f; else v.w = f; }
+};
+template <> struct Vec16<bf16_t> {
+    uint4 v;
+    __device__ static Vec16 zero() { Vec16 r; r.v = make_uint4(0, 0, 0, 0); return r; }
+    __device__ static Vec16 load(const bf16_t* p) { Vec16 r; r.v = *reinterpret_cast<const uint4*>(p); return r; }
+    __device__ void store(bf16_t* p) const { *reinterpret_cast<uint4*>(p) = v; }
+    __device__ uint32_t word(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+    __device__ uint32_t bits(int i) const { uint32_t w = word(i >> 1); return (i & 1) ? (w >> 16) : (w & 0xFFFFu); }
+    __device__ float get(int i) const { return bf16_bits_to_f32(bits(i)); }
+    __device__ void setword(int i, uint32_t w) { if (i == 0) v.x = w; else if (i == 1) v.y = w; else if (i == 2) v.z = w; else v.w = w; }
+    __device__ void set2(int pair, float lo, float hi) { setword(pair, f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16)); }
+};
+
+// ---- wave / block reductions (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over a block of NW waves; result valid in every thread. `sm` needs NW floats.
+template <int NW> __device__ __forceinline__ float block_sum(float v, float* sm) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r += sm[i];
+    return r;
+}
+
+__device__ __forceinline__ float lrelu_f(float x) { return x > 0.f ? x : 0.2f * x; }

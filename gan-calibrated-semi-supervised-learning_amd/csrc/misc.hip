@@ -1,0 +1,630 @@
+// HBM-bound / tiny kernels of the cGAN WGAN-GP step on gfx950: NCHW<->NHWC boundary packing,
+// the 512->1 k4 s1 p1 critic head (fwd/dgrad/wgrad), spectral-norm power iteration, gradient-penalty
+// norm, grad-norm clip + Adam over flat buffers, generator head (avg-pool + Linear + tanh), the
+// box/EIoU loss with its analytic gradient, and dropout mask generation.
+//
+// Reference lines replaced are cited per kernel (paths relative to the reference root).
+#include "common.h"
+
+namespace {
+
+bool bad_dtype(int dt) { return dt != GCSSL_F32 && dt != GCSSL_BF16; }
+
+// =========================================================================================
+// boundary: NCHW fp32 (B,3,S,S) pairs -> NHWC [B][S*S][8] (channels 0-2 = a, 3-5 = b, 6-7 = 0)
+// torch.cat([pred, other], 1) at cgan/models.py:257; interpolation at cgan/losses.py:203-204.
+// =========================================================================================
+template <typename T>
+__global__ void pack_pair_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                 const float* __restrict__ b2, const float* __restrict__ alpha,
+                                 T* __restrict__ out, int B, int HW) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * HW) return;
+    const int n = idx / HW, p = idx % HW;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float av = a[((size_t)n * 3 + c) * HW + p];
+        const float bv = b ? b[((size_t)n * 3 + c) * HW + p] : 0.f;
+        if (alpha) {   // alpha*real + (1-alpha)*fake, rounded op by op like the eager reference
+            const float al = alpha[n], om = __fsub_rn(1.0f, al);
+            const float fv = b2[((size_t)n * 3 + c) * HW + p];
+            v[c] = __fadd_rn(__fmul_rn(al, av), __fmul_rn(om, av));
+            v[3 + c] = __fadd_rn(__fmul_rn(al, bv), __fmul_rn(om, fv));
+        } else { v[c] = av; v[3 + c] = bv; }
+    }
+    v[6] = 0.f; v[7] = 0.f;
+    T* o = out + idx * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) Elem<T>::st(o + c, v[c]);
+}
+
+// NHWC8 fp32 gradient -> two NCHW (B,3,S,S) fp32 tensors (d/d pred, d/d other)
+__global__ void unpack_grad_kernel(const float* __restrict__ g, float* __restrict__ ga, float* __restrict__ gb,
+                                   int B, int HW) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * HW) return;
+    const int n = idx / HW, p = idx % HW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (ga) ga[((size_t)n * 3 + c) * HW + p] = g[idx * 8 + c];
+        if (gb) gb[((size_t)n * 3 + c) * HW + p] = g[idx * 8 + 3 + c];
+    }
+}
+
+// =========================================================================================
+// critic head: Conv2d(512,1,k4,s1,p1,bias=False)  cgan/models.py:252.  N=1 output channel -> HBM-bound.
+// w5p is the fp32 weight repacked [16][C].
+// =========================================================================================
+__global__ void prep_c5_kernel(const float* __restrict__ w, float* __restrict__ wp, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 16 * C) return;
+    const int ci = idx % C, tap = idx / C;
+    wp[idx] = w[(size_t)ci * 16 + tap];
+}
+
+// one wave per output element
+template <typename T>
+__global__ void c5_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ wp, float* __restrict__ out,
+                              int N, int Hi, int Wi, int C) {
+    const int Ho = Hi - 1, Wo = Wi - 1;
+    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wid >= N * Ho * Wo) return;
+    const int n = wid / (Ho * Wo), oy = (wid / Wo) % Ho, ox = wid % Wo;
+    float s = 0.f;
+    for (int ky = 0; ky < 4; ++ky) {
+        const int iy = oy - 1 + ky;
+        if ((unsigned)iy >= (unsigned)Hi) continue;
+        for (int kx = 0; kx < 4; ++kx) {
+            const int ix = ox - 1 + kx;
+            if ((unsigned)ix >= (unsigned)Wi) continue;
+            const T* xp = x + ((size_t)(n * Hi + iy) * Wi + ix) * ldx;
+            const float* wq = wp + (ky * 4 + kx) * C;
+            for (int c = lane; c < C; c += 64) s += Elem<T>::ld(xp + c) * wq[c];
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[wid] = s;
+}
+
+// dx[n,iy,ix,c] = sum_{oy,ox} dout(n,oy,ox) wp[(iy-oy+1)*4 + (ix-ox+1)][c];  dout tensor or per-group constant
+template <typename T>
+__global__ void c5_dgrad_kernel(const float* __restrict__ dout, float g0, float g1, float g2, int group_n,
+                                const float* __restrict__ wp, T* __restrict__ dx, int lddx, int N, int Hi, int Wi, int C) {
+    const int Ho = Hi - 1, Wo = Wi - 1;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * Hi * Wi * C) return;
+    const int c = idx % C; const size_t pix = idx / C;
+    const int ix = pix % Wi, iy = (pix / Wi) % Hi, n = pix / ((size_t)Wi * Hi);
+    float gconst = 0.f;
+    if (!dout) { const int g = n / group_n; gconst = g == 0 ? g0 : (g == 1 ? g1 : g2); }
+    float s = 0.f;
+    for (int ky = 0; ky < 4; ++ky) {
+        const int oy = iy + 1 - ky;
+        if ((unsigned)oy >= (unsigned)Ho) continue;
+        for (int kx = 0; kx < 4; ++kx) {
+            const int ox = ix + 1 - kx;
+            if ((unsigned)ox >= (unsigned)Wo) continue;
+            const float d = dout ? dout[((size_t)n * Ho + oy) * Wo + ox] : gconst;
+            s += d * wp[(ky * 4 + kx) * C + c];
+        }
+    }
+    Elem<T>::st(dx + pix * lddx + c, s);
+}
+
+// dw[c][tap] += sum_{n,oy,ox} dout(n,oy,ox) x[n,oy-1+ky,ox-1+kx,c]   (atomic over blockIdx.z sample chunks)
+template <typename T>
+__global__ void c5_wgrad_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ dout, float g0, float g1,
+                                float g2, int group_n, float* __restrict__ dw, int N, int Hi, int Wi, int C) {
+    const int Ho = Hi - 1, Wo = Wi - 1;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, tap = blockIdx.y;
+    if (c >= C) return;
+    const int ky = tap >> 2, kx = tap & 3;
+    const int per = (N + gridDim.z - 1) / gridDim.z;
+    const int nb = blockIdx.z * per, ne = min(N, nb + per);
+    float s = 0.f;
+    for (int n = nb; n < ne; ++n) {
+        float gconst = 0.f;
+        if (!dout) { const int g = n / group_n; gconst = g == 0 ? g0 : (g == 1 ? g1 : g2); if (gconst == 0.f) continue; }
+        for (int oy = 0; oy < Ho; ++oy) {
+            const int iy = oy - 1 + ky;
+            if ((unsigned)iy >= (unsigned)Hi) continue;
+            for (int ox = 0; ox < Wo; ++ox) {
+                const int ix = ox - 1 + kx;
+                if ((unsigned)ix >= (unsigned)Wi) continue;
+                const float d = dout ? dout[((size_t)n * Ho + oy) * Wo + ox] : gconst;
+                s += d * Elem<T>::ld(x + ((size_t)(n * Hi + iy) * Wi + ix) * ldx + c);
+            }
+        }
+    }
+    atomicAdd(dw + (size_t)c * 16 + tap, s);
+}
+
+// =========================================================================================
+// spectral norm power iteration (legacy torch.nn.utils.spectral_norm as used at cgan/models.py:237-238):
+//   v <- normalize(W^T u), u <- normalize(W v)  (eps 1e-12), sigma = u . (W v).   Up to 4 layers per launch.
+// =========================================================================================
+struct SnLayer { const float* w; float* u; float* v; float* t; float* s; int rows, cols; };
+struct SnBatch { SnLayer l[4]; int nl; float* sigma; float* isig; float* u_hist; float* v_hist; int hist_stride_u, hist_stride_v; int slot, nslots; };
+
+// t = W^T u : block = 64 columns x 4 row groups
+__global__ __launch_bounds__(256) void sn_wtu_kernel(SnBatch b) {
+    const SnLayer L = b.l[blockIdx.y];
+    __shared__ float sm[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + tx;
+    if (blockIdx.x * 64 >= L.cols) return;
+    float s = 0.f;
+    if (col < L.cols)
+        for (int r = ty; r < L.rows; r += 4) s += L.w[(size_t)r * L.cols + col] * L.u[r];
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && col < L.cols) L.t[col] = sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx];
+}
+
+// s = W (t / max(|t|, eps)); block 0 also publishes v.  One wave per row, 4 rows per block.
+__global__ __launch_bounds__(256) void sn_wv_kernel(SnBatch b) {
+    const SnLayer L = b.l[blockIdx.y];
+    __shared__ float red[4];
+    if ((int)blockIdx.x * 4 >= L.rows) return;
+    float q = 0.f;
+    for (int c = threadIdx.x; c < L.cols; c += 256) { const float t = L.t[c]; q += t * t; }
+    const float nt = sqrtf(block_sum<4>(q, red));
+    const float inv = 1.f / fmaxf(nt, 1e-12f);
+    if (blockIdx.x == 0) {
+        float* vh = b.v_hist + ((size_t)blockIdx.y * b.nslots + b.slot) * b.hist_stride_v;
+        for (int c = threadIdx.x; c < L.cols; c += 256) { const float vv = L.t[c] * inv; L.v[c] = vv; vh[c] = vv; }
+    }
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= L.rows) return;
+    float s = 0.f;
+    for (int c = lane; c < L.cols; c += 64) s += L.w[(size_t)row * L.cols + c] * (L.t[c] * inv);
+    s = wave_sum(s);
+    if (lane == 0) L.s[row] = s;
+}
+
+// u = s / max(|s|, eps); sigma = u . s
+__global__ __launch_bounds__(256) void sn_fin_kernel(SnBatch b) {
+    const SnLayer L = b.l[blockIdx.x];
+    __shared__ float red[4];
+    float q = 0.f;
+    for (int r = threadIdx.x; r < L.rows; r += 256) { const float s = L.s[r]; q += s * s; }
+    const float ss = block_sum<4>(q, red);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    float* uh = b.u_hist + ((size_t)blockIdx.x * b.nslots + b.slot) * b.hist_stride_u;
+    for (int r = threadIdx.x; r < L.rows; r += 256) { const float uu = L.s[r] * inv; L.u[r] = uu; uh[r] = uu; }
+    if (threadIdx.x == 0) {
+        const float sg = ss * inv;
+        b.sigma[blockIdx.x * b.nslots + b.slot] = sg;
+        b.isig[blockIdx.x * b.nslots + b.slot] = 1.f / sg;
+    }
+}
+
+// eval mode: sigma = u . (W v) with the stored u, v (no iteration)
+__global__ __launch_bounds__(256) void sn_sigma_kernel(SnBatch b) {
+    const SnLayer L = b.l[blockIdx.x];
+    __shared__ float red[4];
+    float q = 0.f;
+    for (int r = threadIdx.x >> 6; r < L.rows; r += 4) {
+        float s = 0.f;
+        for (int c = threadIdx.x & 63; c < L.cols; c += 64) s += L.w[(size_t)r * L.cols + c] * L.v[c];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) q += s * L.u[r];
+    }
+    const float sg = block_sum<4>(q, red);
+    if (threadIdx.x == 0) { b.sigma[blockIdx.x * b.nslots + b.slot] = sg; b.isig[blockIdx.x * b.nslots + b.slot] = 1.f / sg; }
+}
+
+// =========================================================================================
+// gradient penalty norm  cgan/losses.py:223-231:  nrm_b = sqrt(sum g^2 + 1e-12); gp = mean((nrm-1)^2)
+// also emits coef_b = lambda_gp * 2/B * (nrm_b-1)/nrm_b, the adjoint seed of the reverse pass.
+// =========================================================================================
+__global__ __launch_bounds__(256) void gp_norm_kernel(const float* __restrict__ g, size_t per_sample, int B, float lambda_gp,
+                                                     float* __restrict__ nrm, float* __restrict__ coef, float* gp_sum) {
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    const float* p = g + (size_t)n * per_sample;
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < per_sample; i += 256) { const float v = p[i]; s += v * v; }
+    const float tot = block_sum<4>(s, red);
+    if (threadIdx.x == 0) {
+        const float nr = sqrtf(tot + 1e-12f);
+        nrm[n] = nr;
+        coef[n] = lambda_gp * (2.0f / B) * (nr - 1.f) / nr;
+        atomicAdd(gp_sum, (nr - 1.f) * (nr - 1.f) / B);
+    }
+}
+
+template <typename T>
+__global__ void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ coef, T* __restrict__ y,
+                                  size_t per_sample, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    Elem<T>::st(y + i, x[i] * coef[i / per_sample]);
+}
+
+// =========================================================================================
+// clip_grad_norm_(max_norm) + Adam over flat fp32 buffers
+// (torch.nn.utils.clip_grad_norm_ + torch.optim.Adam at cgan/cgan_train_enhanced.py:256-257,331-332,368-369)
+// =========================================================================================
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const double v = g[i]; s += v * v; }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// state[0] = step count (as float64), state[1] = sum of squares of the gradient, state[2] = last total norm
+__global__ void adam_tick_kernel(double* state) { state[0] += 1.0; state[2] = sqrt(state[1]); }
+
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, const double* __restrict__ state, float lr, float b1, float b2, float eps,
+                            float max_norm, int write_clipped) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double t = state[0];
+    const float total = (float)sqrt(state[1]);
+    const float coef = fminf(1.0f, max_norm / (total + 1e-6f));
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+    const float gi = g[i] * coef;
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);             // lerp_, as torch's single-tensor Adam
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+    if (write_clipped) g[i] = gi;
+}
+
+// =========================================================================================
+// generator head  cgan/models.py:118-123,139-141: mean over H*W -> Linear(64,4) -> tanh -> * delta_scale
+// =========================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void pool_fc_tanh_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float scale, float* __restrict__ pooled,
+                                                          float* __restrict__ traw, float* __restrict__ delta, int HW) {
+    __shared__ float sm[4][64];
+    __shared__ float pl[64];
+    const int n = blockIdx.x, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const T* xp = x + (size_t)n * HW * ldx + tx;
+    float s = 0.f;
+    for (int p = ty; p < HW; p += 4) s += Elem<T>::ld(xp + (size_t)p * ldx);
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0) { const float pm = (sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx]) / HW; pl[tx] = pm; pooled[(size_t)n * 64 + tx] = pm; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float y = bias[threadIdx.x];
+        for (int c = 0; c < 64; ++c) y += w[threadIdx.x * 64 + c] * pl[c];
+        const float t = tanhf(y);
+        traw[n * 4 + threadIdx.x] = t;
+        delta[n * 4 + threadIdx.x] = t * scale;
+    }
+}
+
+// head backward: dy = g_delta*scale*(1-t^2); dW = dy^T pooled; db = sum dy; da_bcast[n][c] = (dy W)[c] / HW
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ g_delta, const float* __restrict__ traw,
+                                                      const float* __restrict__ pooled, const float* __restrict__ w, float scale,
+                                                      int B, int HW, float* __restrict__ dw, float* __restrict__ db,
+                                                      float* __restrict__ da_bcast) {
+    // single block: 256 threads = 4 outputs x 64 channels
+    const int j = threadIdx.x >> 6, c = threadIdx.x & 63;
+    float acc = 0.f, accb = 0.f;
+    for (int n = 0; n < B; ++n) {
+        const float t = traw[n * 4 + j];
+        const float dy = g_delta[n * 4 + j] * scale * (1.f - t * t);
+        acc += dy * pooled[(size_t)n * 64 + c];
+        accb += dy;
+    }
+    dw[j * 64 + c] = acc;
+    if (c == 0) db[j] = accb;
+    for (int n = j; n < B; n += 4) {
+        float s = 0.f;
+        for (int k = 0; k < 4; ++k) { const float t = traw[n * 4 + k]; s += g_delta[n * 4 + k] * scale * (1.f - t * t) * w[k * 64 + c]; }
+        da_bcast[(size_t)n * 64 + c] = s / HW;
+    }
+}
+
+// =========================================================================================
+// apply_delta_to_bbox (train) + EIoU loss + analytic gradient wrt delta.  cgan/losses.py:19-73,99-150.
+// One thread per sample; loss_sum += (1 - eiou_n)/B... (loss = 1 - mean(eiou)): accumulates -eiou/B, caller adds 1.
+// =========================================================================================
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ void sclamp(float x, float lo, float hi, float& val, float& der) {
+    const float s = sigm((x - (lo + hi) * 0.5f) / 0.5f);
+    val = lo + (hi - lo) * s; der = (hi - lo) * s * (1.f - s) / 0.5f;
+}
+__device__ void apply_delta_train(const float* box, const float* d, float* out, float* jac) {
+    float dc[4], ddc[4];
+    for (int k = 0; k < 4; ++k) sclamp(d[k], -1.5f, 1.5f, dc[k], ddc[k]);
+    const float cx0 = box[0] + dc[0] * box[2], cy0 = box[1] + dc[1] * box[3];
+    const float e2 = fminf(fmaxf(dc[2], -1.f), 1.f), e3 = fminf(fmaxf(dc[3], -1.f), 1.f);
+    const float in2 = (dc[2] >= -1.f && dc[2] <= 1.f) ? 1.f : 0.f, in3 = (dc[3] >= -1.f && dc[3] <= 1.f) ? 1.f : 0.f;
+    const float w0 = box[2] * expf(e2), h0 = box[3] * expf(e3);
+    float dcx, dcy, dw, dh;
+    sclamp(cx0, 0.05f, 0.95f, out[0], dcx); sclamp(cy0, 0.05f, 0.95f, out[1], dcy);
+    sclamp(w0, 0.02f, 0.8f, out[2], dw); sclamp(h0, 0.02f, 0.8f, out[3], dh);
+    if (jac) { jac[0] = dcx * box[2] * ddc[0]; jac[1] = dcy * box[3] * ddc[1]; jac[2] = dw * w0 * in2 * ddc[2]; jac[3] = dh * h0 * in3 * ddc[3]; }
+}
+__device__ __forceinline__ float selmax(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
+__device__ __forceinline__ float selmin(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
+
+__global__ void eiou_kernel(const float* __restrict__ pred_box, const float* __restrict__ delta, const float* __restrict__ delta_true,
+                            int B, float lambda_iou, float* __restrict__ g_delta, float* __restrict__ cal, float* loss_acc) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= B) return;
+    const float eps = 1e-6f;
+    float p[4], t[4], jac[4];
+    apply_delta_train(pred_box + n * 4, delta + n * 4, p, jac);
+    apply_delta_train(pred_box + n * 4, delta_true + n * 4, t, nullptr);
+    const float px1 = p[0] - p[2] / 2, px2 = p[0] + p[2] / 2, py1 = p[1] - p[3] / 2, py2 = p[1] + p[3] / 2;
+    const float tx1 = t[0] - t[2] / 2, tx2 = t[0] + t[2] / 2, ty1 = t[1] - t[3] / 2, ty2 = t[1] + t[3] / 2;
+    const float iwr = fminf(px2, tx2) - fmaxf(px1, tx1), ihr = fminf(py2, ty2) - fmaxf(py1, ty1);
+    const float iw = fmaxf(iwr, 0.f), ih = fmaxf(ihr, 0.f);
+    const float inter = iw * ih;
+    const float parea = (px2 - px1) * (py2 - py1), tarea = (tx2 - tx1) * (ty2 - ty1);
+    const float uni = parea + tarea - inter + eps;
+    const float iou = inter / uni;
+    const float ew = fmaxf(px2, tx2) - fminf(px1, tx1), eh = fmaxf(py2, ty2) - fminf(py1, ty1);
+    const float c2 = ew * ew + eh * eh + eps;
+    const float rho2 = (p[0] - t[0]) * (p[0] - t[0]) + (p[1] - t[1]) * (p[1] - t[1]);
+    const float dw2 = (p[2] - t[2]) * (p[2] - t[2]), dh2 = (p[3] - t[3]) * (p[3] - t[3]);
+    const float cw = ew * ew + eps, chh = eh * eh + eps;
+    const float eiou = iou - rho2 / c2 - dw2 / cw - dh2 / chh;
+    atomicAdd(loss_acc, -eiou / B);
+    for (int k = 0; k < 4; ++k) cal[n * 4 + k] = p[k];
+    // gradient of eiou wrt the corners
+    const float g_iw = ih * (iwr >= 0.f ? 1.f : 0.f), g_ih = iw * (ihr >= 0.f ? 1.f : 0.f);
+    const float di = 1.f / uni + inter / (uni * uni), dpa = -inter / (uni * uni);
+    float gx1 = di * g_iw * (-selmax(px1, tx1)), gx2 = di * g_iw * selmin(px2, tx2);
+    float gy1 = di * g_ih * (-selmax(py1, ty1)), gy2 = di * g_ih * selmin(py2, ty2);
+    gx1 += dpa * (-(py2 - py1)); gx2 += dpa * (py2 - py1);
+    gy1 += dpa * (-(px2 - px1)); gy2 += dpa * (px2 - px1);
+    const float g_ew = rho2 / (c2 * c2) * 2.f * ew + dw2 / (cw * cw) * 2.f * ew;
+    const float g_eh = rho2 / (c2 * c2) * 2.f * eh + dh2 / (chh * chh) * 2.f * eh;
+    gx1 += g_ew * (-selmin(px1, tx1)); gx2 += g_ew * selmax(px2, tx2);
+    gy1 += g_eh * (-selmin(py1, ty1)); gy2 += g_eh * selmax(py2, ty2);
+    float gb[4];
+    gb[0] = gx1 + gx2 - 2.f * (p[0] - t[0]) / c2;
+    gb[1] = gy1 + gy2 - 2.f * (p[1] - t[1]) / c2;
+    gb[2] = 0.5f * (gx2 - gx1) - 2.f * (p[2] - t[2]) / cw;
+    gb[3] = 0.5f * (gy2 - gy1) - 2.f * (p[3] - t[3]) / chh;
+    for (int k = 0; k < 4; ++k) g_delta[n * 4 + k] = lambda_iou * gb[k] * (-1.0f / B) * jac[k];
+}
+
+// =========================================================================================
+// dropout keep-masks (Bernoulli 0.5), counter-based hash (splitmix64) -- nn.Dropout(0.5) cgan/models.py:106,109,110
+// =========================================================================================
+__global__ void mask_gen_kernel(uint8_t* __restrict__ out, size_t n, uint64_t seed, const double* counter) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t x = (uint64_t)i + seed * 0x9E3779B97F4A7C15ull + (counter ? (uint64_t)counter[0] * 0xD1B54A32D192ED03ull : 0ull);
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    out[i] = (uint8_t)((x >> 40) & 1);
+}
+
+// mean of each of `groups` equal chunks of x
+__global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict__ x, int per_group, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < per_group; i += 256) s += x[(size_t)blockIdx.x * per_group + i];
+    const float tot = block_sum<4>(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot / per_group;
+}
+
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ x, T* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) Elem<T>::st(y + i, x[i]);
+}
+template <typename T>
+__global__ void uncast_kernel(const T* __restrict__ x, float* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = Elem<T>::ld(x + i);
+}
+
+}  // namespace
+
+#define GRID1(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256), 0, (hipStream_t)stream
+
+extern "C" {
+
+int gcssl_pack_pair(int dtype, const float* a, const float* b, void* out, int B, int S, void* stream) {
+    if (!a || !out) return GCSSL_ENULL;
+    if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (B <= 0 || S <= 0) return GCSSL_EBADSHAPE;
+    const size_t n = (size_t)B * S * S;
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(pack_pair_kernel<float>, GRID1(n), a, b, nullptr, nullptr, (float*)out, B, S * S);
+    else hipLaunchKernelGGL(pack_pair_kernel<bf16_t>, GRID1(n), a, b, nullptr, nullptr, (bf16_t*)out, B, S * S);
+    return gcssl_launch_status();
+}
+
+int gcssl_pack_interp(int dtype, const float* pred, const float* gt, const float* refined, const float* alpha,
+                      void* out, int B, int S, void* stream) {
+    if (!pred || !gt || !refined || !alpha || !out) return GCSSL_ENULL;
+    if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (B <= 0 || S <= 0) return GCSSL_EBADSHAPE;
+    const size_t n = (size_t)B * S * S;
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(pack_pair_kernel<float>, GRID1(n), pred, gt, refined, alpha, (float*)out, B, S * S);
+    else hipLaunchKernelGGL(pack_pair_kernel<bf16_t>, GRID1(n), pred, gt, refined, alpha, (bf16_t*)out, B, S * S);
+    return gcssl_launch_status();
+}
+
+int gcssl_unpack_grad(const float* g, float* ga, float* gb, int B, int S, void* stream) {
+    if (!g || (!ga && !gb)) return GCSSL_ENULL;
+    if (B <= 0 || S <= 0) return GCSSL_EBADSHAPE;
+    hipLaunchKernelGGL(unpack_grad_kernel, GRID1((size_t)B * S * S), g, ga, gb, B, S * S);
+    return gcssl_launch_status();
+}
+
+int gcssl_prep_c5_weight(const float* w, float* wp, int C, void* stream) {
+    if (!w || !wp) return GCSSL_ENULL;
+    if (C <= 0) return GCSSL_EBADSHAPE;
+    hipLaunchKernelGGL(prep_c5_kernel, GRID1(16 * C), w, wp, C);
+    return gcssl_launch_status();
+}
+
+int gcssl_conv4x4s1_c1_fwd(int dtype, const void* x, int ldx, const float* wp, float* out, int N, int Hi, int Wi,
+                           int C, void* stream) {
+    if (!x || !wp || !out) return GCSSL_ENULL;
+    if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || ldx < C) return GCSSL_EBADSHAPE;
+    const size_t threads = (size_t)N * (Hi - 1) * (Wi - 1) * 64;
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(c5_fwd_kernel<float>, GRID1(threads), (const float*)x, ldx, wp, out, N, Hi, Wi, C);
+    else hipLaunchKernelGGL(c5_fwd_kernel<bf16_t>, GRID1(threads), (const bf16_t*)x, ldx, wp, out, N, Hi, Wi, C);
+    return gcssl_launch_status();
+}
+
+int gcssl_conv4x4s1_c1_dgrad(int dtype, const float* dout, float g0, float g1, float g2, int group_n, const float* wp,
+                             void* dx, int lddx, int N, int Hi, int Wi, int C, void* stream) {
+    if (!wp || !dx) return GCSSL_ENULL;
+    if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || lddx < C || (!dout && group_n <= 0)) return GCSSL_EBADSHAPE;
+    const size_t n = (size_t)N * Hi * Wi * C;
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(c5_dgrad_kernel<float>, GRID1(n), dout, g0, g1, g2, group_n, wp, (float*)dx, lddx, N, Hi, Wi, C);
+    else hipLaunchKernelGGL(c5_dgrad_kernel<bf16_t>, GRID1(n), dout, g0, g1, g2, group_n, wp, (bf16_t*)dx, lddx, N, Hi, Wi, C);
+    return gcssl_launch_status();
+}
+
+int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dout, float g0, float g1, float g2,
+                             int group_n, float* dw, int N, int Hi, int Wi, int C, void* stream) {
+    if (!x || !dw) return GCSSL_ENULL;
+    if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || ldx < C || (!dout && group_n <= 0)) return GCSSL_EBADSHAPE;
+    int zs = N / 8; if (zs < 1) zs = 1; if (zs > 64) zs = 64;
+    dim3 grid((C + 255) / 256, 16, zs);
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(c5_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C);
+    else hipLaunchKernelGGL(c5_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C);
+    return gcssl_launch_status();
+}
+
+// One power iteration (or, with iterate=0, just sigma from the stored u,v) for nl <= 4 layers.
+// w[i]: [rows[i]][cols[i]] fp32; u/v updated in place; t/s: scratch (cols / rows floats).
+// sigma/isig: [nl][nslots]; u_hist: [nl][nslots][hist_stride_u]; v_hist likewise; this call fills slot `slot`.
+int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* const* v, float* const* t, float* const* s,
+                        const int* rows, const int* cols, float* sigma, float* isig, float* u_hist, float* v_hist,
+                        int hist_stride_u, int hist_stride_v, int slot, int nslots, int iterate, void* stream) {
+    if (!w || !u || !v || !t || !s || !rows || !cols || !sigma || !isig || !u_hist || !v_hist) return GCSSL_ENULL;
+    if (nl < 1 || nl > 4 || slot < 0 || slot >= nslots) return GCSSL_EBADSHAPE;
+    SnBatch b{};
+    int maxc = 0, maxr = 0;
+    for (int i = 0; i < nl; ++i) {
+        if (!w[i] || !u[i] || !v[i] || !t[i] || !s[i]) return GCSSL_ENULL;
+        if (rows[i] <= 0 || cols[i] <= 0 || rows[i] > hist_stride_u || cols[i] > hist_stride_v) return GCSSL_EBADSHAPE;
+        b.l[i] = SnLayer{w[i], u[i], v[i], t[i], s[i], rows[i], cols[i]};
+        if (cols[i] > maxc) maxc = cols[i];
+        if (rows[i] > maxr) maxr = rows[i];
+    }
+    b.nl = nl; b.sigma = sigma; b.isig = isig; b.u_hist = u_hist; b.v_hist = v_hist;
+    b.hist_stride_u = hist_stride_u; b.hist_stride_v = hist_stride_v; b.slot = slot; b.nslots = nslots;
+    hipStream_t st = (hipStream_t)stream;
+    if (iterate) {
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3((maxc + 63) / 64, nl), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(sn_wv_kernel, dim3((maxr + 3) / 4, nl), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(sn_fin_kernel, dim3(nl), dim3(256), 0, st, b);
+    } else {
+        hipLaunchKernelGGL(sn_sigma_kernel, dim3(nl), dim3(256), 0, st, b);
+    }
+    return gcssl_launch_status();
+}
+
+int gcssl_gp_norm(const float* g, long per_sample, int B, float lambda_gp, float* nrm, float* coef, float* gp_sum,
+                  void* stream) {
+    if (!g || !nrm || !coef || !gp_sum) return GCSSL_ENULL;
+    if (per_sample <= 0 || B <= 0) return GCSSL_EBADSHAPE;
+    hipLaunchKernelGGL(gp_norm_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, g, (size_t)per_sample, B, lambda_gp, nrm, coef, gp_sum);
+    return gcssl_launch_status();
+}
+
+int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long per_sample, int B, void* stream) {
+    if (!x || !coef || !y) return GCSSL_ENULL;
+    if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (per_sample <= 0 || B <= 0) return GCSSL_EBADSHAPE;
+    const size_t total = (size_t)per_sample * B;
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(scale_rows_kernel<float>, GRID1(total), x, coef, (float*)y, (size_t)per_sample, total);
+    else hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, GRID1(total), x, coef, (bf16_t*)y, (size_t)per_sample, total);
+    return gcssl_launch_status();
+}
+
+// state: 3 doubles {step, sumsq, last_total_norm}.  Caller zeroes state[1] before each use (gcssl_zero or memset).
+int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* state, float lr, float b1, float b2,
+                    float eps, float max_norm, int write_clipped, void* stream) {
+    if (!p || !g || !m || !v || !state) return GCSSL_ENULL;
+    if (n <= 0) return GCSSL_EBADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(state + 1, 0, sizeof(double), st);
+    int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, (size_t)n, state + 1);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, state);
+    hipLaunchKernelGGL(adam_kernel, GRID1(n), p, g, m, v, (size_t)n, state, lr, b1, b2, eps, max_norm, write_clipped);
+    return gcssl_launch_status();
+}
+
+int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, const float* w, const float* bias, float scale,
+                           float* pooled, float* traw, float* delta, int B, int HW, int C, void* stream) {
+    if (!x || !w || !bias || !pooled || !traw || !delta) return GCSSL_ENULL;
+    if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (B <= 0 || HW <= 0 || C != 64 || ldx < C) return GCSSL_EBADSHAPE;
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(pool_fc_tanh_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, w, bias, scale, pooled, traw, delta, HW);
+    else hipLaunchKernelGGL(pool_fc_tanh_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, w, bias, scale, pooled, traw, delta, HW);
+    return gcssl_launch_status();
+}
+
+int gcssl_head_bwd(const float* g_delta, const float* traw, const float* pooled, const float* w, float scale, int B,
+                   int HW, float* dw, float* db, float* da_bcast, void* stream) {
+    if (!g_delta || !traw || !pooled || !w || !dw || !db || !da_bcast) return GCSSL_ENULL;
+    if (B <= 0 || HW <= 0) return GCSSL_EBADSHAPE;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, g_delta, traw, pooled, w, scale, B, HW, dw, db, da_bcast);
+    return gcssl_launch_status();
+}
+
+// loss_acc must be zeroed by the caller; afterwards loss = 1 + *loss_acc
+int gcssl_eiou_fwd_bwd(const float* pred_box, const float* delta, const float* delta_true, int B, float lambda_iou,
+                       float* g_delta, float* calibrated, float* loss_acc, void* stream) {
+    if (!pred_box || !delta || !delta_true || !g_delta || !calibrated || !loss_acc) return GCSSL_ENULL;
+    if (B <= 0) return GCSSL_EBADSHAPE;
+    hipLaunchKernelGGL(eiou_kernel, GRID1(B), pred_box, delta, delta_true, B, lambda_iou, g_delta, calibrated, loss_acc);
+    return gcssl_launch_status();
+}
+
+int gcssl_dropout_mask_gen(uint8_t* out, long n, unsigned long long seed, const double* counter, void* stream) {
+    if (!out) return GCSSL_ENULL;
+    if (n <= 0) return GCSSL_EBADSHAPE;
+    hipLaunchKernelGGL(mask_gen_kernel, GRID1(n), out, (size_t)n, (uint64_t)seed, counter);
+    return gcssl_launch_status();
+}
+
+int gcssl_group_mean(const float* x, int groups, int per_group, float* out, void* stream) {
+    if (!x || !out) return GCSSL_ENULL;
+    if (groups <= 0 || per_group <= 0) return GCSSL_EBADSHAPE;
+    hipLaunchKernelGGL(group_mean_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, x, per_group, out);
+    return gcssl_launch_status();
+}
+
+int gcssl_cast(int dtype, const float* x, void* y, long n, void* stream) {
+    if (!x || !y) return GCSSL_ENULL;
+    if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (n <= 0) return GCSSL_EBADSHAPE;
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(cast_kernel<float>, GRID1(n), x, (float*)y, (size_t)n);
+    else hipLaunchKernelGGL(cast_kernel<bf16_t>, GRID1(n), x, (bf16_t*)y, (size_t)n);
+    return gcssl_launch_status();
+}
+
+int gcssl_uncast(int dtype, const void* x, float* y, long n, void* stream) {
+    if (!x || !y) return GCSSL_ENULL;
+    if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (n <= 0) return GCSSL_EBADSHAPE;
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(uncast_kernel<float>, GRID1(n), (const float*)x, y, (size_t)n);
+    else hipLaunchKernelGGL(uncast_kernel<bf16_t>, GRID1(n), (const bf16_t*)x, y, (size_t)n);
+    return gcssl_launch_status();
+}
+
+const char* gcssl_version(void) { return "gcssl-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

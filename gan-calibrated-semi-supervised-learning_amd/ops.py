@@ -1,0 +1,196 @@
+"""Thin launch wrappers over the C ABI (include/gcssl.h).  They only marshal arguments: every tensor here is a
+caller-owned device buffer, activations are NHWC views `[N][H][W][C]` (possibly channel slices of a wider
+buffer: the pixel stride is taken from ``t.stride(2)``), and nothing is allocated or synchronised.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import call
+
+LRELU, RELU = 1, 2
+
+
+def _ld(t: torch.Tensor) -> int:
+    """pixel stride (elements) of an NHWC view; requires the view to be dense in (n,h,w) and unit stride in c."""
+    assert t.dim() == 4 and t.stride(3) == 1, "expected an NHWC view with contiguous channels"
+    ld = t.stride(2)
+    assert t.stride(1) == ld * t.shape[2] and t.stride(0) == ld * t.shape[2] * t.shape[1], "non-dense NHWC view"
+    return ld
+
+
+def code(t: torch.Tensor) -> int:
+    return _lib.dtype_code(t.dtype)
+
+
+# ---- boundary
+def pack_pair(a, b, out):
+    B, _, S, _ = a.shape
+    call("gcssl_pack_pair", code(out), a, b, out, B, S)
+
+
+def pack_interp(pred, gt, refined, alpha, out):
+    B, _, S, _ = pred.shape
+    call("gcssl_pack_interp", code(out), pred, gt, refined, alpha, out, B, S)
+
+
+def unpack_grad(g, ga, gb):
+    B, S = g.shape[0], g.shape[1]
+    call("gcssl_unpack_grad", g, ga, gb, B, S)
+
+
+# ---- weights
+def prep_conv_weight(w, wf, wt, cout, cin, cinp, dt):
+    call("gcssl_prep_conv_weight", dt, w, wf, wt, cout, cin, cinp)
+
+
+def prep_c5_weight(w, wp):
+    call("gcssl_prep_c5_weight", w, wp, wp.shape[1])
+
+
+# ---- conv k4 s2 p1
+def conv_fwd(x, wf, y, cin, cout, bias=None, gscale=None, group_n=0, act=0):
+    N, Hi, Wi, _ = x.shape
+    call("gcssl_conv4x4s2_fwd", code(x), x, _ld(x), wf, bias, gscale, group_n, y, _ld(y), N, Hi, Wi, cin, cout, act)
+
+
+def conv_dgrad(dy, wt, dx, cin, cout, gscale=None, group_n=0):
+    """dx: [N][Hi][Wi][>=cin] (fp32 output allowed whatever dy's dtype), dy: [N][Hi/2][Wi/2][>=cout]."""
+    N, Hi, Wi, _ = dx.shape
+    out_f32 = 1 if (dx.dtype == torch.float32 and dy.dtype != torch.float32) else 0
+    call("gcssl_conv4x4s2_dgrad", code(dy), dy, _ld(dy), wt, gscale, group_n, dx, _ld(dx), N, Hi, Wi, cin, cout, out_f32)
+
+
+def wgrad_splits(N, Hi, Wi, cin, cout) -> int:
+    r = _lib.call_nostream("gcssl_conv4x4s2_wgrad_splits", N, Hi, Wi, cin, cout)
+    if r <= 0:
+        raise RuntimeError(f"gcssl_conv4x4s2_wgrad_splits: bad geometry {(N, Hi, Wi, cin, cout)}")
+    return r
+
+
+def conv_wgrad(x, dy, slab, cin, cout):
+    N, Hi, Wi, _ = x.shape
+    call("gcssl_conv4x4s2_wgrad", code(x), x, _ld(x), dy, _ld(dy), slab, N, Hi, Wi, cin, cout)
+
+
+def wgrad_reduce(slab, nsplit, dw, cout, cin, cin_real, coef=None, cscale=None, u=None, v=None, nrank=0,
+                 accumulate=False):
+    """u, v: 2-D [nrank][>=cout] / [nrank][>=cin_real*16] (row strides are taken from the tensors)."""
+    call("gcssl_wgrad_reduce", slab, nsplit, dw, cout, cin, cin_real, coef, cscale, u,
+         u.stride(0) if u is not None else 0, v, v.stride(0) if v is not None else 0, nrank, int(accumulate))
+
+
+# ---- critic head
+def c5_fwd(x, wp, out):
+    N, Hi, Wi, _ = x.shape
+    call("gcssl_conv4x4s1_c1_fwd", code(x), x, _ld(x), wp, out, N, Hi, Wi, wp.shape[1])
+
+
+def c5_dgrad(dx, wp, dout=None, consts=(0.0, 0.0, 0.0), group_n=1):
+    N, Hi, Wi, _ = dx.shape
+    call("gcssl_conv4x4s1_c1_dgrad", code(dx), dout, float(consts[0]), float(consts[1]), float(consts[2]), group_n,
+         wp, dx, _ld(dx), N, Hi, Wi, wp.shape[1])
+
+
+def c5_wgrad(x, dw, C, dout=None, consts=(0.0, 0.0, 0.0), group_n=1):
+    """dw: fp32 [C][16] (PyTorch layout of the [1][C][4][4] weight), accumulated atomically."""
+    N, Hi, Wi, _ = x.shape
+    call("gcssl_conv4x4s1_c1_wgrad", code(x), x, _ld(x), dout, float(consts[0]), float(consts[1]), float(consts[2]),
+         group_n, dw, N, Hi, Wi, C)
+
+
+# ---- norm / activation
+def in_act_fwd(z, a, mean, rstd, C, act, mask=None):
+    N, H, W, _ = z.shape
+    call("gcssl_in_act_fwd", code(z), z, _ld(z), a, _ld(a), mean, rstd, mask, N, H * W, C, act)
+
+
+def in_act_bwd(z, mean, rstd, dzs, C, act, da=None, da2=None, da_bcast=None, mask=None, zt=None, zt_n0=0,
+               gscale=None, group_n=0, bias=None, dbias=None, cdot=None):
+    N, H, W, _ = z.shape
+    call("gcssl_in_act_bwd", code(z), da, _ld(da) if da is not None else 0, da2, _ld(da2) if da2 is not None else 0,
+         da_bcast, z, _ld(z), mean, rstd, mask, zt, zt_n0, gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot,
+         N, H * W, C, act)
+
+
+def in_dbl_bwd(gb_a, qz, gb_zs, z, mean, rstd, gt_a, zt, C, act, cdot=None):
+    N, H, W, _ = z.shape
+    call("gcssl_in_dbl_bwd", code(z), gb_a, _ld(gb_a), qz, _ld(qz), gb_zs, _ld(gb_zs) if gb_zs is not None else 0,
+         z, _ld(z), mean, rstd, gt_a, _ld(gt_a), zt, cdot, N, H * W, C, act)
+
+
+def act_bwd(da, a, dzs, C, da2=None, gscale=None, group_n=0, bias=None, dbias=None, cdot=None):
+    N, H, W, _ = a.shape
+    call("gcssl_act_bwd", code(a), da, _ld(da), da2, _ld(da2) if da2 is not None else 0, a, _ld(a), gscale, group_n,
+         bias, dzs, _ld(dzs), dbias, cdot, N, H * W, C)
+
+
+def dot_accum(x, y, C, out):
+    N, H, W, _ = x.shape
+    call("gcssl_dot_accum", code(x), x, _ld(x), y, _ld(y), N * H * W, C, out)
+
+
+# ---- spectral norm
+class SnState:
+    """Argument block for gcssl_sn_power_iter over the critic's spectrally-normalised layers."""
+
+    def __init__(self, ws, us, vs, nslots, device):
+        self.n = len(ws)
+        self.rows = [w.shape[0] for w in ws]
+        self.cols = [w[0].numel() for w in ws]
+        self.ws, self.us, self.vs = ws, us, vs
+        self.t = [torch.empty(c, device=device) for c in self.cols]
+        self.s = [torch.empty(r, device=device) for r in self.rows]
+        self.nslots = nslots
+        self.su, self.sv = max(self.rows), max(self.cols)
+        self.sigma = torch.zeros(self.n, nslots, device=device)
+        self.isig = torch.zeros(self.n, nslots, device=device)
+        self.u_hist = torch.zeros(self.n, nslots, self.su, device=device)
+        self.v_hist = torch.zeros(self.n, nslots, self.sv, device=device)
+        self._rows, self._cols = _lib.int_array(self.rows), _lib.int_array(self.cols)
+        self.refresh_ptrs()
+
+    def refresh_ptrs(self):
+        self._w, self._u, self._v = _lib.ptr_array(self.ws), _lib.ptr_array(self.us), _lib.ptr_array(self.vs)
+        self._t, self._s = _lib.ptr_array(self.t), _lib.ptr_array(self.s)
+
+    def iterate(self, slot: int, iterate: bool = True):
+        call("gcssl_sn_power_iter", self.n, self._w, self._u, self._v, self._t, self._s, self._rows, self._cols,
+             self.sigma, self.isig, self.u_hist, self.v_hist, self.su, self.sv, slot, self.nslots, int(iterate))
+
+
+# ---- GP, optimiser, heads
+def gp_norm(g, B, lambda_gp, nrm, coef, gp_sum):
+    call("gcssl_gp_norm", g, g.numel() // B, B, float(lambda_gp), nrm, coef, gp_sum)
+
+
+def scale_rows(x, coef, y, B):
+    call("gcssl_scale_rows", code(y), x, coef, y, x.numel() // B, B)
+
+
+def clip_adam(p, g, m, v, state, lr, b1, b2, eps=1e-8, max_norm=1.0, write_clipped=False):
+    call("gcssl_clip_adam", p, g, m, v, p.numel(), state, float(lr), float(b1), float(b2), float(eps),
+         float(max_norm), int(write_clipped))
+
+
+def pool_fc_tanh_fwd(x, w, bias, scale, pooled, traw, delta):
+    N, H, W, _ = x.shape
+    call("gcssl_pool_fc_tanh_fwd", code(x), x, _ld(x), w, bias, float(scale), pooled, traw, delta, N, H * W, 64)
+
+
+def head_bwd(g_delta, traw, pooled, w, scale, B, HW, dw, db, da_bcast):
+    call("gcssl_head_bwd", g_delta, traw, pooled, w, float(scale), B, HW, dw, db, da_bcast)
+
+
+def eiou_fwd_bwd(pred_box, delta, delta_true, lambda_iou, g_delta, calibrated, loss_acc):
+    call("gcssl_eiou_fwd_bwd", pred_box, delta, delta_true, pred_box.shape[0], float(lambda_iou), g_delta,
+         calibrated, loss_acc)
+
+
+def dropout_mask_gen(out, seed, counter=None):
+    call("gcssl_dropout_mask_gen", out, out.numel(), int(seed), counter)
+
+
+def group_mean(x, groups, out):
+    call("gcssl_group_mean", x, groups, x.numel() // groups, out)

@@ -1,0 +1,138 @@
+/* gcssl.h -- C ABI of libgcssl_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the hot path of
+ * 1213ray/GAN-Calibrated-Semi-Supervised-Learning, i.e. the WGAN-GP cGAN training step
+ * (reference: cgan/cgan_train_enhanced.py:304-369, cgan/models.py, cgan/losses.py).
+ *
+ * The reference has NO native/FFI boundary: its hot path is stock torch.nn ops.  Each entry
+ * point below therefore cites the reference op (file:line) it replaces.  Conventions:
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer owned by the caller
+ *     (including all workspaces); the library keeps no device state.
+ *   - `stream` is a hipStream_t; kernels are only enqueued on it, never synchronised (graph-capture safe).
+ *   - return value: 0 ok; <0 argument error (GCSSL_E*); >0 a hipError_t from the launch.  Never throws.
+ *   - dtype: element type of activations/operands (GCSSL_F32 exact-fp32 MFMA, GCSSL_BF16 bf16 MFMA with fp32
+ *     accumulation).  Statistics, losses, weight gradients, master weights and optimiser state are always fp32.
+ *   - activations are NHWC: tensor[n][y][x][c] with an explicit pixel stride `ld*` (elements) so a kernel can
+ *     read/write a channel slice of a concat buffer in place; spatial sizes and channel counts are powers of 2.
+ */
+#ifndef GCSSL_H
+#define GCSSL_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCSSL_OK 0
+#define GCSSL_EBADSHAPE (-1)
+#define GCSSL_EBADDTYPE (-2)
+#define GCSSL_EALIGN (-3)
+#define GCSSL_ENULL (-4)
+#define GCSSL_F32 0
+#define GCSSL_BF16 1
+
+const char* gcssl_version(void);
+
+/* ---- boundary packing ------------------------------------------------------------------------------------
+ * torch.cat([pred_patch, other_patch], 1) (cgan/models.py:257): two NCHW fp32 (B,3,S,S) tensors -> NHWC
+ * [B][S*S][8] (channels 0-2 = a, 3-5 = b (zeros if b==NULL), 6-7 = 0). */
+int gcssl_pack_pair(int dtype, const float* a, const float* b, void* out, int B, int S, void* stream);
+/* interpolation alpha*real + (1-alpha)*fake of both halves (cgan/losses.py:203-204), alpha: [B]. */
+int gcssl_pack_interp(int dtype, const float* pred, const float* gt, const float* refined, const float* alpha,
+                      void* out, int B, int S, void* stream);
+/* NHWC8 fp32 input-gradient -> the two NCHW (B,3,S,S) gradients torch.autograd.grad returns (cgan/losses.py:213). */
+int gcssl_unpack_grad(const float* g, float* ga, float* gb, int B, int S, void* stream);
+
+/* ---- weights -----------------------------------------------------------------------------------------------
+ * fp32 PyTorch-layout conv weight [Cout][Cin][4][4] -> packed MFMA operand layouts in `dtype`:
+ * wf [Cout][16][CinP] (forward GEMM) and wt [CinP][16][Cout] (dgrad GEMM); channels Cin..CinP-1 are zero.
+ * For a ConvTranspose2d weight [CinT][CoutT][4][4] pass Cout=CinT, Cin=CoutT.  Either output may be NULL. */
+int gcssl_prep_conv_weight(int dtype, const float* w, void* wf, void* wt, int Cout, int Cin, int CinP, void* stream);
+/* critic head weight [1][C][4][4] -> fp32 [16][C]. */
+int gcssl_prep_c5_weight(const float* w, float* wp, int C, void* stream);
+
+/* ---- Conv2d(k4,s2,p1): cgan/models.py:57 (G.down*), :236 (D.c1-c4) -------------------------------------------
+ * y[n,oy,ox,co] = act( gscale[n/group_n] * conv(x, W)[...] + bias[co] );  x [N][Hi][Wi][ldx>=Cin], y [N][Hi/2][Wi/2][ldy>=Cout].
+ * bias, gscale nullable; act: 0 none, 1 LeakyReLU(0.2) (cgan/models.py:60,242).  gscale carries 1/sigma of the
+ * spectral norm (cgan/models.py:237-238) per sample group.  Also serves the data-gradient of ConvTranspose2d. */
+int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const float* bias, const float* gscale,
+                        int group_n, void* y, int ldy, int N, int Hi, int Wi, int Cin, int Cout, int act, void* stream);
+/* data gradient of the conv == ConvTranspose2d(k4,s2,p1) forward (cgan/models.py:72,113):
+ * dx[N][Hi][Wi][lddx>=Cin] = gscale * convT(dy[N][Hi/2][Wi/2][lddy>=Cout], W).  out_f32: write fp32 whatever dtype. */
+int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, const float* gscale, int group_n,
+                          void* dx, int lddx, int N, int Hi, int Wi, int Cin, int Cout, int out_f32, void* stream);
+/* weight gradient: slab[s][Cout][16][Cin] (fp32, s < gcssl_conv4x4s2_wgrad_splits(...)) partial sums over the
+ * s-th K range of sum_{n,oy,ox} dy[n,oy,ox,co] x[n,2oy-1+ky,2ox-1+kx,ci].  Cin is 8 (padded first layer) or >= 64. */
+int gcssl_conv4x4s2_wgrad_splits(int N, int Hi, int Wi, int Cin, int Cout);
+int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, float* slab, int N, int Hi,
+                          int Wi, int Cin, int Cout, void* stream);
+/* dw[Cout][Cin_real][4][4] (=|+=) sum_s slab[s] - sum_k coef[k]*cscale[k] u_k[co] v_k[ci*16+tap]: split-K reduction
+ * fused with the spectral-norm quotient rule d(W/sigma) (sigma = u^T W v; cgan/models.py:237-238).
+ * u: nrank rows of stride ustride (>= Cout); v: nrank rows of stride vstride (>= Cin_real*16); cscale nullable. */
+int gcssl_wgrad_reduce(const float* slab, int nsplit, float* dw, int Cout, int Cin, int Cin_real, const float* coef,
+                       const float* cscale, const float* u, int ustride, const float* v, int vstride, int nrank,
+                       int accumulate, void* stream);
+
+/* ---- critic head Conv2d(512,1,k4,s1,p1,bias=False): cgan/models.py:252 ------------------------------------------
+ * out [N][Hi-1][Wi-1] fp32.  dgrad/wgrad take either a dout tensor or per-group constants g0,g1,g2 (dout==NULL):
+ * the WGAN seeds -1/(B hw), +1/(B hw) of cgan/cgan_train_enhanced.py:327-328 and the ones of cgan/losses.py:216. */
+int gcssl_conv4x4s1_c1_fwd(int dtype, const void* x, int ldx, const float* wp, float* out, int N, int Hi, int Wi, int C, void* stream);
+int gcssl_conv4x4s1_c1_dgrad(int dtype, const float* dout, float g0, float g1, float g2, int group_n, const float* wp,
+                             void* dx, int lddx, int N, int Hi, int Wi, int C, void* stream);
+int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dout, float g0, float g1, float g2, int group_n,
+                             float* dw, int N, int Hi, int Wi, int C, void* stream);   /* dw[C][16] += (atomic) */
+
+/* ---- InstanceNorm2d(affine=False, eps=1e-5) + activation (+Dropout): cgan/models.py:59-63,73-76,114,241-242 -----
+ * act: 1 LeakyReLU(0.2), 2 ReLU.  mask: dropout keep mask [N][HW][C] (uint8) or NULL; kept values are scaled by 2. */
+int gcssl_in_act_fwd(int dtype, const void* z, int ldz, void* a, int lda, float* mean, float* rstd, const uint8_t* mask,
+                     int N, int HW, int C, int act, void* stream);
+/* first-order backward: dn = act'(xhat) (da + da2 + da_bcast) [*2 keep]; dz = rstd (dn - mean dn - xhat mean(dn xhat))
+ * (+ zt for samples n >= zt_n0: the double-backward term); dzs = dz * gscale[n/group_n];
+ * dbias[c] += sum dz; cdot[n/group_n] += sum dz (z - bias[c])  (spectral-norm term).  Optional args nullable. */
+int gcssl_in_act_bwd(int dtype, const void* da, int ldda, const void* da2, int ldda2, const float* da_bcast,
+                     const void* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask, const void* zt,
+                     int zt_n0, const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias,
+                     float* cdot, int N, int HW, int C, int act, void* stream);
+/* second-order backward (create_graph=True, cgan/losses.py:213-220): adjoint of dz=IN_bwd(z, act'*gb_a) for an
+ * incoming adjoint qz: gt_a = act'(xhat) * d/d(dn), zt = d/dz; cdot += sum gb_zs*qz. */
+int gcssl_in_dbl_bwd(int dtype, const void* gb_a, int ldgb, const void* qz, int ldq, const void* gb_zs, int ldgz,
+                     const void* z, int ldz, const float* mean, const float* rstd, void* gt_a, int ldga, void* zt,
+                     float* cdot, int N, int HW, int C, int act, void* stream);
+/* LeakyReLU backward for the norm-less layers (D.c1, G.down1; cgan/models.py:103,246), from the activation OUTPUT a. */
+int gcssl_act_bwd(int dtype, const void* da, int ldda, const void* da2, int ldda2, const void* a, int lda,
+                  const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias, float* cdot,
+                  int N, int HW, int C, void* stream);
+int gcssl_dot_accum(int dtype, const void* x, int ldx, const void* y, int ldy, long pixels, int C, float* out, void* stream);
+
+/* ---- spectral norm power iteration (torch.nn.utils.spectral_norm, cgan/models.py:237-238) -----------------------
+ * v <- normalize(W^T u), u <- normalize(W v), eps 1e-12; sigma = u.(W v).  nl <= 4 layers per call; iterate=0 only
+ * evaluates sigma (eval mode).  History slot `slot` of u_hist/v_hist/sigma/isig receives this iteration's values. */
+int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* const* v, float* const* t, float* const* s,
+                        const int* rows, const int* cols, float* sigma, float* isig, float* u_hist, float* v_hist,
+                        int hist_stride_u, int hist_stride_v, int slot, int nslots, int iterate, void* stream);
+
+/* ---- gradient penalty (cgan/losses.py:223-231) -------------------------------------------------------------------
+ * nrm[b] = sqrt(sum g_b^2 + 1e-12); gp_sum += mean((nrm-1)^2); coef[b] = lambda_gp*2/B*(nrm-1)/nrm. */
+int gcssl_gp_norm(const float* g, long per_sample, int B, float lambda_gp, float* nrm, float* coef, float* gp_sum, void* stream);
+int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long per_sample, int B, void* stream);
+
+/* ---- clip_grad_norm_(1.0) + Adam (cgan/cgan_train_enhanced.py:256-257,331-332,368-369) over flat fp32 buffers ---
+ * state: 3 doubles {step, sumsq scratch, last total norm}; step is advanced on the device (graph replay safe). */
+int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* state, float lr, float b1, float b2,
+                    float eps, float max_norm, int write_clipped, void* stream);
+
+/* ---- generator head (cgan/models.py:118-123,139-141) and box/EIoU loss (cgan/losses.py:19-73,99-150) ------------- */
+int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, const float* w, const float* bias, float scale,
+                           float* pooled, float* traw, float* delta, int B, int HW, int C, void* stream);
+int gcssl_head_bwd(const float* g_delta, const float* traw, const float* pooled, const float* w, float scale, int B,
+                   int HW, float* dw, float* db, float* da_bcast, void* stream);
+int gcssl_eiou_fwd_bwd(const float* pred_box, const float* delta, const float* delta_true, int B, float lambda_iou,
+                       float* g_delta, float* calibrated, float* loss_acc, void* stream);
+
+/* ---- misc ---------------------------------------------------------------------------------------------------------- */
+int gcssl_dropout_mask_gen(uint8_t* out, long n, unsigned long long seed, const double* counter, void* stream);
+int gcssl_group_mean(const float* x, int groups, int per_group, float* out, void* stream);
+int gcssl_cast(int dtype, const float* x, void* y, long n, void* stream);
+int gcssl_uncast(int dtype, const void* x, float* y, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

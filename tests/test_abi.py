@@ -1,0 +1,56 @@
+"""CPU-only: the C-ABI library builds for gfx950, loads, and exports every symbol include/gcssl.h declares.
+No compute calls are made here (no GPU)."""
+import ctypes
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT, load_pkg
+
+
+@pytest.fixture(scope="module")
+def lib_mod():
+    m = load_pkg("_lib")
+    m.build()
+    return m
+
+
+def test_header_declares_the_expected_surface(lib_mod):
+    protos = lib_mod.parse_header()
+    for name in ["gcssl_conv4x4s2_fwd", "gcssl_conv4x4s2_dgrad", "gcssl_conv4x4s2_wgrad", "gcssl_wgrad_reduce",
+                 "gcssl_conv4x4s1_c1_fwd", "gcssl_conv4x4s1_c1_dgrad", "gcssl_conv4x4s1_c1_wgrad",
+                 "gcssl_in_act_fwd", "gcssl_in_act_bwd", "gcssl_in_dbl_bwd", "gcssl_act_bwd",
+                 "gcssl_sn_power_iter", "gcssl_gp_norm", "gcssl_clip_adam", "gcssl_pool_fc_tanh_fwd",
+                 "gcssl_head_bwd", "gcssl_eiou_fwd_bwd", "gcssl_dropout_mask_gen", "gcssl_pack_pair",
+                 "gcssl_pack_interp", "gcssl_unpack_grad", "gcssl_prep_conv_weight"]:
+        assert name in protos, name
+
+
+def test_every_declared_symbol_is_exported(lib_mod):
+    handle = lib_mod.lib()
+    protos = lib_mod.parse_header()
+    for name, (_, argtypes) in protos.items():
+        fn = getattr(handle, name)
+        assert fn.argtypes == argtypes
+    assert handle.gcssl_version().decode().startswith("gcssl-hip")
+    # and nothing exported is undeclared
+    out = subprocess.run(["nm", "-D", "--defined-only", str(lib_mod.LIB_PATH)], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\b(gcssl_\w+)\b", out))
+    assert exported == set(protos), exported ^ set(protos)
+
+
+def test_argument_validation_without_gpu(lib_mod):
+    """Pure host-side checks return negative codes before any launch (safe on a CPU-only box)."""
+    h = lib_mod.lib()
+    assert h.gcssl_conv4x4s2_fwd(0, None, 8, None, None, None, 0, None, 64, 1, 8, 8, 8, 64, 0, None) == -4
+    assert h.gcssl_conv4x4s2_wgrad_splits(4, 12, 12, 64, 64) == -1          # non power-of-two spatial size
+    assert h.gcssl_conv4x4s2_wgrad_splits(256, 16, 16, 64, 128) > 0
+    assert h.gcssl_gp_norm(None, 10, 2, ctypes.c_float(1.0), None, None, None, None) == -4
+
+
+def test_code_object_is_gfx950(lib_mod):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(lib_mod.LIB_PATH)],
+                         capture_output=True, text=True).stdout
+    blob = lib_mod.LIB_PATH.read_bytes()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob, out[:200]

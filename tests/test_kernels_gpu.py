@@ -1,0 +1,350 @@
+"""Per-kernel parity of the HIP kernels (called through the C ABI) against torch CPU fp32 / the oracle formulas.
+Tolerances: exact-fp32 MFMA mode 2e-5 relative to the tensor scale; bf16 mode 2e-2 (bf16 operands, fp32 accumulate)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from torch.nn.grad import conv2d_weight
+
+from conftest import load_pkg, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DTS = [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return load_pkg("ops")
+
+
+def nhwc(x, dt, pad_to=None):
+    """CPU NCHW fp32 -> device NHWC tensor (optionally zero-padded channels)."""
+    x = x.permute(0, 2, 3, 1).contiguous()
+    if pad_to and pad_to > x.shape[3]:
+        x = F.pad(x, (0, pad_to - x.shape[3]))
+    return x.to("cuda", dt).contiguous()
+
+
+def nchw(x):
+    return x.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def q(x, dt):
+    """round-trip through the compute dtype (so the CPU reference sees the same operand values)"""
+    return x.to(dt).float()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def packed_weights(ops, w, dt, cinp=None):
+    cout, cin = w.shape[:2]
+    cinp = cinp or cin
+    wf = torch.empty(cout, 16, cinp, device="cuda", dtype=dt)
+    wt = torch.empty(cinp, 16, cout, device="cuda", dtype=dt)
+    ops.prep_conv_weight(w.cuda(), wf, wt, cout, cin, cinp, ops.code(wf))
+    return wf, wt
+
+
+CONV_CASES = [  # N, Hi, Cin(real), CinP, Cout
+    (3, 16, 64, 64, 128),     # 64x64 tile
+    (2, 8, 256, 256, 512),
+    (5, 32, 6, 8, 64),        # first layer, padded channels
+    (8, 128, 64, 64, 128),    # large M -> 128x128 tile
+    (24, 32, 128, 128, 64),   # 128x64 tile
+    (3, 4, 256, 256, 512),    # 4x4 -> 2x2 (D.c4 at 32x32 input)
+]
+
+
+@pytest.mark.parametrize("dt,tol", DTS)
+@pytest.mark.parametrize("N,Hi,Cin,CinP,Cout", CONV_CASES)
+def test_conv_fwd(ops, dt, tol, N, Hi, Cin, CinP, Cout):
+    x = q(rnd(N, Cin, Hi, Hi, seed=1), dt)
+    w = rnd(Cout, Cin, 4, 4, seed=2, scale=0.05)
+    b = rnd(Cout, seed=3, scale=0.1)
+    gs = torch.tensor([1.3, 0.7, 2.1])[: (N + (N + 2) // 3 - 1) // ((N + 2) // 3)]
+    group_n = (N + 2) // 3
+    wf, _ = packed_weights(ops, w, dt, CinP)
+    xd = nhwc(x, dt, CinP)
+    y = torch.zeros(N, Hi // 2, Hi // 2, Cout, device="cuda", dtype=dt)
+    ops.conv_fwd(xd, wf, y, CinP, Cout, bias=b.cuda(), gscale=gs.cuda(), group_n=group_n, act=1)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, q(w, dt), None, 2, 1)
+    scale = gs[torch.arange(N) // group_n].view(-1, 1, 1, 1)
+    ref = F.leaky_relu(ref * scale + b.view(1, -1, 1, 1), 0.2)
+    assert rel_err(nchw(y), ref) < tol
+
+
+@pytest.mark.parametrize("dt,tol", DTS)
+@pytest.mark.parametrize("N,Hi,Cin,CinP,Cout", CONV_CASES)
+def test_conv_dgrad(ops, dt, tol, N, Hi, Cin, CinP, Cout):
+    dy = q(rnd(N, Cout, Hi // 2, Hi // 2, seed=4), dt)
+    w = rnd(Cout, Cin, 4, 4, seed=5, scale=0.05)
+    _, wt = packed_weights(ops, w, dt, CinP)
+    dyd = nhwc(dy, dt)
+    gs = torch.tensor([0.9], device="cuda")
+    dx = torch.zeros(N, Hi, Hi, CinP, device="cuda", dtype=dt)
+    ops.conv_dgrad(dyd, wt, dx, CinP, Cout, gscale=gs, group_n=N)
+    dx32 = torch.zeros(N, Hi, Hi, CinP, device="cuda", dtype=torch.float32)
+    ops.conv_dgrad(dyd, wt, dx32, CinP, Cout)
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(dy, q(w, dt), None, 2, 1)
+    assert rel_err(nchw(dx)[:, :Cin], ref * 0.9) < tol
+    assert rel_err(nchw(dx32)[:, :Cin], ref) < tol
+    if CinP > Cin:
+        assert float(dx32[..., Cin:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt,tol", DTS)
+@pytest.mark.parametrize("N,Hi,Cin,CinP,Cout", CONV_CASES)
+def test_conv_wgrad(ops, dt, tol, N, Hi, Cin, CinP, Cout):
+    x = q(rnd(N, Cin, Hi, Hi, seed=6), dt)
+    dy = q(rnd(N, Cout, Hi // 2, Hi // 2, seed=7), dt)
+    xd, dyd = nhwc(x, dt, CinP), nhwc(dy, dt)
+    ns = ops.wgrad_splits(N, Hi, Hi, CinP, Cout)
+    slab = torch.full((ns, Cout, 16, CinP), float("nan"), device="cuda")
+    ops.conv_wgrad(xd, dyd, slab, CinP, Cout)
+    dw = torch.full((Cout, Cin, 4, 4), float("nan"), device="cuda")
+    # rank-1 correction as used by the spectral-norm quotient rule
+    coef = torch.tensor([0.5, -0.25], device="cuda")
+    u = rnd(2, Cout, seed=8).cuda()
+    v = rnd(2, Cin * 16, seed=9).cuda()
+    ops.wgrad_reduce(slab, ns, dw, Cout, CinP, Cin, coef=coef, cscale=torch.tensor([2.0, 0.5], device="cuda"), u=u, v=v, nrank=2)
+    torch.cuda.synchronize()
+    ref = conv2d_weight(x, (Cout, Cin, 4, 4), dy, 2, 1)
+    corr = sum(float(coef[k]) * (2.0, 0.5)[k] * torch.outer(u[k].cpu(), v[k].cpu()).view(Cout, Cin, 4, 4) for k in range(2))
+    assert rel_err(dw.cpu(), ref - corr) < tol
+
+
+@pytest.mark.parametrize("dt,tol", DTS)
+@pytest.mark.parametrize("N,H,C,act", [(3, 8, 128, 1), (2, 2, 512, 1), (2, 32, 64, 2), (4, 4, 256, 2)])
+def test_instance_norm_fwd_bwd_dbl(ops, dt, tol, N, H, C, act):
+    from oracle import manual_step as M
+    z = q(rnd(N, C, H, H, seed=10, scale=2.0) + 0.3, dt)
+    da = q(rnd(N, C, H, H, seed=11), dt)
+    mask = (rnd(N, C, H, H, seed=12) > 0)
+    zd, dad = nhwc(z, dt), nhwc(da, dt)
+    maskd = mask.permute(0, 2, 3, 1).contiguous().to("cuda", torch.uint8)
+    # forward into a channel slice of a wider (concat) buffer
+    wide = torch.zeros(N, H, H, 2 * C, device="cuda", dtype=dt)
+    a = wide[..., C:]
+    mean = torch.empty(N, C, device="cuda"); rstd = torch.empty(N, C, device="cuda")
+    ops.in_act_fwd(zd, a, mean, rstd, C, act, mask=maskd)
+    torch.cuda.synchronize()
+    mu, r = M.in_stats(z)
+    xh = (z - mu) * r
+    aref = (M.lrelu(xh) if act == 1 else torch.relu(xh)) * mask.float() * 2
+    assert rel_err(mean.cpu(), mu.view(N, C)) < 1e-5 and rel_err(rstd.cpu(), r.view(N, C)) < 1e-5
+    assert rel_err(nchw(a), aref) < tol
+    assert float(wide[..., :C].abs().max()) == 0.0
+    # backward (with dropout mask, group scale, bias/cdot bookkeeping)
+    bias = rnd(C, seed=13, scale=0.1)
+    gsc = torch.tensor([1.5, 0.5], device="cuda")
+    group_n = (N + 1) // 2
+    dzs = torch.empty(N, H, H, C, device="cuda", dtype=dt)
+    dbias = torch.zeros(C, device="cuda"); cdot = torch.zeros(2, device="cuda")
+    ops.in_act_bwd(zd, mean, rstd, dzs, C, act, da=dad, mask=maskd, gscale=gsc, group_n=group_n, bias=bias.cuda(),
+                   dbias=dbias, cdot=cdot)
+    torch.cuda.synchronize()
+    ag = torch.where(xh > 0, torch.ones_like(xh), torch.full_like(xh, 0.2 if act == 1 else 0.0))
+    dn = da * mask.float() * 2 * ag
+    dz = M.in_bwd(xh, r, dn)
+    grp = (torch.arange(N) // group_n)
+    assert rel_err(nchw(dzs), dz * gsc.cpu()[grp].view(-1, 1, 1, 1)) < tol
+    # sum dz (z-b) is analytically ~0 for a normalised layer (sum dz = 0, sum dz xhat ~ eps): judge the error
+    # against the magnitude of the summed terms, not against the cancelled result
+    terms = dz * (z - bias.view(1, -1, 1, 1))
+    cd = torch.stack([terms[grp == g].double().sum() for g in range(2)])
+    mag = torch.stack([terms[grp == g].abs().double().sum() for g in range(2)])
+    assert float(((cdot.cpu().double() - cd).abs() / mag).max()) < max(tol, 1e-5)
+    assert float(dbias.abs().max().cpu()) < max(tol, 1e-5) * float(dz.abs().sum(dim=(0, 2, 3)).max())
+    # double backward
+    qz = q(rnd(N, C, H, H, seed=14), dt)
+    gzs = q(rnd(N, C, H, H, seed=15), dt)
+    gt_a = torch.empty(N, H, H, C, device="cuda", dtype=dt); zt = torch.empty(N, H, H, C, device="cuda", dtype=dt)
+    cd2 = torch.zeros(1, device="cuda")
+    ops.in_dbl_bwd(dad, nhwc(qz, dt), nhwc(gzs, dt), zd, mean, rstd, gt_a, zt, C, act, cdot=cd2)
+    torch.cuda.synchronize()
+    dn2 = da * ag
+    gtn, ztr = M.in_bwd_bwd(xh, r, dn2, qz)
+    assert rel_err(nchw(gt_a), gtn * ag) < tol
+    assert rel_err(nchw(zt), ztr) < max(tol, 1e-4)
+    assert rel_err(cd2.cpu(), (gzs * qz).sum().view(1)) < max(tol, 1e-4)
+
+
+@pytest.mark.parametrize("dt,tol", DTS)
+def test_act_bwd_and_dot(ops, dt, tol):
+    N, H, C = 4, 16, 64
+    a = q(F.leaky_relu(rnd(N, C, H, H, seed=20), 0.2), dt)
+    da = q(rnd(N, C, H, H, seed=21), dt); da2 = q(rnd(N, C, H, H, seed=22), dt)
+    bias = rnd(C, seed=23, scale=0.1)
+    gsc = torch.tensor([2.0, 0.5], device="cuda")
+    dzs = torch.empty(N, H, H, C, device="cuda", dtype=dt)
+    dbias = torch.zeros(C, device="cuda"); cdot = torch.zeros(2, device="cuda")
+    ops.act_bwd(nhwc(da, dt), nhwc(a, dt), dzs, C, da2=nhwc(da2, dt), gscale=gsc, group_n=2, bias=bias.cuda(),
+                dbias=dbias, cdot=cdot)
+    torch.cuda.synchronize()
+    dz = torch.where(a > 0, da + da2, 0.2 * (da + da2))
+    grp = torch.arange(N) // 2
+    assert rel_err(nchw(dzs), dz * gsc.cpu()[grp].view(-1, 1, 1, 1)) < tol
+    assert rel_err(dbias.cpu(), dz.sum(dim=(0, 2, 3))) < max(tol, 1e-4)
+    zrec = torch.where(a > 0, a, a * 5.0)
+    cd = torch.stack([(dz[grp == g] * (zrec[grp == g] - bias.view(1, -1, 1, 1))).sum() for g in range(2)])
+    assert rel_err(cdot.cpu(), cd) < max(tol, 1e-4)
+    out = torch.zeros(1, device="cuda")
+    ops.dot_accum(nhwc(da, dt), nhwc(da2, dt), C, out)
+    assert rel_err(out.cpu(), (da * da2).sum().view(1)) < max(tol, 1e-4)
+
+
+@pytest.mark.parametrize("dt,tol", DTS)
+@pytest.mark.parametrize("N,H", [(6, 2), (3, 4), (2, 8)])
+def test_critic_head(ops, dt, tol, N, H):
+    C = 512
+    x = q(rnd(N, C, H, H, seed=30), dt)
+    w = rnd(1, C, 4, 4, seed=31, scale=0.05)
+    wp = torch.empty(16, C, device="cuda")
+    ops.prep_c5_weight(w.cuda(), wp)
+    xd = nhwc(x, dt)
+    out = torch.empty(N, H - 1, H - 1, device="cuda")
+    ops.c5_fwd(xd, wp, out)
+    ref = F.conv2d(x, w, None, 1, 1)
+    assert rel_err(out.cpu().view_as(ref), ref) < max(tol * 0.5, 2e-5)
+    dout = rnd(N, 1, H - 1, H - 1, seed=32)
+    dx = torch.empty(N, H, H, C, device="cuda", dtype=dt)
+    ops.c5_dgrad(dx, wp, dout=dout.cuda().contiguous())
+    assert rel_err(nchw(dx), F.conv_transpose2d(dout, w, None, 1, 1)) < tol
+    consts = (-0.5, 0.25, 0.0)
+    ops.c5_dgrad(dx, wp, consts=consts, group_n=N // 3)
+    dconst = torch.tensor(consts)[torch.arange(N) // (N // 3)].view(-1, 1, 1, 1).expand(N, 1, H - 1, H - 1)
+    assert rel_err(nchw(dx), F.conv_transpose2d(dconst.contiguous(), w, None, 1, 1)) < tol
+    dw = torch.zeros(C, 16, device="cuda")
+    ops.c5_wgrad(xd, dw, C, dout=dout.cuda().contiguous())
+    assert rel_err(dw.cpu().view(1, C, 4, 4), conv2d_weight(x, w.shape, dout, 1, 1)) < max(tol, 1e-4)
+    dw.zero_()
+    ops.c5_wgrad(xd, dw, C, consts=consts, group_n=N // 3)
+    assert rel_err(dw.cpu().view(1, C, 4, 4), conv2d_weight(x, w.shape, dconst.contiguous(), 1, 1)) < max(tol, 1e-4)
+
+
+def test_spectral_norm_power_iteration(ops):
+    from oracle import manual_step as M
+    shapes = [(64, 6 * 16), (128, 64 * 16), (256, 128 * 16), (512, 256 * 16)]
+    ws = [rnd(r, c, seed=40 + i, scale=0.05) for i, (r, c) in enumerate(shapes)]
+    us = [F.normalize(rnd(r, seed=50 + i), dim=0) for i, (r, _) in enumerate(shapes)]
+    vs = [F.normalize(rnd(c, seed=60 + i), dim=0) for i, (_, c) in enumerate(shapes)]
+    wd, ud, vd = [w.cuda() for w in ws], [u.cuda() for u in us], [v.cuda() for v in vs]
+    sn = ops.SnState(wd, ud, vd, 3, "cuda")
+    sn.iterate(0, iterate=False)
+    torch.cuda.synchronize()
+    for i in range(4):
+        s0 = torch.dot(us[i], ws[i] @ vs[i])
+        assert abs(float(sn.sigma[i, 0]) - float(s0)) < 1e-5 * abs(float(s0)) + 1e-7
+    for k in range(3):
+        sn.iterate(k)
+    torch.cuda.synchronize()
+    for i in range(4):
+        u, v = us[i], vs[i]
+        for k in range(3):
+            u, v, s = M.sn_power_iter(ws[i], u, v)
+            r, c = shapes[i]
+            assert rel_err(sn.u_hist[i, k, :r].cpu(), u) < 2e-5
+            assert rel_err(sn.v_hist[i, k, :c].cpu(), v) < 2e-5
+            assert abs(float(sn.sigma[i, k]) - float(s)) < 2e-5 * float(s)
+            assert abs(float(sn.isig[i, k]) * float(s) - 1) < 2e-5
+        assert rel_err(ud[i].cpu(), u) < 2e-5 and rel_err(vd[i].cpu(), v) < 2e-5
+
+
+def test_pack_interp_gp_norm_unpack(ops):
+    B, S = 5, 32
+    pred, gt, ref = rnd(B, 3, S, S, seed=70), rnd(B, 3, S, S, seed=71), rnd(B, 3, S, S, seed=72)
+    alpha = torch.rand(B, generator=torch.Generator().manual_seed(3))
+    for dt in (torch.float32, torch.bfloat16):
+        out = torch.empty(3 * B, S, S, 8, device="cuda", dtype=dt)
+        ops.pack_pair(pred.cuda(), gt.cuda(), out[:B])
+        ops.pack_pair(pred.cuda(), ref.cuda(), out[B:2 * B])
+        ops.pack_interp(pred.cuda(), gt.cuda(), ref.cuda(), alpha.cuda(), out[2 * B:])
+        a = alpha.view(-1, 1, 1, 1)
+        exp = torch.cat([torch.cat([pred, gt], 1), torch.cat([pred, ref], 1),
+                         torch.cat([a * pred + (1 - a) * pred, a * gt + (1 - a) * ref], 1)], 0)
+        got = nchw(out)
+        if dt == torch.float32:
+            assert torch.equal(got[:, :6], exp)       # bit-exact: same op-by-op rounding as eager torch
+        else:
+            assert rel_err(got[:, :6], exp) < 1e-2
+        assert float(got[:, 6:].abs().max()) == 0.0
+    g = rnd(B, S, S, 8, seed=73).cuda()
+    nrm = torch.empty(B, device="cuda"); coef = torch.empty(B, device="cuda"); gp = torch.zeros(1, device="cuda")
+    ops.gp_norm(g, B, 1.0, nrm, coef, gp)
+    n_ref = torch.sqrt((g.cpu().reshape(B, -1) ** 2).sum(1) + 1e-12)
+    assert rel_err(nrm.cpu(), n_ref) < 1e-5
+    assert abs(float(gp) - float(((n_ref - 1) ** 2).mean())) < 1e-4 * float(((n_ref - 1) ** 2).mean())
+    assert rel_err(coef.cpu(), 2.0 / B * (n_ref - 1) / n_ref) < 1e-5
+    y = torch.empty(B, S, S, 8, device="cuda", dtype=torch.bfloat16)
+    ops.scale_rows(g, coef, y, B)
+    assert rel_err(y.float().cpu(), g.cpu() * coef.cpu().view(-1, 1, 1, 1)) < 1e-2
+    ga = torch.empty(B, 3, S, S, device="cuda"); gb = torch.empty(B, 3, S, S, device="cuda")
+    ops.unpack_grad(g, ga, gb)
+    assert torch.equal(ga.cpu(), g.cpu().permute(0, 3, 1, 2)[:, :3]) and torch.equal(gb.cpu(), g.cpu().permute(0, 3, 1, 2)[:, 3:6])
+
+
+def test_clip_adam_matches_torch(ops):
+    n = 100003
+    p0 = rnd(n, seed=80)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2e-4, betas=(0.5, 0.999))
+    p = p0.cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    state = torch.zeros(3, device="cuda", dtype=torch.float64)
+    for t in range(3):
+        g = rnd(n, seed=81 + t, scale=0.05)
+        ref.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        gd = g.cuda()
+        ops.clip_adam(p, gd, m, v, state, 2e-4, 0.5, 0.999, write_clipped=True)
+        torch.cuda.synchronize()
+        assert abs(float(state[2]) - float(tn)) < 1e-5 * float(tn)
+        assert float(state[0]) == t + 1
+        assert rel_err(gd.cpu(), ref.grad) < 1e-5
+        assert float((p.cpu() - ref.detach()).abs().max()) < 2e-7
+    assert rel_err(m.cpu(), opt.state[ref]["exp_avg"]) < 1e-5
+    assert rel_err(v.cpu(), opt.state[ref]["exp_avg_sq"]) < 1e-5
+
+
+def test_generator_head_and_eiou(ops):
+    from oracle import manual_step as M
+    from conftest import load_golden
+    B, S = 6, 16
+    x = rnd(B, 64, S, S, seed=90)
+    w, b = rnd(4, 64, seed=91, scale=0.125), rnd(4, seed=92, scale=0.125)
+    pooled = torch.empty(B, 64, device="cuda"); traw = torch.empty(B, 4, device="cuda"); delta = torch.empty(B, 4, device="cuda")
+    ops.pool_fc_tanh_fwd(nhwc(x, torch.float32), w.cuda(), b.cuda(), 0.3, pooled, traw, delta)
+    pr = x.mean(dim=(2, 3)); tr = torch.tanh(pr @ w.t() + b)
+    assert rel_err(pooled.cpu(), pr) < 1e-5 and rel_err(delta.cpu(), tr * 0.3) < 1e-5
+    gd = rnd(B, 4, seed=93)
+    dw = torch.empty(4, 64, device="cuda"); db = torch.empty(4, device="cuda"); dab = torch.empty(B, 64, device="cuda")
+    ops.head_bwd(gd.cuda(), traw, pooled, w.cuda(), 0.3, B, S * S, dw, db, dab)
+    dy = gd * 0.3 * (1 - tr * tr)
+    assert rel_err(dw.cpu(), dy.t() @ pr) < 1e-5 and rel_err(db.cpu(), dy.sum(0)) < 1e-5
+    assert rel_err(dab.cpu(), (dy @ w) / (S * S)) < 1e-5
+    # EIoU + box math against the reference's known-answer vectors
+    fix = load_golden("loss_vectors")
+    bbox, dl = torch.from_numpy(fix["bbox"]), torch.from_numpy(fix["delta"])
+    dtrue = torch.from_numpy(load_pkg("synth").normal("kv.dt", 7, (16, 4), 0.1))
+    g = torch.empty(16, 4, device="cuda"); cal = torch.empty(16, 4, device="cuda"); acc = torch.zeros(1, device="cuda")
+    ops.eiou_fwd_bwd(bbox.cuda(), dl.cuda(), dtrue.cuda(), 1.0, g, cal, acc)
+    assert abs(1.0 + float(acc) - float(fix["hybrid_total"])) < 1e-5
+    assert rel_err(cal.cpu(), fix["apply_train"]) < 1e-5
+    assert rel_err(g.cpu(), fix["hybrid_grad_delta"]) < 1e-4
+
+
+def test_dropout_mask_gen(ops):
+    m = torch.empty(1 << 20, device="cuda", dtype=torch.uint8)
+    ops.dropout_mask_gen(m, 1234)
+    frac = float(m.float().mean())
+    assert set(m.unique().tolist()) <= {0, 1} and abs(frac - 0.5) < 5e-3
+    m2 = torch.empty_like(m)
+    ops.dropout_mask_gen(m2, 1235)
+    assert abs(float((m == m2).float().mean()) - 0.5) < 5e-3
