@@ -24,7 +24,7 @@ SOURCES = ["igemm.hip", "norm.hip", "misc.hip"]
 F32, BF16 = 0, 1
 ERRORS = {-1: "GCSSL_EBADSHAPE", -2: "GCSSL_EBADDTYPE", -3: "GCSSL_EALIGN", -4: "GCSSL_ENULL"}
 
-_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
+_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
        "unsigned long long": ctypes.c_ulonglong}
 
 

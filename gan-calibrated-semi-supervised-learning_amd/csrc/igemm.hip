@@ -128,7 +128,7 @@ struct ConvParams {
     int lgWo, lgHoWo, lgCin, lgCout;
     int M;              // GEMM rows
     int act;            // fwd epilogue: 1 = LeakyReLU(0.2)
-    int out_f32;        // dgrad: write fp32 regardless of T
+    int out_f32;        // fwd/dgrad: write fp32 regardless of T
     int ktiles_per_split;   // wgrad
 };
 
@@ -202,8 +202,9 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
         if (t + 1 < nk) lstore((t + 1) & 1);
         __syncthreads();
     }
-    // epilogue
+    // epilogue (out_f32: the pre-norm tensor z stays fp32 in bf16 mode, see norm.hip)
     T* y = static_cast<T*>(p.y);
+    float* y32 = static_cast<float*>(p.y);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -219,7 +220,8 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
                 float v = acc[i][j][r] * s;
                 if (p.bias) v += p.bias[co];
                 if (p.act == 1) v = lrelu_f(v);
-                Elem<T>::st(y + (size_t)m * p.ldy + co, v);
+                if (p.out_f32) y32[(size_t)m * p.ldy + co] = v;
+                else Elem<T>::st(y + (size_t)m * p.ldy + co, v);
             }
         }
 }
@@ -487,7 +489,7 @@ extern "C" {
 
 int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const float* bias,
                         const float* gscale, int group_n, void* y, int ldy, int N, int Hi, int Wi,
-                        int Cin, int Cout, int act, void* stream) {
+                        int Cin, int Cout, int act, int out_f32, void* stream) {
     if (!x || !wf || !y) return GCSSL_ENULL;
     int rc = check_geom(N, Hi, Wi, Cin, Cout);
     if (rc) return rc;
@@ -495,7 +497,7 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
     const int kv = dtype == GCSSL_F32 ? 4 : 8;
     if (ldx % kv || !aligned16(x) || !aligned16(wf)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = x; p.w = wf; p.y = y; p.bias = bias; p.gscale = gscale; p.group_n = group_n;
-    p.ldx = ldx; p.ldy = ldy; p.act = act;
+    p.ldx = ldx; p.ldy = ldy; p.act = act; p.out_f32 = out_f32;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GCSSL_F32) return dispatch_fwd<float>(p, st);

@@ -260,22 +260,24 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // state[0] = step count (as float64), state[1] = sum of squares of the gradient, state[2] = last total norm
 __global__ void adam_tick_kernel(double* state) { state[0] += 1.0; state[2] = sqrt(state[1]); }
 
+// scalar constants follow torch's single-tensor Adam: python doubles, cast to float where they meet the tensor
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, const double* __restrict__ state, float lr, float b1, float b2, float eps,
-                            float max_norm, int write_clipped) {
+                            size_t n, const double* __restrict__ state, double lr, double b1, double b2, double eps,
+                            double max_norm, int write_clipped) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double t = state[0];
     const float total = (float)sqrt(state[1]);
-    const float coef = fminf(1.0f, max_norm / (total + 1e-6f));
-    const float bc1 = (float)(1.0 - pow((double)b1, t));
-    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+    const float coef = fminf(1.0f, (float)max_norm / (total + 1e-6f));
+    const float step = (float)(lr / (1.0 - pow(b1, t)));
+    const float bc2s = (float)sqrt(1.0 - pow(b2, t));
+    const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2);
     const float gi = g[i] * coef;
-    const float mi = m[i] + (gi - m[i]) * (1.f - b1);             // lerp_, as torch's single-tensor Adam
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    const float mi = m[i] + w1 * (gi - m[i]);                     // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * b2f + w2 * (gi * gi);                 // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
     m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / bc2s + eps;
-    p[i] = p[i] - (lr / bc1) * (mi / denom);
+    const float denom = sqrtf(vi) / bc2s + (float)eps;
+    p[i] = p[i] - step * (mi / denom);
     if (write_clipped) g[i] = gi;
 }
 
@@ -553,8 +555,8 @@ int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long
 }
 
 // state: 3 doubles {step, sumsq, last_total_norm}.  Caller zeroes state[1] before each use (gcssl_zero or memset).
-int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* state, float lr, float b1, float b2,
-                    float eps, float max_norm, int write_clipped, void* stream) {
+int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* state, double lr, double b1, double b2,
+                    double eps, double max_norm, int write_clipped, void* stream) {
     if (!p || !g || !m || !v || !state) return GCSSL_ENULL;
     if (n <= 0) return GCSSL_EBADSHAPE;
     hipStream_t st = (hipStream_t)stream;

@@ -7,6 +7,11 @@
 // Replaces: nn.InstanceNorm2d + LeakyReLU/ReLU (+ Dropout) at cgan/models.py:59-63,73-76,114,241-242
 // and their autograd first/second-order backward used by cgan/losses.py:213-220 (create_graph=True).
 // Formulas: oracle/manual_step.py (in_bwd, in_bwd_bwd), verified against autograd.
+//
+// The pre-norm tensor z is ALWAYS fp32 (also in bf16 mode): with only 4..64 elements per (n,c) plane at 32x32 inputs,
+// z - mean(z) cancels most of a bf16 mantissa (measured: 18 % error on the gradient penalty with bf16 z).  For the
+// same reason every INCOMING gradient of the backward kernels (da, da2, gb_a, qz, zt) is fp32 -- they come out of fp32
+// MFMA accumulators anyway -- and only the tensors that feed the next MFMA (a, dzs, gt_a, gb_zs) are in `dtype`.
 #include "common.h"
 
 namespace {
@@ -36,44 +41,44 @@ __device__ __forceinline__ float act_grad(float xhat, int act) { return xhat > 0
 
 // a = act((z - mean) * rstd) [* keep * 2];  writes mean/rstd [N][C]
 template <typename T>
-__global__ __launch_bounds__(CW * RG) void in_act_fwd_kernel(const T* __restrict__ z, int ldz, T* __restrict__ a, int lda,
+__global__ __launch_bounds__(CW * RG) void in_act_fwd_kernel(const float* __restrict__ z, int ldz, T* __restrict__ a, int lda,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
                                                             const uint8_t* __restrict__ mask, int HW, int C, int act) {
     __shared__ float sm[1][RG][CW];
     const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
     const int c = blockIdx.x * CW + tx, n = blockIdx.y;
-    const T* zp = z + (size_t)n * HW * ldz + c;
+    const float* zp = z + (size_t)n * HW * ldz + c;
     float s[1] = {0.f};
-    for (int p = ty; p < HW; p += RG) s[0] += Elem<T>::ld(zp + (size_t)p * ldz);
+    for (int p = ty; p < HW; p += RG) s[0] += zp[(size_t)p * ldz];
     combine<1>(s, sm, tx, ty);
     const float mu = s[0] / HW;
     s[0] = 0.f;
-    for (int p = ty; p < HW; p += RG) { const float d = Elem<T>::ld(zp + (size_t)p * ldz) - mu; s[0] += d * d; }
+    for (int p = ty; p < HW; p += RG) { const float d = zp[(size_t)p * ldz] - mu; s[0] += d * d; }
     combine<1>(s, sm, tx, ty);
     const float r = 1.0f / sqrtf(s[0] / HW + IN_EPS);
     if (ty == 0) { mean[(size_t)n * C + c] = mu; rstd[(size_t)n * C + c] = r; }
     T* ap = a + (size_t)n * HW * lda + c;
     const uint8_t* mp = mask ? mask + (size_t)n * HW * C + c : nullptr;
     for (int p = ty; p < HW; p += RG) {
-        float v = act_fwd((Elem<T>::ld(zp + (size_t)p * ldz) - mu) * r, act);
+        float v = act_fwd((zp[(size_t)p * ldz] - mu) * r, act);
         if (mp) v *= mp[(size_t)p * C] ? 2.f : 0.f;
         Elem<T>::st(ap + (size_t)p * lda, v);
     }
 }
 
 struct InBwdParams {
-    const void* da; int ldda;          // incoming gradient of the activation output (nullable if da_bcast)
-    const void* da2; int ldda2;        // optional second gradient added to da (skip connection)
+    const float* da; int ldda;         // incoming gradient of the activation output, fp32 (nullable if da_bcast)
+    const float* da2; int ldda2;       // optional second gradient added to da (skip connection), fp32
     const float* da_bcast;             // optional [N][C] gradient broadcast over H*W (global-avg-pool backward)
-    const void* z; int ldz;
+    const float* z; int ldz;           // pre-norm conv output, always fp32
     const float* mean; const float* rstd;
     const uint8_t* mask;               // dropout keep mask [N][HW][C], nullable
-    const void* zt; int zt_n0;         // optional double-backward term added to dz of samples n >= zt_n0 ([N-zt_n0][HW][C])
+    const float* zt; int zt_n0;        // optional fp32 double-backward term added to dz of samples n >= zt_n0 ([N-zt_n0][HW][C])
     const float* gscale; int group_n;  // output multiplier per sample group, nullable
     const float* bias;                 // conv bias (for the spectral-norm <dz, z-b> term), nullable
     void* dzs; int lddz;               // output: dz * gscale
     float* dbias;                      // [C] += sum dz (atomic), nullable
-    float* cdot;                       // [ngroups] += sum dz (z - bias) (atomic), nullable
+    float* cdot;                       // [ngroups] += sum dzs (z - bias) = <G_k, W_orig>/sigma_k^2 (atomic), nullable
     int HW, C, act;
 };
 
@@ -85,38 +90,38 @@ __global__ __launch_bounds__(CW * RG) void in_act_bwd_kernel(InBwdParams q) {
     const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
     const int c = blockIdx.x * CW + tx, n = blockIdx.y;
     const int HW = q.HW, C = q.C;
-    const T* zp = static_cast<const T*>(q.z) + (size_t)n * HW * q.ldz + c;
-    const T* dap = q.da ? static_cast<const T*>(q.da) + (size_t)n * HW * q.ldda + c : nullptr;
-    const T* da2p = q.da2 ? static_cast<const T*>(q.da2) + (size_t)n * HW * q.ldda2 + c : nullptr;
+    const float* zp = q.z + (size_t)n * HW * q.ldz + c;
+    const float* dap = q.da ? q.da + (size_t)n * HW * q.ldda + c : nullptr;
+    const float* da2p = q.da2 ? q.da2 + (size_t)n * HW * q.ldda2 + c : nullptr;
     const uint8_t* mp = q.mask ? q.mask + (size_t)n * HW * C + c : nullptr;
     const float mu = q.mean[(size_t)n * C + c], r = q.rstd[(size_t)n * C + c];
     const float dab = q.da_bcast ? q.da_bcast[(size_t)n * C + c] : 0.f;
     auto dn_at = [&](int p, float xh) {
         float d = dab;
-        if (dap) d += Elem<T>::ld(dap + (size_t)p * q.ldda);
-        if (da2p) d += Elem<T>::ld(da2p + (size_t)p * q.ldda2);
+        if (dap) d += dap[(size_t)p * q.ldda];
+        if (da2p) d += da2p[(size_t)p * q.ldda2];
         if (mp) d *= mp[(size_t)p * C] ? 2.f : 0.f;
         return d * act_grad(xh, q.act);
     };
     float s[2] = {0.f, 0.f};
     for (int p = ty; p < HW; p += RG) {
-        const float xh = (Elem<T>::ld(zp + (size_t)p * q.ldz) - mu) * r;
+        const float xh = (zp[(size_t)p * q.ldz] - mu) * r;
         const float dn = dn_at(p, xh);
         s[0] += dn; s[1] += dn * xh;
     }
     combine<2>(s, sm, tx, ty);
     const float m1 = s[0] / HW, m2 = s[1] / HW;
     const float gs = q.gscale ? q.gscale[n / q.group_n] : 1.f;
-    const T* ztp = (q.zt && n >= q.zt_n0) ? static_cast<const T*>(q.zt) + (size_t)(n - q.zt_n0) * HW * C + c : nullptr;
+    const float* ztp = (q.zt && n >= q.zt_n0) ? q.zt + (size_t)(n - q.zt_n0) * HW * C + c : nullptr;
     T* op = static_cast<T*>(q.dzs) + (size_t)n * HW * q.lddz + c;
     const float b = q.bias ? q.bias[c] : 0.f;
     float sb = 0.f, sd = 0.f;
     for (int p = ty; p < HW; p += RG) {
-        const float zv = Elem<T>::ld(zp + (size_t)p * q.ldz);
+        const float zv = zp[(size_t)p * q.ldz];
         const float xh = (zv - mu) * r;
         float dz = r * (dn_at(p, xh) - m1 - xh * m2);
-        if (ztp) dz += Elem<T>::ld(ztp + (size_t)p * C);
-        sb += dz; sd += dz * (zv - b);
+        if (ztp) dz += ztp[(size_t)p * C];
+        sb += dz; sd += dz * gs * (zv - b);
         Elem<T>::st(op + (size_t)p * q.lddz, dz * gs);
     }
     if (q.dbias) {
@@ -131,13 +136,13 @@ __global__ __launch_bounds__(CW * RG) void in_act_bwd_kernel(InBwdParams q) {
 }
 
 struct InDblParams {
-    const void* gb_a; int ldgb;        // first-order chain gradient wrt activation output (dn = act' * gb_a)
-    const void* qz; int ldq;           // adjoint of the first-order dz (gt_z)
+    const float* gb_a; int ldgb;       // first-order chain gradient wrt activation output (dn = act' * gb_a), fp32
+    const float* qz; int ldq;          // adjoint of the first-order dz (gt_z), fp32
     const void* gb_zs; int ldgz;       // first-order dz * isig (for the spectral-norm dot), nullable
-    const void* z; int ldz;
+    const float* z; int ldz;           // always fp32
     const float* mean; const float* rstd;
     void* gt_a; int ldga;              // out: act'(xhat) * rstd * (q - mean(q) - xhat mean(q xhat))
-    void* zt;                          // out: adjoint wrt z, dense [N][HW][C]
+    float* zt;                         // out: adjoint wrt z, dense fp32 [N][HW][C]
     float* cdot;                       // scalar += sum gb_zs * q (atomic), nullable
     int HW, C, act;
 };
@@ -150,17 +155,17 @@ __global__ __launch_bounds__(CW * RG) void in_dbl_bwd_kernel(InDblParams q) {
     const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
     const int c = blockIdx.x * CW + tx, n = blockIdx.y;
     const int HW = q.HW, C = q.C;
-    const T* zp = static_cast<const T*>(q.z) + (size_t)n * HW * q.ldz + c;
-    const T* gp = static_cast<const T*>(q.gb_a) + (size_t)n * HW * q.ldgb + c;
-    const T* qp = static_cast<const T*>(q.qz) + (size_t)n * HW * q.ldq + c;
+    const float* zp = q.z + (size_t)n * HW * q.ldz + c;
+    const float* gp = q.gb_a + (size_t)n * HW * q.ldgb + c;
+    const float* qp = q.qz + (size_t)n * HW * q.ldq + c;
     const T* gzp = q.gb_zs ? static_cast<const T*>(q.gb_zs) + (size_t)n * HW * q.ldgz + c : nullptr;
     const float mu = q.mean[(size_t)n * C + c], r = q.rstd[(size_t)n * C + c];
     float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float sd = 0.f;
     for (int p = ty; p < HW; p += RG) {
-        const float xh = (Elem<T>::ld(zp + (size_t)p * q.ldz) - mu) * r;
-        const float dn = act_grad(xh, q.act) * Elem<T>::ld(gp + (size_t)p * q.ldgb);
-        const float qq = Elem<T>::ld(qp + (size_t)p * q.ldq);
+        const float xh = (zp[(size_t)p * q.ldz] - mu) * r;
+        const float dn = act_grad(xh, q.act) * gp[(size_t)p * q.ldgb];
+        const float qq = qp[(size_t)p * q.ldq];
         s[0] += dn; s[1] += dn * xh; s[2] += qq; s[3] += qq * xh; s[4] += qq * dn;
         if (gzp) sd += Elem<T>::ld(gzp + (size_t)p * q.ldgz) * qq;
     }
@@ -169,14 +174,14 @@ __global__ __launch_bounds__(CW * RG) void in_dbl_bwd_kernel(InDblParams q) {
     const float m1 = s[0] * inv, m2 = s[1] * inv, mq = s[2] * inv, mqx = s[3] * inv, mqd = s[4] * inv;
     const float k0 = mqd - mq * m1 - 3.f * mqx * m2;
     T* gap = static_cast<T*>(q.gt_a) + (size_t)n * HW * q.ldga + c;
-    T* ztp = static_cast<T*>(q.zt) + (size_t)n * HW * C + c;
+    float* ztp = q.zt + (size_t)n * HW * C + c;
     for (int p = ty; p < HW; p += RG) {
-        const float xh = (Elem<T>::ld(zp + (size_t)p * q.ldz) - mu) * r;
+        const float xh = (zp[(size_t)p * q.ldz] - mu) * r;
         const float ag = act_grad(xh, q.act);
-        const float dn = ag * Elem<T>::ld(gp + (size_t)p * q.ldgb);
-        const float qq = Elem<T>::ld(qp + (size_t)p * q.ldq);
+        const float dn = ag * gp[(size_t)p * q.ldgb];
+        const float qq = qp[(size_t)p * q.ldq];
         Elem<T>::st(gap + (size_t)p * q.ldga, ag * r * (qq - mq - xh * mqx));
-        Elem<T>::st(ztp + (size_t)p * C, r * r * (-xh * k0 - m2 * (qq - mq) - mqx * (dn - m1)));
+        ztp[(size_t)p * C] = r * r * (-xh * k0 - m2 * (qq - mq) - mqx * (dn - m1));
     }
     if (q.cdot) {
         const float tot = block_sum<CW * RG / 64>(sd, red);
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(CW * RG) void in_dbl_bwd_kernel(InDblParams q) {
 
 // ---- layers without a norm (D.c1, G.down1): a = lrelu(z) was fused in the conv epilogue; backward is elementwise
 struct ActBwdParams {
-    const void* da; int ldda; const void* da2; int ldda2;
+    const float* da; int ldda; const float* da2; int ldda2;      // incoming gradients, fp32
     const void* a; int lda;
     const float* gscale; int group_n;
     const float* bias;
@@ -202,8 +207,8 @@ __global__ __launch_bounds__(CW * RG) void act_bwd_kernel(ActBwdParams q) {
     const int c = blockIdx.x * CW + tx, n = blockIdx.y;
     const int HW = q.HW;
     const T* ap = static_cast<const T*>(q.a) + (size_t)n * HW * q.lda + c;
-    const T* dap = static_cast<const T*>(q.da) + (size_t)n * HW * q.ldda + c;
-    const T* da2p = q.da2 ? static_cast<const T*>(q.da2) + (size_t)n * HW * q.ldda2 + c : nullptr;
+    const float* dap = q.da + (size_t)n * HW * q.ldda + c;
+    const float* da2p = q.da2 ? q.da2 + (size_t)n * HW * q.ldda2 + c : nullptr;
     T* op = static_cast<T*>(q.dzs) + (size_t)n * HW * q.lddz + c;
     const float gs = q.gscale ? q.gscale[n / q.group_n] : 1.f;
     const float b = q.bias ? q.bias[c] : 0.f;
@@ -213,11 +218,11 @@ __global__ __launch_bounds__(CW * RG) void act_bwd_kernel(ActBwdParams q) {
     const int p0 = blockIdx.z * chunk, p1 = min(HW, p0 + chunk);
     for (int p = p0 + ty; p < p1; p += RG) {
         const float av = Elem<T>::ld(ap + (size_t)p * q.lda);
-        float d = Elem<T>::ld(dap + (size_t)p * q.ldda);
-        if (da2p) d += Elem<T>::ld(da2p + (size_t)p * q.ldda2);
+        float d = dap[(size_t)p * q.ldda];
+        if (da2p) d += da2p[(size_t)p * q.ldda2];
         const float dz = av > 0.f ? d : 0.2f * d;
         const float zv = av > 0.f ? av : av * 5.0f;          // invert LeakyReLU(0.2)
-        sb += dz; sd += dz * (zv - b);
+        sb += dz; sd += dz * gs * (zv - b);
         Elem<T>::st(op + (size_t)p * q.lddz, dz * gs);
     }
     if (q.dbias) {
@@ -233,14 +238,14 @@ __global__ __launch_bounds__(CW * RG) void act_bwd_kernel(ActBwdParams q) {
 
 // out += sum x*y  (strided NHWC views), used for the <gb_zs, gt_z> spectral-norm term of the norm-less layer
 template <typename T>
-__global__ void dot_accum_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ y, int ldy,
+__global__ void dot_accum_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
                                  size_t pixels, int C, float* out) {
     __shared__ float red[4];
     float s = 0.f;
     const size_t total = pixels * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i / C; const int c = i % C;
-        s += Elem<T>::ld(x + pix * ldx + c) * Elem<T>::ld(y + pix * ldy + c);
+        s += Elem<T>::ld(x + pix * ldx + c) * y[pix * ldy + c];
     }
     const float tot = block_sum<4>(s, red);
     if (threadIdx.x == 0) atomicAdd(out, tot);
@@ -252,24 +257,24 @@ bool bad_dtype(int dt) { return dt != GCSSL_F32 && dt != GCSSL_BF16; }
 
 extern "C" {
 
-int gcssl_in_act_fwd(int dtype, const void* z, int ldz, void* a, int lda, float* mean, float* rstd,
+int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float* mean, float* rstd,
                      const uint8_t* mask, int N, int HW, int C, int act, void* stream) {
     if (!z || !a || !mean || !rstd) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lda < C || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
     dim3 grid(C / CW, N);
     if (dtype == GCSSL_F32)
-        hipLaunchKernelGGL(in_act_fwd_kernel<float>, grid, dim3(CW * RG), 0, (hipStream_t)stream, (const float*)z, ldz,
+        hipLaunchKernelGGL(in_act_fwd_kernel<float>, grid, dim3(CW * RG), 0, (hipStream_t)stream, z, ldz,
                            (float*)a, lda, mean, rstd, mask, HW, C, act);
     else
-        hipLaunchKernelGGL(in_act_fwd_kernel<bf16_t>, grid, dim3(CW * RG), 0, (hipStream_t)stream, (const bf16_t*)z, ldz,
+        hipLaunchKernelGGL(in_act_fwd_kernel<bf16_t>, grid, dim3(CW * RG), 0, (hipStream_t)stream, z, ldz,
                            (bf16_t*)a, lda, mean, rstd, mask, HW, C, act);
     return gcssl_launch_status();
 }
 
-int gcssl_in_act_bwd(int dtype, const void* da, int ldda, const void* da2, int ldda2, const float* da_bcast,
-                     const void* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask,
-                     const void* zt, int zt_n0, const float* gscale, int group_n, const float* bias,
+int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const float* da_bcast,
+                     const float* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask,
+                     const float* zt, int zt_n0, const float* gscale, int group_n, const float* bias,
                      void* dzs, int lddz, float* dbias, float* cdot, int N, int HW, int C, int act, void* stream) {
     if ((!da && !da_bcast) || !z || !mean || !rstd || !dzs) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
@@ -283,9 +288,9 @@ int gcssl_in_act_bwd(int dtype, const void* da, int ldda, const void* da2, int l
     return gcssl_launch_status();
 }
 
-int gcssl_in_dbl_bwd(int dtype, const void* gb_a, int ldgb, const void* qz, int ldq, const void* gb_zs, int ldgz,
-                     const void* z, int ldz, const float* mean, const float* rstd, void* gt_a, int ldga,
-                     void* zt, float* cdot, int N, int HW, int C, int act, void* stream) {
+int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, int ldq, const void* gb_zs, int ldgz,
+                     const float* z, int ldz, const float* mean, const float* rstd, void* gt_a, int ldga,
+                     float* zt, float* cdot, int N, int HW, int C, int act, void* stream) {
     if (!gb_a || !qz || !z || !mean || !rstd || !gt_a || !zt) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || ldgb < C || ldq < C || ldga < C) return GCSSL_EBADSHAPE;
@@ -296,7 +301,7 @@ int gcssl_in_dbl_bwd(int dtype, const void* gb_a, int ldgb, const void* qz, int 
     return gcssl_launch_status();
 }
 
-int gcssl_act_bwd(int dtype, const void* da, int ldda, const void* da2, int ldda2, const void* a, int lda,
+int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const void* a, int lda,
                   const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias,
                   float* cdot, int N, int HW, int C, void* stream) {
     if (!da || !a || !dzs) return GCSSL_ENULL;
@@ -311,7 +316,7 @@ int gcssl_act_bwd(int dtype, const void* da, int ldda, const void* da2, int ldda
     return gcssl_launch_status();
 }
 
-int gcssl_dot_accum(int dtype, const void* x, int ldx, const void* y, int ldy, long pixels, int C, float* out,
+int gcssl_dot_accum(int dtype, const void* x, int ldx, const float* y, int ldy, long pixels, int C, float* out,
                     void* stream) {
     if (!x || !y || !out) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
@@ -320,10 +325,10 @@ int gcssl_dot_accum(int dtype, const void* x, int ldx, const void* y, int ldy, l
     int blocks = (int)((total + 255) / 256); if (blocks > 1024) blocks = 1024;
     if (dtype == GCSSL_F32)
         hipLaunchKernelGGL(dot_accum_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx,
-                           (const float*)y, ldy, (size_t)pixels, C, out);
+                           y, ldy, (size_t)pixels, C, out);
     else
         hipLaunchKernelGGL(dot_accum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                           (const bf16_t*)y, ldy, (size_t)pixels, C, out);
+                           y, ldy, (size_t)pixels, C, out);
     return gcssl_launch_status();
 }
 

@@ -1,0 +1,479 @@
+"""Explicit-schedule step engine: the WGAN-GP cGAN training iteration of the reference
+(cgan/cgan_train_enhanced.py:304-369) as a fixed sequence of HIP kernel launches on one stream -- no autograd
+tape, no host synchronisation, every buffer preallocated (so the whole iteration can be captured in a hipGraph).
+
+MI355X-first choices:
+  * the three critic forwards of a D step (real, fake, interpolated; :308,:316 and cgan/losses.py:210) run as ONE
+    3B-sample batch; their different spectral-norm sigmas become a per-sample-group scale in the conv epilogue;
+  * the WGAN-GP double backward (cgan/losses.py:213-220 + :330) is written out by hand (oracle/manual_step.py is
+    the executable spec): first-order dgrad chain, its reverse (forward-conv chain + wgrad + InstanceNorm
+    double-backward), then one batched backward of the three forwards;
+  * activations are NHWC in the compute dtype, concat buffers are written in place, weight gradients go
+    split-K slab -> fused reduce (+ spectral-norm rank-1 correction) straight into one flat fp32 gradient buffer
+    that is also the RCCL all-reduce bucket and the fused clip+Adam operand.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib, ops
+from .ops import LRELU, RELU
+
+D_IDX = (0, 2, 5, 8)
+D_CH = [(6, 64), (64, 128), (128, 256), (256, 512)]            # (Cin, Cout) of the SN convs
+G_DOWN = [(3, 64), (64, 128), (128, 256), (256, 512)]
+G_UP = [(512, 256), (512, 128), (256, 64), (128, 64)]          # ConvTranspose (CinT, CoutT)
+D_PARAM_KEYS = [k for i in D_IDX for k in (f"model.{i}.bias", f"model.{i}.weight_orig")] + ["model.11.weight"]
+G_PARAM_KEYS = ["down1.model.0.weight", "down2.model.0.weight", "down3.model.0.weight", "down4.model.0.weight",
+                "up1.model.0.weight", "up2.model.0.weight", "up3.model.0.weight", "up4.0.weight",
+                "fc_delta.1.weight", "fc_delta.1.bias"]
+
+
+def _pad8(c: int) -> int:
+    return max(8, c)
+
+
+class FlatParams:
+    """Parameters of one network as views into one flat fp32 buffer (+ grad / Adam moments of the same shape)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], keys: Sequence[str], device):
+        self.keys = list(keys)
+        n = sum(sd[k].numel() for k in keys)
+        self.p = torch.empty(n, device=device)
+        self.g = torch.zeros(n, device=device)
+        self.m = torch.zeros(n, device=device)
+        self.v = torch.zeros(n, device=device)
+        self.state = torch.zeros(3, device=device, dtype=torch.float64)   # step, sumsq scratch, last grad norm
+        self.views, self.gviews, off = {}, {}, 0
+        for k in keys:
+            t = sd[k]
+            self.views[k] = self.p[off:off + t.numel()].view(t.shape)
+            self.gviews[k] = self.g[off:off + t.numel()].view(t.shape)
+            self.views[k].copy_(t)
+            off += t.numel()
+
+    def moment_views(self, k: str):
+        off = 0
+        for kk in self.keys:
+            n = self.views[kk].numel()
+            if kk == k:
+                return self.m[off:off + n].view(self.views[kk].shape), self.v[off:off + n].view(self.views[kk].shape)
+            off += n
+        raise KeyError(k)
+
+
+class StepEngine:
+    """Holds G and D (weights, Adam state, spectral-norm u/v) on one GPU and runs reference-ordered iterations.
+
+    dtype: "fp32" (exact fp32 MFMA; the parity mode) or "bf16" (bf16 operands, fp32 accumulate; throughput mode).
+    ``allreduce(flat_grad)`` (optional) is called on the flat D / G gradient right before clip+Adam: the data-parallel
+    hook (dist.py).  ``refine_fn(delta, k)`` stands in for the host re-crop stage ``get_refined_patch_batch``
+    (cgan/cgan_train_enhanced.py:37-137): it must return a (B,3,S,S) fp32 NCHW tensor with no dependence path
+    back into the engine's buffers.
+    """
+
+    def __init__(self, sd_g: Dict[str, torch.Tensor], sd_d: Dict[str, torch.Tensor], batch: int, size: int,
+                 n_critic: int = 2, dtype="bf16", device="cuda", lr: float = 2e-4, betas=(0.5, 0.999),
+                 delta_scale: float = 0.3, lambda_gp: float = 1.0, lambda_iou: float = 1.0, seed: int = 42,
+                 allreduce: Optional[Callable[[torch.Tensor], None]] = None):
+        if size < 32 or size & (size - 1):
+            raise ValueError("img size must be a power of two >= 32 (the reference raises below 32: SURVEY §0)")
+        self.B, self.S, self.c = batch, size, n_critic
+        self.dev = torch.device(device)
+        self.code = _lib.dtype_code(dtype)
+        self.T = _lib.torch_dtype(self.code)
+        self.lr, self.betas = lr, betas
+        self.delta_scale, self.lambda_gp, self.lambda_iou = delta_scale, lambda_gp, lambda_iou
+        self.seed = seed
+        self.allreduce = allreduce
+        _lib.lib()                                                  # fail loudly now if the HIP library is missing
+        dev = self.dev
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.D = FlatParams({k: sd_d[k].to(dev, torch.float32) for k in D_PARAM_KEYS}, D_PARAM_KEYS, dev)
+        self.G = FlatParams({k: sd_g[k].to(dev, torch.float32) for k in G_PARAM_KEYS}, G_PARAM_KEYS, dev)
+        self.u = [sd_d[f"model.{i}.weight_u"].to(dev, torch.float32).clone() for i in D_IDX]
+        self.v = [sd_d[f"model.{i}.weight_v"].to(dev, torch.float32).clone() for i in D_IDX]
+        self.sn = ops.SnState([self.D.views[f"model.{i}.weight_orig"] for i in D_IDX], self.u, self.v, 3, dev)
+        self._alloc()
+        self._d_dirty = True
+        self._g_dirty = True
+        self.mask_counter = torch.zeros(1, device=dev, dtype=torch.float64)
+
+    # ------------------------------------------------------------------------------------------ buffers
+    def _alloc(self):
+        B, S, T, dev = self.B, self.S, self.T, self.dev
+        N3 = 3 * B
+
+        def act(n, s, c, dt=T):
+            return torch.empty(n, s, s, c, device=dev, dtype=dt)
+        f32 = dict(device=dev, dtype=torch.float32)
+        # ---- packed weights
+        self.d_wf, self.d_wt = [], []
+        for cin, cout in D_CH:
+            cp = _pad8(cin)
+            self.d_wf.append(torch.empty(cout, 16, cp, device=dev, dtype=T))
+            self.d_wt.append(torch.empty(cp, 16, cout, device=dev, dtype=T))
+        self.d_w5p = torch.empty(16, 512, **f32)
+        self.gd_wf, self.gd_wt, self.gu_wf, self.gu_wt = [], [], [], []
+        for cin, cout in G_DOWN:
+            cp = _pad8(cin)
+            self.gd_wf.append(torch.empty(cout, 16, cp, device=dev, dtype=T))
+            self.gd_wt.append(torch.empty(cp, 16, cout, device=dev, dtype=T))
+        for cint, coutt in G_UP:        # as a conv: Cout = CinT, Cin = CoutT
+            self.gu_wf.append(torch.empty(cint, 16, coutt, device=dev, dtype=T))
+            self.gu_wt.append(torch.empty(coutt, 16, cint, device=dev, dtype=T))
+        # ---- critic, 3B batch
+        self.x0 = act(N3, S, 8)
+        sizes = [S // 2, S // 4, S // 8, S // 16]
+        self.d_a = [act(N3, s, c) for s, (_, c) in zip(sizes, D_CH)]
+        # pre-InstanceNorm tensors are fp32 in both modes (z - mean(z) over 4..64 elements cancels a bf16 mantissa)
+        self.d_z = [None] + [act(N3, s, c, torch.float32) for s, (_, c) in zip(sizes[1:], D_CH[1:])]
+        self.d_mean = [None] + [torch.empty(N3, c, **f32) for _, c in D_CH[1:]]
+        self.d_rstd = [None] + [torch.empty(N3, c, **f32) for _, c in D_CH[1:]]
+        self.h5 = sizes[3] - 1
+        self.d_out = torch.empty(N3, self.h5, self.h5, **f32)
+        # GP chain (B samples)
+        # gradient tensors that feed a norm/activation backward kernel are fp32 (norm.hip header); those that feed an
+        # MFMA (gb_zs, gt_a, dzs) are in the compute dtype
+        F32 = torch.float32
+        self.gb_a = [act(B, s, c, F32) for s, (_, c) in zip(sizes, D_CH)]     # d out / d a_l
+        self.gb_zs = [act(B, s, c) for s, (_, c) in zip(sizes, D_CH)]         # (d out / d z_l) * isig
+        self.gb_x0 = torch.empty(B, S, S, 8, **f32)
+        self.gp_nrm = torch.empty(B, **f32)
+        self.gp_coef = torch.empty(B, **f32)
+        self.gt_x = act(B, S, 8)
+        self.gt_z = [act(B, s, c, F32) for s, (_, c) in zip(sizes, D_CH)]
+        self.gt_a = [act(B, s, c) for s, (_, c) in zip(sizes, D_CH)]
+        self.zt = [None] + [act(B, s, c, F32) for s, (_, c) in zip(sizes[1:], D_CH[1:])]
+        # backward of the 3B forward
+        self.d_da = [act(N3, s, c, F32) for s, (_, c) in zip(sizes, D_CH)]
+        self.d_dzs = [act(N3, s, c) for s, (_, c) in zip(sizes, D_CH)]
+        # scalars: [0:12] cdot[layer][group] = <dW_sn_k, W_orig>/sigma_k^2 (spectral-norm quotient rule), [12] gp_sum, [13] eiou acc, [14:17] group means, [17] wgan-G mean
+        self.scal = torch.zeros(32, **f32)
+        self.cdot = self.scal[0:12].view(4, 3)
+        self.gp_sum = self.scal[12:13]
+        self.eiou_acc = self.scal[13:14]
+        self.means = self.scal[14:17]
+        self.wgan_mean = self.scal[17:18]
+        # wgrad slabs: per D layer [chain splits + forward splits]
+        self.d_slab, self.d_ns = [], []
+        for l, (cin, cout) in enumerate(D_CH):
+            hi = S >> l
+            cp = _pad8(cin)
+            nc = ops.wgrad_splits(B, hi, hi, cp, cout)
+            nf = ops.wgrad_splits(N3, hi, hi, cp, cout)
+            self.d_ns.append((nc, nf))
+            self.d_slab.append(torch.empty(nc + nf, cout, 16, cp, **f32))
+        # ---- generator (B samples)
+        self.g_cat3 = act(B, S // 2, 128)      # [up3 out (64) | d1 (64)]
+        self.g_cat2 = act(B, S // 4, 256)      # [up2 out (128) | d2 (128)]
+        self.g_cat1 = act(B, S // 8, 512)      # [up1 out (256) | d3 (256)]
+        self.g_d4 = act(B, S // 16, 512)
+        z32 = torch.float32
+        self.g_zd = [None, act(B, S // 4, 128, z32), act(B, S // 8, 256, z32), act(B, S // 16, 512, z32)]
+        self.g_zu = [act(B, S // 8, 256, z32), act(B, S // 4, 128, z32), act(B, S // 2, 64, z32), act(B, S, 64, z32)]
+        self.g_u4 = act(B, S, 64)
+        self.g_dmean = [None] + [torch.empty(B, c, **f32) for c in (128, 256, 512)]
+        self.g_drstd = [None] + [torch.empty(B, c, **f32) for c in (128, 256, 512)]
+        self.g_umean = [torch.empty(B, c, **f32) for c in (256, 128, 64, 64)]
+        self.g_urstd = [torch.empty(B, c, **f32) for c in (256, 128, 64, 64)]
+        self.g_masks = [torch.empty(B, S // 16, S // 16, 512, device=dev, dtype=torch.uint8),
+                        torch.empty(B, S // 8, S // 8, 256, device=dev, dtype=torch.uint8),
+                        torch.empty(B, S // 4, S // 4, 128, device=dev, dtype=torch.uint8)]
+        self.g_pooled = torch.empty(B, 64, **f32)
+        self.g_traw = torch.empty(B, 4, **f32)
+        self.g_delta = torch.empty(B, 4, **f32)
+        self.g_gdelta = torch.empty(B, 4, **f32)
+        self.g_cal = torch.empty(B, 4, **f32)
+        self.g_dab = torch.empty(B, 64, **f32)
+        # generator backward
+        self.g_dzu = [act(B, S // 8, 256), act(B, S // 4, 128), act(B, S // 2, 64), act(B, S, 64)]
+        self.g_dcat3 = act(B, S // 2, 128, z32)
+        self.g_dcat2 = act(B, S // 4, 256, z32)
+        self.g_dcat1 = act(B, S // 8, 512, z32)
+        self.g_dd4 = act(B, S // 16, 512, z32)
+        self.g_dzd = [act(B, S // 2, 64), act(B, S // 4, 128), act(B, S // 8, 256), act(B, S // 16, 512)]
+        self.g_dd = [None, act(B, S // 2, 64, z32), act(B, S // 4, 128, z32), act(B, S // 8, 256, z32)]   # grad wrt d1..d3 via the down path
+        self.g_slab_d, self.g_ns_d, self.g_slab_u, self.g_ns_u = [], [], [], []
+        for k, (cin, cout) in enumerate(G_DOWN):
+            hi = S >> k
+            cp = _pad8(cin)
+            ns = ops.wgrad_splits(B, hi, hi, cp, cout)
+            self.g_ns_d.append(ns)
+            self.g_slab_d.append(torch.empty(ns, cout, 16, cp, **f32))
+        for k, (cint, coutt) in enumerate(G_UP):       # conv geometry: x hi-res [.., CoutT], dy lo-res [.., CinT]
+            hi = S >> (3 - k)
+            ns = ops.wgrad_splits(B, hi, hi, coutt, cint)
+            self.g_ns_u.append(ns)
+            self.g_slab_u.append(torch.empty(ns, cint, 16, coutt, **f32))
+
+    # ------------------------------------------------------------------------------------------ weights
+    def _prep_d(self):
+        if not self._d_dirty:
+            return
+        for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX)):
+            ops.prep_conv_weight(self.D.views[f"model.{i}.weight_orig"], self.d_wf[l], self.d_wt[l], cout, cin,
+                                 _pad8(cin), self.code)
+        ops.prep_c5_weight(self.D.views["model.11.weight"], self.d_w5p)
+        self._d_dirty = False
+
+    def _prep_g(self):
+        if not self._g_dirty:
+            return
+        for k, (cin, cout) in enumerate(G_DOWN):
+            ops.prep_conv_weight(self.G.views[f"down{k + 1}.model.0.weight"], self.gd_wf[k], self.gd_wt[k], cout, cin,
+                                 _pad8(cin), self.code)
+        for k, (cint, coutt) in enumerate(G_UP):
+            key = f"up{k + 1}.model.0.weight" if k < 3 else "up4.0.weight"
+            ops.prep_conv_weight(self.G.views[key], self.gu_wf[k], self.gu_wt[k], cint, coutt, coutt, self.code)
+        self._g_dirty = False
+
+    # ------------------------------------------------------------------------------------------ critic forward
+    def _d_forward(self, n: int, gscale_of_layer, group_n: int):
+        """conv stack over the first n rows of the 3B buffers."""
+        x = self.x0[:n]
+        for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX)):
+            bias = self.D.views[f"model.{i}.bias"]
+            if l == 0:
+                ops.conv_fwd(x, self.d_wf[0], self.d_a[0][:n], 8, cout, bias=bias, gscale=gscale_of_layer(0),
+                             group_n=group_n, act=LRELU)
+            else:
+                ops.conv_fwd(self.d_a[l - 1][:n], self.d_wf[l], self.d_z[l][:n], cin, cout, bias=bias,
+                             gscale=gscale_of_layer(l), group_n=group_n)
+                ops.in_act_fwd(self.d_z[l][:n], self.d_a[l][:n], self.d_mean[l][:n], self.d_rstd[l][:n], cout, LRELU)
+        ops.c5_fwd(self.d_a[3][:n], self.d_w5p, self.d_out[:n])
+
+    def critic_scores(self, pred: torch.Tensor, other: torch.Tensor, train: bool = True) -> torch.Tensor:
+        """Discriminator.forward(pred, other) (cgan/models.py:255-258) for one (B,3,S,S) pair -> (B,1,h,w).
+        train=True advances the spectral-norm u,v by one power iteration like the reference's train-mode forward."""
+        B = pred.shape[0]
+        assert B <= 3 * self.B
+        self.sn.iterate(0, iterate=train)
+        self._prep_d()
+        ops.pack_pair(pred, other, self.x0[:B])
+        self._d_forward(B, lambda l: self.sn.isig[l, 0:1], B)
+        return self.d_out[:B].reshape(B, 1, self.h5, self.h5)
+
+    # ------------------------------------------------------------------------------------------ generator forward
+    def _set_masks(self, masks: Optional[Sequence[torch.Tensor]]):
+        """masks given as NCHW keep-masks (fixture/parity mode) or None -> drawn on the device."""
+        if masks is None:
+            for j, m in enumerate(self.g_masks):
+                ops.dropout_mask_gen(m, self.seed * 131 + j, self.mask_counter)
+            self.mask_counter += 1.0
+        else:
+            for m, src in zip(self.g_masks, masks):
+                m.copy_(src.permute(0, 2, 3, 1))
+
+    def _g_forward(self, x8: torch.Tensor, train: bool = True):
+        """GeneratorUNet.forward (cgan/models.py:125-141) on an NHWC8 input whose first 3 channels are pred."""
+        B = self.B
+        d1, d2, d3 = self.g_cat3[..., 64:], self.g_cat2[..., 128:], self.g_cat1[..., 256:]
+        mk = self.g_masks if train else [None, None, None]
+        ops.conv_fwd(x8, self.gd_wf[0], d1, 8, 64, act=LRELU)
+        ops.conv_fwd(d1, self.gd_wf[1], self.g_zd[1], 64, 128)
+        ops.in_act_fwd(self.g_zd[1], d2, self.g_dmean[1], self.g_drstd[1], 128, LRELU)
+        ops.conv_fwd(d2, self.gd_wf[2], self.g_zd[2], 128, 256)
+        ops.in_act_fwd(self.g_zd[2], d3, self.g_dmean[2], self.g_drstd[2], 256, LRELU)
+        ops.conv_fwd(d3, self.gd_wf[3], self.g_zd[3], 256, 512)
+        ops.in_act_fwd(self.g_zd[3], self.g_d4, self.g_dmean[3], self.g_drstd[3], 512, LRELU, mask=mk[0])
+        ins = [self.g_d4, self.g_cat1, self.g_cat2, self.g_cat3]
+        outs = [self.g_cat1[..., :256], self.g_cat2[..., :128], self.g_cat3[..., :64], self.g_u4]
+        for k, (cint, coutt) in enumerate(G_UP):
+            ops.conv_dgrad(ins[k], self.gu_wt[k], self.g_zu[k], coutt, cint)
+            ops.in_act_fwd(self.g_zu[k], outs[k], self.g_umean[k], self.g_urstd[k], coutt, RELU,
+                           mask=mk[k + 1] if k < 2 else None)
+        ops.pool_fc_tanh_fwd(self.g_u4, self.G.views["fc_delta.1.weight"], self.G.views["fc_delta.1.bias"],
+                             self.delta_scale, self.g_pooled, self.g_traw, self.g_delta)
+        return self.g_delta
+
+    def generator_delta(self, pred: torch.Tensor, masks=None, train: bool = True) -> torch.Tensor:
+        """GeneratorUNet.forward(pred) -> (B,4) delta."""
+        self._prep_g()
+        ops.pack_pair(pred, None, self.gt_x)          # gt_x doubles as the NHWC8 staging buffer outside a D step
+        if train:
+            self._set_masks(masks)
+        return self._g_forward(self.gt_x, train).clone()
+
+    # ------------------------------------------------------------------------------------------ D step
+    def d_step(self, pred, gt, refine_fn, k: int, alpha: Optional[torch.Tensor], masks) -> None:
+        """One critic update (cgan/cgan_train_enhanced.py:304-332)."""
+        B, S, N3 = self.B, self.S, 3 * self.B
+        I = slice(2 * B, 3 * B)
+        isig = self.sn.isig
+        self.D.g.zero_()
+        self.scal.zero_()
+        for slot in range(3):                                     # real, fake, interp forwards each iterate once
+            self.sn.iterate(slot, True)
+        self._prep_d()
+        self._prep_g()
+        # no-grad generator forward in train mode (:311-312) on the real-group input (channels 0-2 = pred)
+        ops.pack_pair(pred, gt, self.x0[:B])
+        self._set_masks(masks)
+        delta_det = self._g_forward(self.x0[:B], True)
+        refined = refine_fn(delta_det, k)                          # :313-315
+        if alpha is None:
+            alpha = torch.rand(B, device=self.dev)                 # cgan/losses.py:199
+        ops.pack_pair(pred, refined, self.x0[B:2 * B])
+        ops.pack_interp(pred, gt, refined, alpha, self.x0[I])
+        self._d_forward(N3, lambda l: isig[l], B)
+        ops.group_mean(self.d_out, 3, self.means)
+        # ---- GP first-order chain on the interpolated group (cgan/losses.py:213-220)
+        ops.c5_dgrad(self.gb_a[3], self.d_w5p, consts=(1.0, 1.0, 1.0), group_n=B)
+        for l in (3, 2, 1):
+            cin, cout = D_CH[l]
+            ops.in_act_bwd(self.d_z[l][I], self.d_mean[l][I], self.d_rstd[l][I], self.gb_zs[l], cout, LRELU,
+                           da=self.gb_a[l], gscale=isig[l, 2:3], group_n=B)
+            ops.conv_dgrad(self.gb_zs[l], self.d_wt[l], self.gb_a[l - 1], cin, cout)
+        ops.act_bwd(self.gb_a[0], self.d_a[0][I], self.gb_zs[0], 64, gscale=isig[0, 2:3], group_n=B)
+        ops.conv_dgrad(self.gb_zs[0], self.d_wt[0], self.gb_x0, 8, 64)
+        ops.gp_norm(self.gb_x0, B, self.lambda_gp, self.gp_nrm, self.gp_coef, self.gp_sum)     # :223-231
+        # ---- reverse of the chain (the create_graph=True part of d_loss.backward(), :330)
+        ops.scale_rows(self.gb_x0, self.gp_coef, self.gt_x, B)
+        src = self.gt_x
+        for l, (cin, cout) in enumerate(D_CH):
+            cp = _pad8(cin)
+            ops.conv_fwd(src, self.d_wf[l], self.gt_z[l], cp, cout, gscale=isig[l, 2:3], group_n=B)
+            ops.conv_wgrad(src, self.gb_zs[l], self.d_slab[l], cp, cout)
+            if l == 0:
+                ops.dot_accum(self.gb_zs[0], self.gt_z[0], 64, self.cdot[0, 2:3])
+                ops.act_bwd(self.gt_z[0], self.d_a[0][I], self.gt_a[0], 64)
+            else:
+                ops.in_dbl_bwd(self.gb_a[l], self.gt_z[l], self.gb_zs[l], self.d_z[l][I], self.d_mean[l][I],
+                               self.d_rstd[l][I], self.gt_a[l], self.zt[l], cout, LRELU, cdot=self.cdot[l, 2:3])
+            src = self.gt_a[l]
+        gw5 = self.D.gviews["model.11.weight"].view(512, 16)
+        ops.c5_wgrad(self.gt_a[3], gw5, 512, consts=(1.0, 1.0, 1.0), group_n=B)
+        # ---- backward of the three forwards, batched: seeds -1/(B hw), +1/(B hw), 0  (:327-330)
+        hw = self.h5 * self.h5
+        seeds = (-1.0 / (B * hw), 1.0 / (B * hw), 0.0)
+        ops.c5_wgrad(self.d_a[3], gw5, 512, consts=seeds, group_n=B)
+        ops.c5_dgrad(self.d_da[3], self.d_w5p, consts=seeds, group_n=B)
+        for l in (3, 2, 1, 0):
+            cin, cout = D_CH[l]
+            cp = _pad8(cin)
+            i = D_IDX[l]
+            bias, gbias = self.D.views[f"model.{i}.bias"], self.D.gviews[f"model.{i}.bias"]
+            if l > 0:
+                ops.in_act_bwd(self.d_z[l], self.d_mean[l], self.d_rstd[l], self.d_dzs[l], cout, LRELU,
+                               da=self.d_da[l], zt=self.zt[l], zt_n0=2 * B, gscale=isig[l], group_n=B, bias=bias,
+                               dbias=gbias, cdot=self.cdot[l])
+            else:
+                ops.act_bwd(self.d_da[0], self.d_a[0], self.d_dzs[0], 64, gscale=isig[0], group_n=B, bias=bias,
+                            dbias=gbias, cdot=self.cdot[0])
+            nc, nf = self.d_ns[l]
+            xin = self.x0 if l == 0 else self.d_a[l - 1]
+            ops.conv_wgrad(xin, self.d_dzs[l], self.d_slab[l][nc:], cp, cout)
+            ops.wgrad_reduce(self.d_slab[l], nc + nf, self.D.gviews[f"model.{i}.weight_orig"], cout, cp, cin,
+                             coef=self.cdot[l], u=self.sn.u_hist[l], v=self.sn.v_hist[l], nrank=3)
+            if l > 0:
+                ops.conv_dgrad(self.d_dzs[l], self.d_wt[l], self.d_da[l - 1], cin, cout)
+        if self.allreduce is not None:
+            self.allreduce(self.D.g)
+        ops.clip_adam(self.D.p, self.D.g, self.D.m, self.D.v, self.D.state, self.lr, self.betas[0], self.betas[1],
+                      write_clipped=True)                          # :331-332
+        self._d_dirty = True
+
+    # ------------------------------------------------------------------------------------------ G step
+    def g_step(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
+        """The generator update (cgan/cgan_train_enhanced.py:345-369)."""
+        B, S = self.B, self.S
+        self.scal[13:].zero_()
+        self._prep_g()
+        ops.pack_pair(pred, None, self.x0[:B])
+        self._set_masks(masks)
+        self._g_forward(self.x0[:B], True)                                             # :348
+        ops.eiou_fwd_bwd(pred_box, self.g_delta, delta_true, self.lambda_iou, self.g_gdelta, self.g_cal,
+                         self.eiou_acc)                                                # :351-355
+        self.delta_pred = self.g_delta.clone()
+        # D forward on (pred, refined_G): value only (zero gradient to G) but it advances u,v (:361)
+        refined_g = refine_fn(self.delta_pred, self.c)                                 # :358-360
+        scores = self.critic_scores(pred, refined_g, train=True)
+        ops.group_mean(scores, 1, self.wgan_mean)                                      # loss_WGAN_G = -mean (:362)
+        # ---- backward of lambda_iou * EIoU through G (:365-366)
+        self.G.g.zero_()
+        # (critic_scores re-packed x0[:B] as (pred, refined): channels 0-2 are still pred, and the padded channels
+        #  3-7 are dropped by the down1 reduce via Cin_real=3)
+        gW = self.G.gviews
+        ops.head_bwd(self.g_gdelta, self.g_traw, self.g_pooled, self.G.views["fc_delta.1.weight"], self.delta_scale,
+                     B, S * S, gW["fc_delta.1.weight"], gW["fc_delta.1.bias"], self.g_dab)
+        ins = [self.g_d4, self.g_cat1, self.g_cat2, self.g_cat3]                       # inputs of up1..up4
+        dcat = [self.g_dd4, self.g_dcat1, self.g_dcat2, self.g_dcat3]                  # grads wrt those inputs
+        for k in (3, 2, 1, 0):
+            cint, coutt = G_UP[k]
+            key = f"up{k + 1}.model.0.weight" if k < 3 else "up4.0.weight"
+            if k == 3:
+                ops.in_act_bwd(self.g_zu[3], self.g_umean[3], self.g_urstd[3], self.g_dzu[3], coutt, RELU,
+                               da_bcast=self.g_dab)
+            else:
+                ops.in_act_bwd(self.g_zu[k], self.g_umean[k], self.g_urstd[k], self.g_dzu[k], coutt, RELU,
+                               da=dcat[k + 1][..., :coutt], mask=self.g_masks[k + 1] if k < 2 else None)
+            ops.conv_wgrad(self.g_dzu[k], ins[k], self.g_slab_u[k], coutt, cint)       # roles swapped (ConvTranspose)
+            ops.wgrad_reduce(self.g_slab_u[k], self.g_ns_u[k], gW[key], cint, coutt, coutt)
+            ops.conv_fwd(self.g_dzu[k], self.gu_wf[k], dcat[k], coutt, cint)
+        d_act = [self.g_cat3[..., 64:], self.g_cat2[..., 128:], self.g_cat1[..., 256:]]            # d1, d2, d3
+        dskip = [self.g_dcat3[..., 64:], self.g_dcat2[..., 128:], self.g_dcat1[..., 256:]]
+        for k in (3, 2, 1, 0):
+            cin, cout = G_DOWN[k]
+            cp = _pad8(cin)
+            if k == 3:
+                ops.in_act_bwd(self.g_zd[3], self.g_dmean[3], self.g_drstd[3], self.g_dzd[3], 512, LRELU,
+                               da=self.g_dd4, mask=self.g_masks[0])
+            elif k > 0:
+                ops.in_act_bwd(self.g_zd[k], self.g_dmean[k], self.g_drstd[k], self.g_dzd[k], cout, LRELU,
+                               da=self.g_dd[k + 1], da2=dskip[k])
+            else:
+                ops.act_bwd(self.g_dd[1], d_act[0], self.g_dzd[0], 64, da2=dskip[0])
+            xin = self.x0[:B] if k == 0 else d_act[k - 1]
+            ops.conv_wgrad(xin, self.g_dzd[k], self.g_slab_d[k], cp, cout)
+            ops.wgrad_reduce(self.g_slab_d[k], self.g_ns_d[k], gW[f"down{k + 1}.model.0.weight"], cout, cp, cin)
+            if k > 0:
+                ops.conv_dgrad(self.g_dzd[k], self.gd_wt[k], self.g_dd[k], cin, cout)
+        if self.allreduce is not None:
+            self.allreduce(self.G.g)
+        ops.clip_adam(self.G.p, self.G.g, self.G.m, self.G.v, self.G.state, self.lr, self.betas[0], self.betas[1],
+                      write_clipped=True)                                               # :368-369
+        self._g_dirty = True
+
+    # ------------------------------------------------------------------------------------------ iteration
+    def run_iteration(self, pred, gt, delta_true, pred_box, refine_fn, alphas=None, masks=None, on_critic=None):
+        """Enqueue one full iteration (n_critic D steps + 1 G step); no host sync, nothing read back."""
+        for k in range(self.c):
+            self.d_step(pred, gt, refine_fn, k, None if alphas is None else alphas[k],
+                        None if masks is None else masks[k])
+            if on_critic is not None:
+                on_critic(k)
+        self.g_step(pred, delta_true, pred_box, refine_fn, None if masks is None else masks[self.c])
+
+    def iteration(self, pred, gt, delta_true, pred_box, refine_fn, alphas=None, masks=None) -> dict:
+        """run_iteration + the scalars the reference logs (.item() syncs at :335-337,372-374)."""
+        log = {"d_loss": [], "gp": [], "wd": [], "d_grad_norm": [], "real": [], "fake": [], "d_interp": []}
+
+        def grab(_k):
+            m = self.means.tolist()
+            gp = float(self.gp_sum)
+            wd = m[0] - m[1]
+            log["wd"].append(wd); log["gp"].append(gp); log["d_loss"].append(-wd + self.lambda_gp * gp)
+            log["d_grad_norm"].append(float(self.D.state[2]))
+            B = self.B
+            log["real"].append(self.d_out[:B].clone()); log["fake"].append(self.d_out[B:2 * B].clone())
+            log["d_interp"].append(self.d_out[2 * B:].clone())
+        self.run_iteration(pred, gt, delta_true, pred_box, refine_fn, alphas, masks, on_critic=grab)
+        loss_iou = 1.0 + float(self.eiou_acc)
+        loss_wgan = -float(self.wgan_mean)
+        log.update(loss_iou=loss_iou, loss_wgan=loss_wgan, loss_g=self.lambda_iou * loss_iou + loss_wgan,
+                   g_grad_norm=float(self.G.state[2]), delta_pred=self.delta_pred.clone(),
+                   calibrated=self.g_cal.clone(), fake_for_g=self.d_out[:self.B].clone())
+        return log
+
+    # ------------------------------------------------------------------------------------------ state access
+    def state_dicts(self):
+        """(generator_state_dict, discriminator_state_dict) keyed like the reference."""
+        g = {k: v.detach().clone() for k, v in self.G.views.items()}
+        d = {k: v.detach().clone() for k, v in self.D.views.items()}
+        for l, i in enumerate(D_IDX):
+            d[f"model.{i}.weight_u"] = self.u[l].clone()
+            d[f"model.{i}.weight_v"] = self.v[l].clone()
+        return g, d

@@ -51,8 +51,11 @@ def prep_c5_weight(w, wp):
 
 # ---- conv k4 s2 p1
 def conv_fwd(x, wf, y, cin, cout, bias=None, gscale=None, group_n=0, act=0):
+    """y may be fp32 while x is bf16 (pre-InstanceNorm tensors are kept in fp32)."""
     N, Hi, Wi, _ = x.shape
-    call("gcssl_conv4x4s2_fwd", code(x), x, _ld(x), wf, bias, gscale, group_n, y, _ld(y), N, Hi, Wi, cin, cout, act)
+    out_f32 = 1 if (y.dtype == torch.float32 and x.dtype != torch.float32) else 0
+    call("gcssl_conv4x4s2_fwd", code(x), x, _ld(x), wf, bias, gscale, group_n, y, _ld(y), N, Hi, Wi, cin, cout, act,
+         out_f32)
 
 
 def conv_dgrad(dy, wt, dx, cin, cout, gscale=None, group_n=0):
@@ -102,32 +105,41 @@ def c5_wgrad(x, dw, C, dout=None, consts=(0.0, 0.0, 0.0), group_n=1):
 
 # ---- norm / activation
 def in_act_fwd(z, a, mean, rstd, C, act, mask=None):
+    """z: fp32 pre-norm tensor; a: activation output in the compute dtype."""
     N, H, W, _ = z.shape
-    call("gcssl_in_act_fwd", code(z), z, _ld(z), a, _ld(a), mean, rstd, mask, N, H * W, C, act)
+    assert z.dtype == torch.float32
+    call("gcssl_in_act_fwd", code(a), z, _ld(z), a, _ld(a), mean, rstd, mask, N, H * W, C, act)
 
 
 def in_act_bwd(z, mean, rstd, dzs, C, act, da=None, da2=None, da_bcast=None, mask=None, zt=None, zt_n0=0,
                gscale=None, group_n=0, bias=None, dbias=None, cdot=None):
     N, H, W, _ = z.shape
-    call("gcssl_in_act_bwd", code(z), da, _ld(da) if da is not None else 0, da2, _ld(da2) if da2 is not None else 0,
+    assert z.dtype == torch.float32 and all(t is None or t.dtype == torch.float32 for t in (da, da2, zt))
+    call("gcssl_in_act_bwd", code(dzs), da, _ld(da) if da is not None else 0, da2, _ld(da2) if da2 is not None else 0,
          da_bcast, z, _ld(z), mean, rstd, mask, zt, zt_n0, gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot,
          N, H * W, C, act)
 
 
 def in_dbl_bwd(gb_a, qz, gb_zs, z, mean, rstd, gt_a, zt, C, act, cdot=None):
     N, H, W, _ = z.shape
-    call("gcssl_in_dbl_bwd", code(z), gb_a, _ld(gb_a), qz, _ld(qz), gb_zs, _ld(gb_zs) if gb_zs is not None else 0,
+    assert z.dtype == torch.float32 and gb_a.dtype == torch.float32 and qz.dtype == torch.float32
+    assert zt.dtype == torch.float32
+    call("gcssl_in_dbl_bwd", code(gt_a), gb_a, _ld(gb_a), qz, _ld(qz), gb_zs, _ld(gb_zs) if gb_zs is not None else 0,
          z, _ld(z), mean, rstd, gt_a, _ld(gt_a), zt, cdot, N, H * W, C, act)
 
 
 def act_bwd(da, a, dzs, C, da2=None, gscale=None, group_n=0, bias=None, dbias=None, cdot=None):
+    """da/da2: fp32 incoming gradients; a and dzs in the compute dtype."""
     N, H, W, _ = a.shape
+    assert da.dtype == torch.float32 and (da2 is None or da2.dtype == torch.float32)
     call("gcssl_act_bwd", code(a), da, _ld(da), da2, _ld(da2) if da2 is not None else 0, a, _ld(a), gscale, group_n,
          bias, dzs, _ld(dzs), dbias, cdot, N, H * W, C)
 
 
 def dot_accum(x, y, C, out):
+    """out += sum x*y; x in the compute dtype, y fp32."""
     N, H, W, _ = x.shape
+    assert y.dtype == torch.float32
     call("gcssl_dot_accum", code(x), x, _ld(x), y, _ld(y), N * H * W, C, out)
 
 

@@ -51,9 +51,11 @@ int gcssl_prep_c5_weight(const float* w, float* wp, int C, void* stream);
 /* ---- Conv2d(k4,s2,p1): cgan/models.py:57 (G.down*), :236 (D.c1-c4) -------------------------------------------
  * y[n,oy,ox,co] = act( gscale[n/group_n] * conv(x, W)[...] + bias[co] );  x [N][Hi][Wi][ldx>=Cin], y [N][Hi/2][Wi/2][ldy>=Cout].
  * bias, gscale nullable; act: 0 none, 1 LeakyReLU(0.2) (cgan/models.py:60,242).  gscale carries 1/sigma of the
- * spectral norm (cgan/models.py:237-238) per sample group.  Also serves the data-gradient of ConvTranspose2d. */
+ * spectral norm (cgan/models.py:237-238) per sample group.  Also serves the data-gradient of ConvTranspose2d.
+ * out_f32: write y as fp32 whatever dtype (pre-InstanceNorm tensors are always fp32, see gcssl_in_act_fwd). */
 int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const float* bias, const float* gscale,
-                        int group_n, void* y, int ldy, int N, int Hi, int Wi, int Cin, int Cout, int act, void* stream);
+                        int group_n, void* y, int ldy, int N, int Hi, int Wi, int Cin, int Cout, int act, int out_f32,
+                        void* stream);
 /* data gradient of the conv == ConvTranspose2d(k4,s2,p1) forward (cgan/models.py:72,113):
  * dx[N][Hi][Wi][lddx>=Cin] = gscale * convT(dy[N][Hi/2][Wi/2][lddy>=Cout], W).  out_f32: write fp32 whatever dtype. */
 int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, const float* gscale, int group_n,
@@ -80,26 +82,29 @@ int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dou
                              float* dw, int N, int Hi, int Wi, int C, void* stream);   /* dw[C][16] += (atomic) */
 
 /* ---- InstanceNorm2d(affine=False, eps=1e-5) + activation (+Dropout): cgan/models.py:59-63,73-76,114,241-242 -----
- * act: 1 LeakyReLU(0.2), 2 ReLU.  mask: dropout keep mask [N][HW][C] (uint8) or NULL; kept values are scaled by 2. */
-int gcssl_in_act_fwd(int dtype, const void* z, int ldz, void* a, int lda, float* mean, float* rstd, const uint8_t* mask,
+ * act: 1 LeakyReLU(0.2), 2 ReLU.  mask: dropout keep mask [N][HW][C] (uint8) or NULL; kept values are scaled by 2.
+ * The pre-norm tensor z and every incoming gradient (da, da2, gb_a, qz, zt) are ALWAYS fp32 (z - mean(z) and
+ * dn - mean(dn) over 4..64 elements cancel a bf16 mantissa); tensors that feed an MFMA (a, dzs, gt_a, gb_zs) are `dtype`. */
+int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float* mean, float* rstd, const uint8_t* mask,
                      int N, int HW, int C, int act, void* stream);
 /* first-order backward: dn = act'(xhat) (da + da2 + da_bcast) [*2 keep]; dz = rstd (dn - mean dn - xhat mean(dn xhat))
  * (+ zt for samples n >= zt_n0: the double-backward term); dzs = dz * gscale[n/group_n];
- * dbias[c] += sum dz; cdot[n/group_n] += sum dz (z - bias[c])  (spectral-norm term).  Optional args nullable. */
-int gcssl_in_act_bwd(int dtype, const void* da, int ldda, const void* da2, int ldda2, const float* da_bcast,
-                     const void* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask, const void* zt,
+ * dbias[c] += sum dz; cdot[n/group_n] += sum dzs (z - bias[c]) -- the coefficient <dW_sn, W_orig>/sigma^2 of the
+ * spectral-norm quotient rule when gscale = 1/sigma.  Optional args nullable. */
+int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const float* da_bcast,
+                     const float* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask, const float* zt,
                      int zt_n0, const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias,
                      float* cdot, int N, int HW, int C, int act, void* stream);
 /* second-order backward (create_graph=True, cgan/losses.py:213-220): adjoint of dz=IN_bwd(z, act'*gb_a) for an
  * incoming adjoint qz: gt_a = act'(xhat) * d/d(dn), zt = d/dz; cdot += sum gb_zs*qz. */
-int gcssl_in_dbl_bwd(int dtype, const void* gb_a, int ldgb, const void* qz, int ldq, const void* gb_zs, int ldgz,
-                     const void* z, int ldz, const float* mean, const float* rstd, void* gt_a, int ldga, void* zt,
+int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, int ldq, const void* gb_zs, int ldgz,
+                     const float* z, int ldz, const float* mean, const float* rstd, void* gt_a, int ldga, float* zt,
                      float* cdot, int N, int HW, int C, int act, void* stream);
 /* LeakyReLU backward for the norm-less layers (D.c1, G.down1; cgan/models.py:103,246), from the activation OUTPUT a. */
-int gcssl_act_bwd(int dtype, const void* da, int ldda, const void* da2, int ldda2, const void* a, int lda,
+int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const void* a, int lda,
                   const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias, float* cdot,
                   int N, int HW, int C, void* stream);
-int gcssl_dot_accum(int dtype, const void* x, int ldx, const void* y, int ldy, long pixels, int C, float* out, void* stream);
+int gcssl_dot_accum(int dtype, const void* x, int ldx, const float* y, int ldy, long pixels, int C, float* out, void* stream);
 
 /* ---- spectral norm power iteration (torch.nn.utils.spectral_norm, cgan/models.py:237-238) -----------------------
  * v <- normalize(W^T u), u <- normalize(W v), eps 1e-12; sigma = u.(W v).  nl <= 4 layers per call; iterate=0 only
@@ -115,8 +120,8 @@ int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long
 
 /* ---- clip_grad_norm_(1.0) + Adam (cgan/cgan_train_enhanced.py:256-257,331-332,368-369) over flat fp32 buffers ---
  * state: 3 doubles {step, sumsq scratch, last total norm}; step is advanced on the device (graph replay safe). */
-int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* state, float lr, float b1, float b2,
-                    float eps, float max_norm, int write_clipped, void* stream);
+int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* state, double lr, double b1, double b2,
+                    double eps, double max_norm, int write_clipped, void* stream);
 
 /* ---- generator head (cgan/models.py:118-123,139-141) and box/EIoU loss (cgan/losses.py:19-73,99-150) ------------- */
 int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, const float* w, const float* bias, float scale,

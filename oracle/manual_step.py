@@ -288,7 +288,7 @@ def eiou_box_loss_and_grad(pred_box: Tensor, delta: Tensor, delta_true: Tensor, 
 # ------------------------------------------------------------------ G forward/backward
 @torch.no_grad()
 def g_forward_backward(sd: Dict[str, Tensor], x: Tensor, delta_scale: float, masks: Sequence[Tensor],
-                       pred_box: Tensor, delta_true: Tensor, lambda_iou: float = 1.0):
+                       pred_box: Tensor, delta_true: Tensor, lambda_iou: float = 1.0, taps: dict = None):
     """GeneratorUNet train-mode forward + hand-written backward of lambda_iou*EIoU (cgan/models.py:125-141,
     cgan/cgan_train_enhanced.py:348-366)."""
     Wd = [sd[f"down{k}.model.0.weight"] for k in (1, 2, 3, 4)]
@@ -345,6 +345,8 @@ def g_forward_backward(sd: Dict[str, Tensor], x: Tensor, delta_scale: float, mas
         xh = (uz[k] - mu) * r
         dn = da * (xh > 0).float()
         dzk = in_bwd(xh, r, dn)
+        if taps is not None:
+            taps[f"dz_u{k + 1}"] = dzk.clone(); taps[f"uin{k + 1}"] = uin[k].clone()
         key = f"up{k + 1}.model.0.weight" if k < 3 else "up4.0.weight"
         grads[key] = conv2d_weight(dzk, Wu[k].shape, uin[k], 2, 1)     # roles swapped for ConvTranspose
         dh = F.conv2d(dzk, Wu[k], None, 2, 1)

@@ -1,0 +1,189 @@
+"""The HIP step engine (through the C ABI) against the golden vectors generated from the REFERENCE's own code
+(tests/golden/*.npz) and against the CPU oracle.  This is the parity test proper.
+
+Tolerances (relative to each tensor's scale):
+  fp32 mode (exact-fp32 MFMA): 1e-3 is the north-star bound; we assert 2e-4 on first-iteration outputs.
+  bf16 mode (bf16 operands / activations, fp32 accumulation): 6e-2 on scores/losses -- reported, not the parity mode.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import check_grad, check_pinned, load_golden, load_pkg, rel_err
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def make_engine(synth, name, dtype):
+    engine = load_pkg("engine")
+    fix = load_golden(name)
+    seed, B, S, n_critic, iters, gray = (int(v) for v in fix["meta"])
+    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+    d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+    eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=n_critic, dtype=dtype, device="cuda:0")
+    return fix, eng, (seed, B, S, n_critic, iters, gray)
+
+
+def inputs_for(synth, name, seed, it, B, S, n_critic, gray):
+    inp = synth.step_inputs(seed + 1000 * it, B, S, n_critic, tag=name)
+    if gray:
+        for key in ("pred", "gt"):
+            z = np.zeros_like(inp[key]); z[:, :, 2:30, 2:30] = inp[key][:, :1, 2:30, 2:30]
+            inp[key] = z
+    return inp
+
+
+def run_iter(eng, inp):
+    refined = [T(r).cuda() for r in inp["refined"]]
+    return eng.iteration(T(inp["pred"]).cuda(), T(inp["gt"]).cuda(), T(inp["delta_true"]).cuda(),
+                         T(inp["pred_box"]).cuda(), lambda delta, k: refined[k],
+                         alphas=[T(a).cuda().view(-1).contiguous() for a in inp["alpha"]],
+                         masks=[[T(m).cuda() for m in ms] for ms in inp["masks"]])
+
+
+@pytest.mark.parametrize("name", ["step_B4_S32", "step_B2_S64", "step_B2_S128", "step_mnist_B4_S32"])
+def test_fp32_step_matches_reference_golden(synth, name):
+    fix, eng, (seed, B, S, n_critic, iters, gray) = make_engine(synth, name, "fp32")
+    full = "it0.c0.d_interp" in fix
+    for it in range(iters):
+        inp = inputs_for(synth, name, seed, it, B, S, n_critic, gray)
+        if it == 0 and full:
+            # run the first critic step by hand so the un-clipped gradients can be inspected
+            pass
+        log = run_iter(eng, inp)
+        for c in range(n_critic):
+            # the very first critic step is a pure function of the fixture inputs: tight bound.  Everything after an
+            # Adam update inherits its ~lr*sign(g) first steps (near-zero gradients may flip sign) -> north-star 1e-3.
+            # Later ITERATIONS start from weights that already differ in a few sign-flipped elements: 5e-3.
+            tol = 2e-4 if (it == 0 and c == 0) else (1e-3 if it == 0 else 5e-3)
+            sc = fix[f"it{it}.c{c}.scalars"]
+            got = np.array([log["d_loss"][c], log["gp"][c], log["wd"][c], log["d_grad_norm"][c]])
+            assert rel_err(got, sc) < tol, (it, c, got, sc)
+            assert rel_err(log["real"][c].cpu().reshape(-1), fix[f"it{it}.c{c}.real_validity"].reshape(-1)) < tol
+            assert rel_err(log["fake"][c].cpu().reshape(-1), fix[f"it{it}.c{c}.fake_validity"].reshape(-1)) < tol
+        gs = fix[f"it{it}.gscalars"]
+        got = np.array([log["loss_g"], log["loss_iou"], log["loss_wgan"], log["g_grad_norm"]])
+        tol = 1e-3 if it == 0 else 5e-3   # the G step sees the critic after n_critic Adam updates
+        assert rel_err(got, gs) < tol, (it, got, gs)
+        tol_g = 2e-4 if it == 0 else 5e-3   # G itself is untouched until its own update
+        assert rel_err(log["delta_pred"].cpu(), fix[f"it{it}.delta_pred"]) < tol_g
+        assert rel_err(log["calibrated"].cpu(), fix[f"it{it}.calibrated"]) < tol_g
+        assert abs(log["loss_iou"] - gs[1]) < tol_g * abs(gs[1])
+        assert rel_err(log["fake_for_g"].cpu().reshape(-1), fix[f"it{it}.fake_validity_for_G"].reshape(-1)) < tol
+        if it == 0 and full:
+            assert rel_err(log["d_interp"][0].cpu().reshape(-1), fix["it0.c0.d_interp"].reshape(-1)) < 2e-4
+    # ---- state after the last iteration: u/v, weights (Adam's first steps are ~lr*sign(g): absolute tolerance)
+    gsd, dsd = eng.state_dicts()
+    last, lr = iters - 1, 2e-4
+    for i in (0, 2, 5, 8):
+        assert rel_err(dsd[f"model.{i}.weight_u"].cpu(), fix[f"it{last}.D.model.{i}.weight_u"]) < 1e-3
+        assert rel_err(dsd[f"model.{i}.weight_v"].cpu(), fix[f"it{last}.D.model.{i}.weight_v"]) < 1e-3
+    for sd, pre, steps in ((dsd, "D", (last + 1) * n_critic), (gsd, "G", last + 1)):
+        for k, v in sd.items():
+            if k.endswith("weight_u") or k.endswith("weight_v"):
+                continue
+            if pre == "D" and k.endswith(".bias") and k != "model.0.bias":
+                continue        # zero-gradient biases (cancelled by InstanceNorm): the reference moves them by rounding noise
+            a = v.cpu().numpy().reshape(-1)
+            key = f"it{last}.{pre}.{k}"
+            atol = 0.05 * lr * steps + 1e-6
+            if key in fix:
+                bad = np.abs(a - fix[key].reshape(-1)) > atol
+            else:
+                smp = a[synth.sample_indices(a.size, 256)]
+                bad = np.abs(smp - fix[key + "@sample"]) > atol
+            # Adam's first steps move every weight by ~lr*sign(g): an element whose (tiny) gradient differs in sign
+            # lands 2*lr away.  Allow 2 % of such elements, and never more than 2*lr*steps of distance.
+            assert bad.mean() <= 0.02, (k, bad.mean())
+            ref = fix[key].reshape(-1) if key in fix else fix[key + "@sample"]
+            got = a if key in fix else smp
+            assert np.abs(got - ref).max() <= 2.2 * lr * steps + 1e-6, k
+
+
+@pytest.mark.parametrize("name", ["step_B4_S32", "step_B2_S64"])
+def test_fp32_first_critic_step_gradients(synth, name):
+    """Un-clipped parameter gradients and the GP input-gradients of the very first critic step, per tensor."""
+    fix, eng, (seed, B, S, n_critic, iters, gray) = make_engine(synth, name, "fp32")
+    inp = inputs_for(synth, name, seed, 0, B, S, n_critic, gray)
+    refined = [T(r).cuda() for r in inp["refined"]]
+    pred, gt = T(inp["pred"]).cuda(), T(inp["gt"]).cuda()
+    eng.lr = 0.0                                    # keep the weights: we only look at gradients
+    eng.d_step(pred, gt, lambda d, k: refined[k], 0, T(inp["alpha"][0]).cuda().view(-1).contiguous(),
+               [T(m).cuda() for m in inp["masks"][0]])
+    torch.cuda.synchronize()
+    total = float(eng.D.state[2])
+    coef = min(1.0, 1.0 / (total + 1e-6))
+    assert abs(total - fix["it0.c0.scalars"][3]) < 2e-4 * total
+    for k in eng.D.keys:
+        if k in ("model.2.bias", "model.5.bias", "model.8.bias"):
+            continue
+        g = eng.D.gviews[k].cpu().numpy() / coef       # clip_adam wrote the clipped gradient back
+        check_grad(fix, f"it0.c0.dgrad.{k}", g, synth, 5e-4)
+    gpx = eng.gb_x0.cpu().permute(0, 3, 1, 2)
+    check_pinned(fix, "it0.c0.gp_grad_pred", gpx[:, :3].contiguous().numpy(), 2e-4, synth)
+    check_pinned(fix, "it0.c0.gp_grad_other", gpx[:, 3:6].contiguous().numpy(), 2e-4, synth)
+    # generator gradients
+    eng.g_step(pred, T(inp["delta_true"]).cuda(), T(inp["pred_box"]).cuda(), lambda d, k: refined[k],
+               [T(m).cuda() for m in inp["masks"][n_critic]])
+    torch.cuda.synchronize()
+    # (the critic was not updated because lr=0, so loss_wgan differs from the fixture; G's gradient does not depend on it)
+    total_g = float(eng.G.state[2])
+    coef_g = min(1.0, 1.0 / (total_g + 1e-6))
+    assert abs(total_g - fix["it0.gscalars"][3]) < 2e-4 * total_g
+    # At S=64 two of the 524288 pre-activations of G.up4 have |xhat| < 1e-6 and take the other ReLU branch than the
+    # reference's CPU run (every upstream tensor agrees to 2e-6; see tests/conftest.check_grad).  Those two elements
+    # perturb ALL upstream-in-backward gradients by up to ~1e-2 of their scale, so that case gets 2e-2; S=32 has no
+    # borderline element and is held to 5e-4.
+    rtol_g, frac = (5e-4, 0.95) if S == 32 else (2e-2, 0.90)
+    for k in eng.G.keys:
+        g = eng.G.gviews[k].cpu().numpy() / coef_g
+        check_grad(fix, f"it0.ggrad.{k}", g, synth, rtol_g, frac_ok=frac)
+
+
+@pytest.mark.parametrize("name", ["step_B4_S32", "step_B2_S64"])
+def test_bf16_step_is_close(synth, name):
+    """bf16 throughput mode: same schedule, bf16 operands.  Error is reported and bounded, not the parity claim."""
+    fix, eng, (seed, B, S, n_critic, iters, gray) = make_engine(synth, name, "bf16")
+    inp = inputs_for(synth, name, seed, 0, B, S, n_critic, gray)
+    log = run_iter(eng, inp)
+    sc = fix["it0.c0.scalars"]
+    got = np.array([log["d_loss"][0], log["gp"][0], log["wd"][0], log["d_grad_norm"][0]])
+    err = rel_err(got, sc)
+    e_real = rel_err(log["real"][0].cpu().reshape(-1), fix["it0.c0.real_validity"].reshape(-1))
+    e_delta = rel_err(log["delta_pred"].cpu(), fix["it0.delta_pred"])
+    print(f"\n[bf16 {name}] scalars rel err {err:.3e}, real-score rel err {e_real:.3e}, delta rel err {e_delta:.3e}")
+    print("   d_loss/gp/wd/gradnorm bf16:", got, " reference fp32:", sc)
+    # Measured on MI355X (round 1): S=64: scalars 3e-4, scores 1e-2, delta 1e-4.  S=32: scores 6e-3, delta 8e-4, GP 3e-2,
+    # but the un-clipped critic gradient norm is 10 % low: at 32x32 input D.c4 normalises over a 2x2 map (4 elements), whose
+    # backward/double-backward amplify the rounding of the bf16 MFMA operands (keeping z and all incoming gradients in
+    # fp32 -- norm.hip -- took the GP error from 18 % to 3 % but cannot remove operand rounding).  fp32 mode is the parity
+    # mode; these bounds only keep the bf16 path from regressing.
+    e_loss = rel_err(got[:3], sc[:3])
+    e_norm = abs(got[3] - sc[3]) / sc[3]
+    assert e_loss < 5e-2 and e_norm < 0.15 and e_real < 3e-2 and e_delta < 1e-2
+
+
+def test_eval_mode_forward_matches_golden(synth):
+    """critic_scores(train=False) / generator_delta(train=False) vs the reference's eval-mode outputs."""
+    engine = load_pkg("engine")
+    for name in ("fwd_B2_S32", "fwd_B2_S64"):
+        fix = load_golden(name)
+        seed, B, S = (int(v) for v in fix["meta"])
+        g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+        d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+        eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=1, dtype="fp32", device="cuda:0")
+        inp = synth.step_inputs(seed, B, S, 1, tag=name)
+        pred, gt = T(inp["pred"]).cuda(), T(inp["gt"]).cuda()
+        sc = eng.critic_scores(pred, gt, train=False).cpu()
+        assert rel_err(sc, fix["eval.d_out"]) < 2e-4
+        dl = eng.generator_delta(pred, train=False).cpu()
+        assert rel_err(dl, fix["eval.g_delta"]) < 2e-4
+        # train mode: one power iteration then forward; u, v must match the reference's buffers
+        sc = eng.critic_scores(pred, gt, train=True).cpu()
+        assert rel_err(sc, fix["train.d_out"]) < 2e-4
+        for l, i in enumerate((0, 2, 5, 8)):
+            assert rel_err(eng.u[l].cpu(), fix[f"train.u.{i}"]) < 1e-4
+            assert rel_err(eng.v[l].cpu(), fix[f"train.v.{i}"]) < 1e-4
+        dl = eng.generator_delta(pred, masks=[T(m).cuda() for m in inp["masks"][0]], train=True).cpu()
+        assert rel_err(dl, fix["train.g_delta"]) < 2e-4

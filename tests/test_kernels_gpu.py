@@ -124,10 +124,10 @@ def test_conv_wgrad(ops, dt, tol, N, Hi, Cin, CinP, Cout):
 @pytest.mark.parametrize("N,H,C,act", [(3, 8, 128, 1), (2, 2, 512, 1), (2, 32, 64, 2), (4, 4, 256, 2)])
 def test_instance_norm_fwd_bwd_dbl(ops, dt, tol, N, H, C, act):
     from oracle import manual_step as M
-    z = q(rnd(N, C, H, H, seed=10, scale=2.0) + 0.3, dt)
-    da = q(rnd(N, C, H, H, seed=11), dt)
+    z = rnd(N, C, H, H, seed=10, scale=2.0) + 0.3          # the pre-norm tensor is fp32 in both modes
+    da = rnd(N, C, H, H, seed=11)                          # ... and so are all incoming gradients
     mask = (rnd(N, C, H, H, seed=12) > 0)
-    zd, dad = nhwc(z, dt), nhwc(da, dt)
+    zd, dad = nhwc(z, torch.float32), nhwc(da, torch.float32)
     maskd = mask.permute(0, 2, 3, 1).contiguous().to("cuda", torch.uint8)
     # forward into a channel slice of a wider (concat) buffer
     wide = torch.zeros(N, H, H, 2 * C, device="cuda", dtype=dt)
@@ -157,17 +157,17 @@ def test_instance_norm_fwd_bwd_dbl(ops, dt, tol, N, H, C, act):
     assert rel_err(nchw(dzs), dz * gsc.cpu()[grp].view(-1, 1, 1, 1)) < tol
     # sum dz (z-b) is analytically ~0 for a normalised layer (sum dz = 0, sum dz xhat ~ eps): judge the error
     # against the magnitude of the summed terms, not against the cancelled result
-    terms = dz * (z - bias.view(1, -1, 1, 1))
+    terms = dz * gsc.cpu()[grp].view(-1, 1, 1, 1) * (z - bias.view(1, -1, 1, 1))
     cd = torch.stack([terms[grp == g].double().sum() for g in range(2)])
     mag = torch.stack([terms[grp == g].abs().double().sum() for g in range(2)])
     assert float(((cdot.cpu().double() - cd).abs() / mag).max()) < max(tol, 1e-5)
     assert float(dbias.abs().max().cpu()) < max(tol, 1e-5) * float(dz.abs().sum(dim=(0, 2, 3)).max())
     # double backward
-    qz = q(rnd(N, C, H, H, seed=14), dt)
+    qz = rnd(N, C, H, H, seed=14)
     gzs = q(rnd(N, C, H, H, seed=15), dt)
-    gt_a = torch.empty(N, H, H, C, device="cuda", dtype=dt); zt = torch.empty(N, H, H, C, device="cuda", dtype=dt)
+    gt_a = torch.empty(N, H, H, C, device="cuda", dtype=dt); zt = torch.empty(N, H, H, C, device="cuda")
     cd2 = torch.zeros(1, device="cuda")
-    ops.in_dbl_bwd(dad, nhwc(qz, dt), nhwc(gzs, dt), zd, mean, rstd, gt_a, zt, C, act, cdot=cd2)
+    ops.in_dbl_bwd(dad, nhwc(qz, torch.float32), nhwc(gzs, dt), zd, mean, rstd, gt_a, zt, C, act, cdot=cd2)
     torch.cuda.synchronize()
     dn2 = da * ag
     gtn, ztr = M.in_bwd_bwd(xh, r, dn2, qz)
@@ -180,12 +180,12 @@ def test_instance_norm_fwd_bwd_dbl(ops, dt, tol, N, H, C, act):
 def test_act_bwd_and_dot(ops, dt, tol):
     N, H, C = 4, 16, 64
     a = q(F.leaky_relu(rnd(N, C, H, H, seed=20), 0.2), dt)
-    da = q(rnd(N, C, H, H, seed=21), dt); da2 = q(rnd(N, C, H, H, seed=22), dt)
+    da = rnd(N, C, H, H, seed=21); da2 = rnd(N, C, H, H, seed=22)
     bias = rnd(C, seed=23, scale=0.1)
     gsc = torch.tensor([2.0, 0.5], device="cuda")
     dzs = torch.empty(N, H, H, C, device="cuda", dtype=dt)
     dbias = torch.zeros(C, device="cuda"); cdot = torch.zeros(2, device="cuda")
-    ops.act_bwd(nhwc(da, dt), nhwc(a, dt), dzs, C, da2=nhwc(da2, dt), gscale=gsc, group_n=2, bias=bias.cuda(),
+    ops.act_bwd(nhwc(da, torch.float32), nhwc(a, dt), dzs, C, da2=nhwc(da2, torch.float32), gscale=gsc, group_n=2, bias=bias.cuda(),
                 dbias=dbias, cdot=cdot)
     torch.cuda.synchronize()
     dz = torch.where(a > 0, da + da2, 0.2 * (da + da2))
@@ -193,15 +193,15 @@ def test_act_bwd_and_dot(ops, dt, tol):
     assert rel_err(nchw(dzs), dz * gsc.cpu()[grp].view(-1, 1, 1, 1)) < tol
     assert rel_err(dbias.cpu(), dz.sum(dim=(0, 2, 3))) < max(tol, 1e-4)
     zrec = torch.where(a > 0, a, a * 5.0)
-    cd = torch.stack([(dz[grp == g] * (zrec[grp == g] - bias.view(1, -1, 1, 1))).sum() for g in range(2)])
+    cd = torch.stack([float(gsc[g]) * (dz[grp == g] * (zrec[grp == g] - bias.view(1, -1, 1, 1))).sum() for g in range(2)])
     assert rel_err(cdot.cpu(), cd) < max(tol, 1e-4)
     out = torch.zeros(1, device="cuda")
-    ops.dot_accum(nhwc(da, dt), nhwc(da2, dt), C, out)
-    assert rel_err(out.cpu(), (da * da2).sum().view(1)) < max(tol, 1e-4)
+    ops.dot_accum(nhwc(q(da, dt), dt), nhwc(da2, torch.float32), C, out)
+    assert rel_err(out.cpu(), (q(da, dt) * da2).sum().view(1)) < max(tol, 1e-4)
 
 
 @pytest.mark.parametrize("dt,tol", DTS)
-@pytest.mark.parametrize("N,H", [(6, 2), (3, 4), (2, 8)])
+@pytest.mark.parametrize("N,H", [(6, 2), (3, 4), (3, 8)])
 def test_critic_head(ops, dt, tol, N, H):
     C = 512
     x = q(rnd(N, C, H, H, seed=30), dt)
@@ -309,8 +309,8 @@ def test_clip_adam_matches_torch(ops):
         assert float(state[0]) == t + 1
         assert rel_err(gd.cpu(), ref.grad) < 1e-5
         assert float((p.cpu() - ref.detach()).abs().max()) < 2e-7
-    assert rel_err(m.cpu(), opt.state[ref]["exp_avg"]) < 1e-5
-    assert rel_err(v.cpu(), opt.state[ref]["exp_avg_sq"]) < 1e-5
+    assert rel_err(m.cpu(), opt.state[ref]["exp_avg"]) < 1e-6
+    assert rel_err(v.cpu(), opt.state[ref]["exp_avg_sq"]) < 1e-6
 
 
 def test_generator_head_and_eiou(ops):
