@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- images/s of the full cGAN WGAN-GP iteration (n_critic critic steps + 1 generator step, optimiser steps
+and gradient all-reduces included) on synthetic 32x32x3 batches, BASELINE.json configs[1]: B=256 per GPU, bf16 MFMA.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for how every field is obtained.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+PKG = "gan-calibrated-semi-supervised-learning_amd"
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense, /opt/skills/guides/MI355X_MICROARCH.md:42-43
+F_D = {32: 0.0535e9, 64: 0.2141e9, 128: 0.8564e9}       # forward FLOPs / image
+F_G = {32: 0.2029e9, 64: 0.8116e9, 128: 3.2464e9}
+
+
+def synthetic_inputs(synth, seed, B, S, c, dev):
+    T = torch.from_numpy
+    inp = synth.step_inputs(seed, B, S, c, tag="bench")
+    return dict(pred=T(inp["pred"]).to(dev), gt=T(inp["gt"]).to(dev), delta_true=T(inp["delta_true"]).to(dev),
+                pred_box=T(inp["pred_box"]).to(dev), refined=[T(r).to(dev) for r in inp["refined"]]), inp
+
+
+def cpu_baseline(synth, seed, B, S, c, budget_s=25.0):
+    """The CPU oracle (oracle/cgan_oracle.py, a port pinned to the reference's golden vectors) on the host cores."""
+    from oracle import cgan_oracle as O
+    T = torch.from_numpy
+    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+    d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+    inp = synth.step_inputs(seed, B, S, c, tag="bench")
+    orc = O.StepOracle(g, d, n_critic=c)
+    refined = [T(r) for r in inp["refined"]]
+    args = (T(inp["pred"]), T(inp["gt"]), T(inp["delta_true"]), T(inp["pred_box"]), lambda dl, k: refined[k],
+            [T(a) for a in inp["alpha"]], [[T(m) for m in ms] for ms in inp["masks"]])
+    t0 = time.perf_counter(); orc.iteration(*args); warm = time.perf_counter() - t0
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.iteration(*args); n += 1
+        el = time.perf_counter() - t0
+        if el + warm > budget_s or n >= 10:
+            break
+    return dict(value=B * n / el, unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} timed iterations (+1 warm-up) of the same B={B}, {S}x{S}, n_critic={c} synthetic step, fp32, "
+                       f"oracle/cgan_oracle.StepOracle on torch CPU ops")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--size", type=int, default=32)
+    ap.add_argument("--n_critic", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    dist_mod = importlib.import_module(PKG + ".dist")
+    rank, world, local = dist_mod.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    synth = importlib.import_module(PKG + ".synth")
+    engine = importlib.import_module(PKG + ".engine")
+    B, S, c = args.batch, args.size, args.n_critic
+    T = torch.from_numpy
+    g = {k: T(v) for k, v in synth.generator_state(42).items()}
+    d = {k: T(v) for k, v in synth.discriminator_state(42).items()}
+    averager = dist_mod.GradAverager() if world > 1 else None
+    eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype=args.dtype, device=dev, seed=42 + rank,
+                            allreduce=averager)
+    data, _ = synthetic_inputs(synth, 42 + rank, B, S, c, dev)          # resident in HBM before anything is timed
+    refine = lambda delta, k: data["refined"][k]
+    call = (data["pred"], data["gt"], data["delta_true"], data["pred_box"], refine)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (eager), then capture
+    for _ in range(max(1, args.warmup)):
+        eng.run_iteration(*call)
+    torch.cuda.synchronize()
+    graphed = None
+    if not args.no_graph:
+        try:
+            graphed = engine.GraphedIteration(eng, *call)
+            graphed.replay(); torch.cuda.synchronize()
+        except Exception as e:                                           # report, then fall back to eager launches
+            print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graphed = None
+    step = graphed.replay if graphed is not None else (lambda: eng.run_iteration(*call))
+
+    # ---- timed region: exactly K iterations between barrier+sync on both sides, max over ranks
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t)
+    ms = el / args.steps * 1e3
+    value = world * B * args.steps / el
+
+    # ---- roofline of the dominant kernel: HIP events around every MFMA conv launch, same buffers, eager launches
+    eng.enable_probe(True)
+    for _ in range(args.probe_steps):
+        eng.run_iteration(*call)
+    prof = eng.probe_summary()
+    eng.enable_probe(False)
+    tot = {k: n * t for k, (n, t, _) in prof.items()}
+    dom = max(tot, key=tot.get)
+    n_dom, ms_dom, fl_dom = prof[dom]
+    conv_ms = sum(tot.values()) / args.probe_steps
+    conv_flops = sum(n * f for (n, _, f) in prof.values()) / args.probe_steps
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    ach = fl_dom / (ms_dom * 1e-3) / 1e12
+    roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                    traffic=None, launches=n_dom, avg_us=round(ms_dom * 1e3, 2),
+                    all_convs=dict(tflops=round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), ms_per_iter=round(conv_ms, 3),
+                                   frac=round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4)))
+    flop_iter = ((12 * c + 1) * F_D[S] + (c + 3) * F_G[S]) * B * world if S in F_D else None
+
+    out = dict(metric="images/sec (G+D step)", value=round(value, 1), unit="images/s", n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=round(ms, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype=args.dtype, data="synthetic",
+               config=dict(workload=f"cGAN WGAN-GP iteration (n_critic={c} critic steps + 1 generator step), "
+                                    f"{S}x{S}x3, batch {B}/GPU, reference G (U-Net) + D (SN PatchGAN)",
+                           global_batch=B * world, img_size=S, n_critic=c, parallelism=f"dp{world}",
+                           launch="hipGraph replay" if graphed is not None else "eager",
+                           algorithmic_tflops=round(flop_iter / (ms * 1e-3) / 1e12, 2) if flop_iter else None),
+               roofline=roofline)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(synth, 42, B, S, c)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,11 @@ class FlatParams:
         raise KeyError(k)
 
 
+def conv_flops(n: int, hi: int, cin: int, cout: int) -> float:
+    """Algorithmic FLOPs (2*MAC) of one k4 s2 p1 conv pass (forward, dgrad or wgrad) over n samples of hi x hi input."""
+    return 2.0 * n * (hi // 2) * (hi // 2) * cout * 16 * cin
+
+
 class StepEngine:
     """Holds G and D (weights, Adam state, spectral-norm u/v) on one GPU and runs reference-ordered iterations.
 
@@ -100,6 +105,31 @@ class StepEngine:
         self._d_dirty = True
         self._g_dirty = True
         self.mask_counter = torch.zeros(1, device=dev, dtype=torch.float64)
+        self.probe = None          # {label: {"events": [(start, stop)...], "flops": f}} when profiling is enabled
+
+    # ------------------------------------------------------------------------------------------ in-situ kernel timing
+    def enable_probe(self, on: bool = True):
+        """Bracket every MFMA conv launch with HIP events on the launch stream (eager mode only)."""
+        self.probe = {} if on else None
+
+    def _conv(self, label: str, flops: float, fn, *args, **kw):
+        if self.probe is None:
+            return fn(*args, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(*args, **kw)
+        e1.record()
+        rec = self.probe.setdefault(label, {"events": [], "flops": flops})
+        rec["events"].append((e0, e1))
+
+    def probe_summary(self):
+        """-> {label: (n_launches, mean_ms, flops_per_launch)} (synchronises)."""
+        torch.cuda.synchronize()
+        out = {}
+        for k, rec in (self.probe or {}).items():
+            ts = [a.elapsed_time(b) for a, b in rec["events"]]
+            out[k] = (len(ts), sum(ts) / max(len(ts), 1), rec["flops"])
+        return out
 
     # ------------------------------------------------------------------------------------------ buffers
     def _alloc(self):
@@ -236,12 +266,13 @@ class StepEngine:
         x = self.x0[:n]
         for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX)):
             bias = self.D.views[f"model.{i}.bias"]
+            fl = conv_flops(n, self.S >> l, cin, cout)
             if l == 0:
-                ops.conv_fwd(x, self.d_wf[0], self.d_a[0][:n], 8, cout, bias=bias, gscale=gscale_of_layer(0),
-                             group_n=group_n, act=LRELU)
+                self._conv(f"D.c1.fwd[n={n}]", fl, ops.conv_fwd, x, self.d_wf[0], self.d_a[0][:n], 8, cout, bias=bias,
+                           gscale=gscale_of_layer(0), group_n=group_n, act=LRELU)
             else:
-                ops.conv_fwd(self.d_a[l - 1][:n], self.d_wf[l], self.d_z[l][:n], cin, cout, bias=bias,
-                             gscale=gscale_of_layer(l), group_n=group_n)
+                self._conv(f"D.c{l + 1}.fwd[n={n}]", fl, ops.conv_fwd, self.d_a[l - 1][:n], self.d_wf[l],
+                           self.d_z[l][:n], cin, cout, bias=bias, gscale=gscale_of_layer(l), group_n=group_n)
                 ops.in_act_fwd(self.d_z[l][:n], self.d_a[l][:n], self.d_mean[l][:n], self.d_rstd[l][:n], cout, LRELU)
         ops.c5_fwd(self.d_a[3][:n], self.d_w5p, self.d_out[:n])
 
@@ -272,17 +303,19 @@ class StepEngine:
         B = self.B
         d1, d2, d3 = self.g_cat3[..., 64:], self.g_cat2[..., 128:], self.g_cat1[..., 256:]
         mk = self.g_masks if train else [None, None, None]
-        ops.conv_fwd(x8, self.gd_wf[0], d1, 8, 64, act=LRELU)
-        ops.conv_fwd(d1, self.gd_wf[1], self.g_zd[1], 64, 128)
+        S = self.S
+        self._conv("G.down1.fwd", conv_flops(B, S, 3, 64), ops.conv_fwd, x8, self.gd_wf[0], d1, 8, 64, act=LRELU)
+        self._conv("G.down2.fwd", conv_flops(B, S // 2, 64, 128), ops.conv_fwd, d1, self.gd_wf[1], self.g_zd[1], 64, 128)
         ops.in_act_fwd(self.g_zd[1], d2, self.g_dmean[1], self.g_drstd[1], 128, LRELU)
-        ops.conv_fwd(d2, self.gd_wf[2], self.g_zd[2], 128, 256)
+        self._conv("G.down3.fwd", conv_flops(B, S // 4, 128, 256), ops.conv_fwd, d2, self.gd_wf[2], self.g_zd[2], 128, 256)
         ops.in_act_fwd(self.g_zd[2], d3, self.g_dmean[2], self.g_drstd[2], 256, LRELU)
-        ops.conv_fwd(d3, self.gd_wf[3], self.g_zd[3], 256, 512)
+        self._conv("G.down4.fwd", conv_flops(B, S // 8, 256, 512), ops.conv_fwd, d3, self.gd_wf[3], self.g_zd[3], 256, 512)
         ops.in_act_fwd(self.g_zd[3], self.g_d4, self.g_dmean[3], self.g_drstd[3], 512, LRELU, mask=mk[0])
         ins = [self.g_d4, self.g_cat1, self.g_cat2, self.g_cat3]
         outs = [self.g_cat1[..., :256], self.g_cat2[..., :128], self.g_cat3[..., :64], self.g_u4]
         for k, (cint, coutt) in enumerate(G_UP):
-            ops.conv_dgrad(ins[k], self.gu_wt[k], self.g_zu[k], coutt, cint)
+            self._conv(f"G.up{k + 1}.fwd", conv_flops(B, S >> (3 - k), coutt, cint), ops.conv_dgrad, ins[k],
+                       self.gu_wt[k], self.g_zu[k], coutt, cint)
             ops.in_act_fwd(self.g_zu[k], outs[k], self.g_umean[k], self.g_urstd[k], coutt, RELU,
                            mask=mk[k + 1] if k < 2 else None)
         ops.pool_fc_tanh_fwd(self.g_u4, self.G.views["fc_delta.1.weight"], self.G.views["fc_delta.1.bias"],
@@ -300,6 +333,20 @@ class StepEngine:
     # ------------------------------------------------------------------------------------------ D step
     def d_step(self, pred, gt, refine_fn, k: int, alpha: Optional[torch.Tensor], masks) -> None:
         """One critic update (cgan/cgan_train_enhanced.py:304-332)."""
+        self.d_compute(pred, gt, refine_fn, k, alpha, masks)
+        self.d_update()
+
+    def d_update(self) -> None:
+        """all-reduce (data parallel) -> clip_grad_norm_(1.0) -> Adam  (:331-332)."""
+        if self.allreduce is not None:
+            self.allreduce(self.D.g)
+        ops.clip_adam(self.D.p, self.D.g, self.D.m, self.D.v, self.D.state, self.lr, self.betas[0], self.betas[1],
+                      write_clipped=True)
+        self._d_dirty = True
+
+    def d_compute(self, pred, gt, refine_fn, k: int, alpha: Optional[torch.Tensor], masks) -> None:
+        """Forward passes, gradient penalty and all critic gradients of one critic step (:305-330); pure kernel
+        launches on the current stream (hipGraph capturable)."""
         B, S, N3 = self.B, self.S, 3 * self.B
         I = slice(2 * B, 3 * B)
         isig = self.sn.isig
@@ -326,17 +373,20 @@ class StepEngine:
             cin, cout = D_CH[l]
             ops.in_act_bwd(self.d_z[l][I], self.d_mean[l][I], self.d_rstd[l][I], self.gb_zs[l], cout, LRELU,
                            da=self.gb_a[l], gscale=isig[l, 2:3], group_n=B)
-            ops.conv_dgrad(self.gb_zs[l], self.d_wt[l], self.gb_a[l - 1], cin, cout)
+            self._conv(f"D.c{l + 1}.gp_dgrad", conv_flops(B, S >> l, cin, cout), ops.conv_dgrad, self.gb_zs[l],
+                       self.d_wt[l], self.gb_a[l - 1], cin, cout)
         ops.act_bwd(self.gb_a[0], self.d_a[0][I], self.gb_zs[0], 64, gscale=isig[0, 2:3], group_n=B)
-        ops.conv_dgrad(self.gb_zs[0], self.d_wt[0], self.gb_x0, 8, 64)
+        self._conv("D.c1.gp_dgrad", conv_flops(B, S, 6, 64), ops.conv_dgrad, self.gb_zs[0], self.d_wt[0], self.gb_x0, 8, 64)
         ops.gp_norm(self.gb_x0, B, self.lambda_gp, self.gp_nrm, self.gp_coef, self.gp_sum)     # :223-231
         # ---- reverse of the chain (the create_graph=True part of d_loss.backward(), :330)
         ops.scale_rows(self.gb_x0, self.gp_coef, self.gt_x, B)
         src = self.gt_x
         for l, (cin, cout) in enumerate(D_CH):
             cp = _pad8(cin)
-            ops.conv_fwd(src, self.d_wf[l], self.gt_z[l], cp, cout, gscale=isig[l, 2:3], group_n=B)
-            ops.conv_wgrad(src, self.gb_zs[l], self.d_slab[l], cp, cout)
+            fl = conv_flops(B, S >> l, cin, cout)
+            self._conv(f"D.c{l + 1}.gp_rev_fwd", fl, ops.conv_fwd, src, self.d_wf[l], self.gt_z[l], cp, cout,
+                       gscale=isig[l, 2:3], group_n=B)
+            self._conv(f"D.c{l + 1}.gp_rev_wgrad", fl, ops.conv_wgrad, src, self.gb_zs[l], self.d_slab[l], cp, cout)
             if l == 0:
                 ops.dot_accum(self.gb_zs[0], self.gt_z[0], 64, self.cdot[0, 2:3])
                 ops.act_bwd(self.gt_z[0], self.d_a[0][I], self.gt_a[0], 64)
@@ -365,20 +415,27 @@ class StepEngine:
                             dbias=gbias, cdot=self.cdot[0])
             nc, nf = self.d_ns[l]
             xin = self.x0 if l == 0 else self.d_a[l - 1]
-            ops.conv_wgrad(xin, self.d_dzs[l], self.d_slab[l][nc:], cp, cout)
+            fl = conv_flops(N3, S >> l, cin, cout)
+            self._conv(f"D.c{l + 1}.wgrad", fl, ops.conv_wgrad, xin, self.d_dzs[l], self.d_slab[l][nc:], cp, cout)
             ops.wgrad_reduce(self.d_slab[l], nc + nf, self.D.gviews[f"model.{i}.weight_orig"], cout, cp, cin,
                              coef=self.cdot[l], u=self.sn.u_hist[l], v=self.sn.v_hist[l], nrank=3)
             if l > 0:
-                ops.conv_dgrad(self.d_dzs[l], self.d_wt[l], self.d_da[l - 1], cin, cout)
-        if self.allreduce is not None:
-            self.allreduce(self.D.g)
-        ops.clip_adam(self.D.p, self.D.g, self.D.m, self.D.v, self.D.state, self.lr, self.betas[0], self.betas[1],
-                      write_clipped=True)                          # :331-332
-        self._d_dirty = True
+                self._conv(f"D.c{l + 1}.dgrad", fl, ops.conv_dgrad, self.d_dzs[l], self.d_wt[l], self.d_da[l - 1], cin, cout)
 
     # ------------------------------------------------------------------------------------------ G step
     def g_step(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
         """The generator update (cgan/cgan_train_enhanced.py:345-369)."""
+        self.g_compute(pred, delta_true, pred_box, refine_fn, masks)
+        self.g_update()
+
+    def g_update(self) -> None:
+        if self.allreduce is not None:
+            self.allreduce(self.G.g)
+        ops.clip_adam(self.G.p, self.G.g, self.G.m, self.G.v, self.G.state, self.lr, self.betas[0], self.betas[1],
+                      write_clipped=True)                                               # :368-369
+        self._g_dirty = True
+
+    def g_compute(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
         B, S = self.B, self.S
         self.scal[13:].zero_()
         self._prep_g()
@@ -410,9 +467,11 @@ class StepEngine:
             else:
                 ops.in_act_bwd(self.g_zu[k], self.g_umean[k], self.g_urstd[k], self.g_dzu[k], coutt, RELU,
                                da=dcat[k + 1][..., :coutt], mask=self.g_masks[k + 1] if k < 2 else None)
-            ops.conv_wgrad(self.g_dzu[k], ins[k], self.g_slab_u[k], coutt, cint)       # roles swapped (ConvTranspose)
+            fl = conv_flops(B, S >> (3 - k), coutt, cint)
+            self._conv(f"G.up{k + 1}.wgrad", fl, ops.conv_wgrad, self.g_dzu[k], ins[k], self.g_slab_u[k], coutt,
+                       cint)                                                            # roles swapped (ConvTranspose)
             ops.wgrad_reduce(self.g_slab_u[k], self.g_ns_u[k], gW[key], cint, coutt, coutt)
-            ops.conv_fwd(self.g_dzu[k], self.gu_wf[k], dcat[k], coutt, cint)
+            self._conv(f"G.up{k + 1}.dgrad", fl, ops.conv_fwd, self.g_dzu[k], self.gu_wf[k], dcat[k], coutt, cint)
         d_act = [self.g_cat3[..., 64:], self.g_cat2[..., 128:], self.g_cat1[..., 256:]]            # d1, d2, d3
         dskip = [self.g_dcat3[..., 64:], self.g_dcat2[..., 128:], self.g_dcat1[..., 256:]]
         for k in (3, 2, 1, 0):
@@ -427,15 +486,11 @@ class StepEngine:
             else:
                 ops.act_bwd(self.g_dd[1], d_act[0], self.g_dzd[0], 64, da2=dskip[0])
             xin = self.x0[:B] if k == 0 else d_act[k - 1]
-            ops.conv_wgrad(xin, self.g_dzd[k], self.g_slab_d[k], cp, cout)
+            fl = conv_flops(B, S >> k, cin, cout)
+            self._conv(f"G.down{k + 1}.wgrad", fl, ops.conv_wgrad, xin, self.g_dzd[k], self.g_slab_d[k], cp, cout)
             ops.wgrad_reduce(self.g_slab_d[k], self.g_ns_d[k], gW[f"down{k + 1}.model.0.weight"], cout, cp, cin)
             if k > 0:
-                ops.conv_dgrad(self.g_dzd[k], self.gd_wt[k], self.g_dd[k], cin, cout)
-        if self.allreduce is not None:
-            self.allreduce(self.G.g)
-        ops.clip_adam(self.G.p, self.G.g, self.G.m, self.G.v, self.G.state, self.lr, self.betas[0], self.betas[1],
-                      write_clipped=True)                                               # :368-369
-        self._g_dirty = True
+                self._conv(f"G.down{k + 1}.dgrad", fl, ops.conv_dgrad, self.g_dzd[k], self.gd_wt[k], self.g_dd[k], cin, cout)
 
     # ------------------------------------------------------------------------------------------ iteration
     def run_iteration(self, pred, gt, delta_true, pred_box, refine_fn, alphas=None, masks=None, on_critic=None):
@@ -477,3 +532,43 @@ class StepEngine:
             d[f"model.{i}.weight_u"] = self.u[l].clone()
             d[f"model.{i}.weight_v"] = self.v[l].clone()
         return g, d
+
+
+class GraphedIteration:
+    """One training iteration as hipGraphs: the launch-bound kernel sequences of each critic step and of the generator
+    step are captured once (torch.cuda.CUDAGraph == hipGraph on ROCm; our ctypes launches go to the capturing stream)
+    and replayed.  With data parallelism the all-reduce + clip/Adam stay outside the graphs, between the segments;
+    single-GPU runs capture the update too.  Inputs are static device tensors; alpha and dropout masks are drawn on the
+    device inside the graph (torch's graph-safe Philox / the counter-based mask kernel), so every replay differs."""
+
+    def __init__(self, eng: "StepEngine", pred, gt, delta_true, pred_box, refine_fn):
+        self.eng = eng
+        self.fused_update = eng.allreduce is None
+        self.d_graphs, self.g_graph = [], None
+        pool = None
+        for k in range(eng.c):
+            eng._d_dirty, eng._g_dirty = True, (k == 0)       # weights change between replays: keep the prep kernels
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                eng.d_compute(pred, gt, refine_fn, k, None, None)
+                if self.fused_update:
+                    eng.d_update()
+            pool = g.pool()
+            self.d_graphs.append(g)
+        eng._d_dirty, eng._g_dirty = True, False
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool):
+            eng.g_compute(pred, delta_true, pred_box, refine_fn, None)
+            if self.fused_update:
+                eng.g_update()
+        self.g_graph = g
+
+    def replay(self):
+        eng = self.eng
+        for g in self.d_graphs:
+            g.replay()
+            if not self.fused_update:
+                eng.d_update()
+        self.g_graph.replay()
+        if not self.fused_update:
+            eng.g_update()
