@@ -132,6 +132,11 @@ def main():
     prof = eng.probe_summary()
     eng.enable_probe(False)
     tot = {k: n * t for k, (n, t, _) in prof.items()}
+    if os.environ.get("GCSSL_BENCH_VERBOSE") and rank == 0:
+        for k in sorted(tot, key=tot.get, reverse=True):
+            n, t, f = prof[k]
+            print(f"[probe] {k:24s} {n // args.probe_steps:3d}/iter  {t * 1e3:8.1f} us  {f / (t * 1e-3) / 1e12:8.1f} TF/s  "
+                  f"{f / 1e9:7.2f} GF", file=sys.stderr)
     dom = max(tot, key=tot.get)
     n_dom, ms_dom, fl_dom = prof[dom]
     conv_ms = sum(tot.values()) / args.probe_steps

@@ -14,6 +14,7 @@
 // (dgrad); weight gradients land in fp32 split-K slabs [split][Cout][16][Cin] that
 // gcssl_wgrad_reduce sums into the PyTorch-layout gradient.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -129,7 +130,8 @@ struct ConvParams {
     int M;              // GEMM rows
     int act;            // fwd epilogue: 1 = LeakyReLU(0.2)
     int out_f32;        // fwd/dgrad: write fp32 regardless of T
-    int ktiles_per_split;   // wgrad
+    int ktiles_per_split;   // wgrad; fwd/dgrad when ksplit > 1
+    int ksplit;             // fwd/dgrad: K is split over ksplit workgroups that atomically add into a zeroed fp32 output
 };
 
 // ------------------------------------------------------------------------------------------
@@ -194,13 +196,19 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = K / BK;
-    gload(0); lstore(0); __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) gload((t + 1) * BK);
-        mma_slab<TM, TN>(As[t & 1], Bs[t & 1], wm0, wn0, lane, acc);
-        if (t + 1 < nk) lstore((t + 1) & 1);
-        __syncthreads();
+    const int nk_all = K / BK;
+    const int ks = p.ksplit > 1 ? (int)blockIdx.z : 0;
+    const int t_beg = p.ksplit > 1 ? ks * p.ktiles_per_split : 0;
+    const int t_end = p.ksplit > 1 ? min(nk_all, t_beg + p.ktiles_per_split) : nk_all;
+    if (t_beg < t_end) {
+        gload(t_beg * BK); lstore(0); __syncthreads();
+        for (int t = t_beg; t < t_end; ++t) {
+            const int b = (t - t_beg) & 1;
+            if (t + 1 < t_end) gload((t + 1) * BK);
+            mma_slab<TM, TN>(As[b], Bs[b], wm0, wn0, lane, acc);
+            if (t + 1 < t_end) lstore(b ^ 1);
+            __syncthreads();
+        }
     }
     // epilogue (out_f32: the pre-norm tensor z stays fp32 in bf16 mode, see norm.hip)
     T* y = static_cast<T*>(p.y);
@@ -218,6 +226,11 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
                 const int co = n0 + wn0 + 32 * j + (lane & 31);
                 if (co >= p.Cout) continue;
                 float v = acc[i][j][r] * s;
+                if (p.ksplit > 1) {                       // linear epilogue only: partial sums add up, bias once
+                    if (p.bias && ks == 0) v += p.bias[co];
+                    atomicAdd(y32 + (size_t)m * p.ldy + co, v);
+                    continue;
+                }
                 if (p.bias) v += p.bias[co];
                 if (p.act == 1) v = lrelu_f(v);
                 if (p.out_f32) y32[(size_t)m * p.ldy + co] = v;
@@ -240,7 +253,9 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
     __shared__ KMajor<T, BN> Bs[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int py = blockIdx.z >> 1, px = blockIdx.z & 1;
+    const int cls = p.ksplit > 1 ? (int)blockIdx.z / p.ksplit : (int)blockIdx.z;
+    const int ks = p.ksplit > 1 ? (int)blockIdx.z % p.ksplit : 0;
+    const int py = cls >> 1, px = cls & 1;
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
     const T* dy = static_cast<const T*>(p.x);
     const T* wt = static_cast<const T*>(p.w);
@@ -288,13 +303,18 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int nk = K / BK;
-    gload(0); lstore(0); __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) gload((t + 1) * BK);
-        mma_slab<TM, TN>(As[t & 1], Bs[t & 1], wm0, wn0, lane, acc);
-        if (t + 1 < nk) lstore((t + 1) & 1);
-        __syncthreads();
+    const int nk_all = K / BK;
+    const int t_beg = p.ksplit > 1 ? ks * p.ktiles_per_split : 0;
+    const int t_end = p.ksplit > 1 ? min(nk_all, t_beg + p.ktiles_per_split) : nk_all;
+    if (t_beg < t_end) {
+        gload(t_beg * BK); lstore(0); __syncthreads();
+        for (int t = t_beg; t < t_end; ++t) {
+            const int b = (t - t_beg) & 1;
+            if (t + 1 < t_end) gload((t + 1) * BK);
+            mma_slab<TM, TN>(As[b], Bs[b], wm0, wn0, lane, acc);
+            if (t + 1 < t_end) lstore(b ^ 1);
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -312,7 +332,8 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
                 const int ci = n0 + wn0 + 32 * j + (lane & 31);
                 if (ci >= p.Cin) continue;
                 const float v = acc[i][j][r] * s;
-                if (p.out_f32) static_cast<float*>(p.y)[pix * p.ldy + ci] = v;
+                if (p.ksplit > 1) atomicAdd(static_cast<float*>(p.y) + pix * p.ldy + ci, v);
+                else if (p.out_f32) static_cast<float*>(p.y)[pix * p.ldy + ci] = v;
                 else Elem<T>::st(static_cast<T*>(p.y) + pix * p.ldy + ci, v);
             }
         }
@@ -409,22 +430,44 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
 
 // sum the split-K slabs, apply the spectral-norm rank-1 corrections, write PyTorch layout
 //   dw[co][ci][tap] (+)= sum_s slab[s][co][tap][ci]  - sum_k coef[k]*cscale[k] u_k[co] v_k[ci*16+tap]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, float* __restrict__ dw,
+// One workgroup = one co x 64 ci x 16 taps: slab reads are coalesced along ci, the [tap][ci] -> [ci][tap] transpose
+// goes through LDS, and the 4-KB output chunk dw[co][ci0..ci0+63][0..15] is written contiguously.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, float* __restrict__ dw,
                                     int Cout, int Cin, int Cin_real, const float* coef, const float* cscale,
                                     const float* u, int ustride, const float* v, int vstride, int nrank,
                                     int accumulate) {
-    // one thread per (co, tap, ci): consecutive threads -> consecutive ci (coalesced slab reads)
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float tile[16][65];
+    const int co = blockIdx.y, ci0 = blockIdx.x * 64;
+    const int cw = min(64, Cin - ci0);                       // channels in this chunk (8 for the padded first layer)
     const size_t total = (size_t)Cout * 16 * Cin;
-    if (idx >= total) return;
-    const int ci = idx % Cin, tap = (idx / Cin) % 16, co = idx / ((size_t)Cin * 16);
-    if (ci >= Cin_real) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * total + idx];
-    for (int k = 0; k < nrank; ++k)
-        s -= coef[k] * (cscale ? cscale[k] : 1.f) * u[(size_t)k * ustride + co] * v[(size_t)k * vstride + ci * 16 + tap];
-    float* o = dw + ((size_t)co * Cin_real + ci) * 16 + tap;
-    *o = accumulate ? (*o + s) : s;
+    // blockIdx.z owns a group of splits (accumulate == 2: dw was zeroed by the caller, groups add atomically)
+    const int per = (nsplit + gridDim.z - 1) / gridDim.z;
+    const int k0 = blockIdx.z * per, k1 = min(nsplit, k0 + per);
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+        const int tap = e >> 6, cil = e & 63;
+        if (cil >= cw) continue;
+        const size_t idx = ((size_t)co * 16 + tap) * Cin + ci0 + cil;
+        float s = 0.f;
+        for (int k = k0; k < k1; ++k) s += slab[(size_t)k * total + idx];
+        tile[tap][cil] = s;
+    }
+    __syncthreads();
+    float uk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        uk[k] = (k < nrank && blockIdx.z == 0) ? coef[k] * (cscale ? cscale[k] : 1.f) * u[(size_t)k * ustride + co] : 0.f;
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+        const int cil = e >> 4, tap = e & 15;
+        const int ci = ci0 + cil;
+        if (cil >= cw || ci >= Cin_real) continue;
+        float s = tile[tap][cil];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nrank) s -= uk[k] * v[(size_t)k * vstride + ci * 16 + tap];
+        float* o = dw + ((size_t)co * Cin_real + ci) * 16 + tap;
+        if (accumulate == 2) atomicAdd(o, s);
+        else *o = accumulate ? (*o + s) : s;
+    }
 }
 
 // fp32 PyTorch-layout weight [Cout][Cin][4][4] -> packed operand layouts in T
@@ -442,13 +485,13 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 
 template <typename T, int BM, int BN>
 int launch_fwd(const ConvParams& p, hipStream_t st) {
-    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, 1);
+    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
     hipLaunchKernelGGL((conv_fwd_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
 }
 template <typename T, int BM, int BN>
 int launch_dgrad(const ConvParams& p, hipStream_t st) {
-    dim3 grid((p.M + BM - 1) / BM, (p.Cin + BN - 1) / BN, 4);
+    dim3 grid((p.M + BM - 1) / BM, (p.Cin + BN - 1) / BN, 4 * (p.ksplit > 1 ? p.ksplit : 1));
     hipLaunchKernelGGL((conv_dgrad_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
 }
@@ -468,18 +511,53 @@ void fill_geom(ConvParams& p, int N, int Hi, int Wi, int Cin, int Cout) {
 }
 
 // pick the workgroup tile so that the grid fills the 256 CUs when the problem allows it
+// Small-M layers (G.down4, the GP chain at batch B, ...) would launch far fewer than 2 workgroups per CU with a
+// 64..128-deep serial K loop each: they are latency-bound, not MFMA-bound.  When the output is fp32 and the epilogue
+// linear, split K across workgroups and accumulate with fp32 atomics into a zeroed output (128-B contiguous per
+// half-wave: the full-rate atomic shape of MI355X_MICROARCH.md "Global float atomics").
+int pick_ksplit(long tiles, int nk, bool allowed) {
+    if (!allowed || tiles >= 384 || nk < 16) return 1;
+    int ks = (int)((512 + tiles - 1) / tiles);
+    if (ks > 8) ks = 8;
+    while (ks > 1 && nk / ks < 8) --ks;
+    return ks;
+}
+
+int zero_output(const ConvParams& p, long rows, int cols, hipStream_t st) {
+    hipError_t e = hipMemset2DAsync(p.y, (size_t)p.ldy * 4, 0, (size_t)cols * 4, (size_t)rows, st);
+    return e == hipSuccess ? GCSSL_OK : (int)e;
+}
+
 template <typename T>
-int dispatch_fwd(const ConvParams& p, hipStream_t st) {
+int dispatch_fwd(ConvParams p, hipStream_t st) {
     const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if (p.Cout >= 128 && t128 >= 256) return launch_fwd<T, 128, 128>(p, st);
     if (p.Cout >= 64 && (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64) >= 256) return launch_fwd<T, 128, 64>(p, st);
+    const long t64 = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64);
+    const int nk = 16 * p.Cin / BK;
+    const bool f32out = p.out_f32 || std::is_same<T, float>::value;
+    p.ksplit = pick_ksplit(t64, nk, f32out && p.act == 0);
+    if (p.ksplit > 1) {
+        p.ktiles_per_split = (nk + p.ksplit - 1) / p.ksplit;
+        int rc = zero_output(p, p.M, p.Cout, st);
+        if (rc) return rc;
+    }
     return launch_fwd<T, 64, 64>(p, st);
 }
 template <typename T>
-int dispatch_dgrad(const ConvParams& p, hipStream_t st) {
+int dispatch_dgrad(ConvParams p, hipStream_t st) {
     const long t128 = 4L * ((p.M + 127) / 128) * ((p.Cin + 127) / 128);
     if (p.Cin >= 128 && t128 >= 256) return launch_dgrad<T, 128, 128>(p, st);
     if (p.Cin >= 64 && 4L * ((p.M + 127) / 128) * ((p.Cin + 63) / 64) >= 256) return launch_dgrad<T, 128, 64>(p, st);
+    const long t64 = 4L * ((p.M + 63) / 64) * ((p.Cin + 63) / 64);
+    const int nk = 4 * p.Cout / BK;
+    const bool f32out = p.out_f32 || std::is_same<T, float>::value;
+    p.ksplit = pick_ksplit(t64, nk, f32out);
+    if (p.ksplit > 1) {
+        p.ktiles_per_split = (nk + p.ksplit - 1) / p.ksplit;
+        int rc = zero_output(p, (long)p.N * p.Hi * p.Wi, p.Cin, st);
+        if (rc) return rc;
+    }
     return launch_dgrad<T, 64, 64>(p, st);      // Cin < 64 (first layer, Cin padded to 8): masked columns
 }
 
@@ -531,6 +609,7 @@ int gcssl_conv4x4s2_wgrad_splits(int N, int Hi, int Wi, int Cin, int Cout) {
     const long tiles = (long)(Cout / bm) * 16 * (Cin / bn) / (Cin == 8 ? 16 : 1);
     const int nkt = (N * (Hi / 2) * (Wi / 2) + BK - 1) / BK;
     long want = (512 + tiles - 1) / tiles;                 // ~2 workgroups per CU
+    if (want > 128) want = 128;                            // padded first layers have a single tile: bound the slab count
     if (want < 1) want = 1;
     if (want > nkt) want = nkt;
     const int per = (nkt + (int)want - 1) / (int)want;
@@ -574,9 +653,10 @@ int gcssl_wgrad_reduce(const float* slab, int nsplit, float* dw, int Cout, int C
                        int vstride, int nrank, int accumulate, void* stream) {
     if (!slab || !dw || (nrank > 0 && (!coef || !u || !v))) return GCSSL_ENULL;
     if (nsplit <= 0 || Cout <= 0 || Cin <= 0 || Cin_real <= 0 || Cin_real > Cin) return GCSSL_EBADSHAPE;
-    if (nrank > 0 && (ustride < Cout || vstride < Cin_real * 16)) return GCSSL_EBADSHAPE;
-    const size_t total = (size_t)Cout * 16 * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    if (nrank > 4 || (nrank > 0 && (ustride < Cout || vstride < Cin_real * 16))) return GCSSL_EBADSHAPE;
+    int zg = 1;
+    if (accumulate == 2) { zg = (nsplit + 15) / 16; if (zg > 16) zg = 16; }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + 63) / 64), (unsigned)Cout, (unsigned)zg), dim3(256), 0,
                        (hipStream_t)stream, slab, nsplit, dw, Cout, Cin, Cin_real, coef, cscale, u, ustride, v, vstride, nrank, accumulate);
     return gcssl_launch_status();
 }

@@ -285,15 +285,20 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
 // generator head  cgan/models.py:118-123,139-141: mean over H*W -> Linear(64,4) -> tanh -> * delta_scale
 // =========================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void pool_fc_tanh_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void pool_fc_tanh_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ pool_sum,
+                                                          const float* __restrict__ w,
                                                           const float* __restrict__ bias, float scale, float* __restrict__ pooled,
                                                           float* __restrict__ traw, float* __restrict__ delta, int HW) {
     __shared__ float sm[4][64];
     __shared__ float pl[64];
     const int n = blockIdx.x, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const T* xp = x + (size_t)n * HW * ldx + tx;
     float s = 0.f;
-    for (int p = ty; p < HW; p += 4) s += Elem<T>::ld(xp + (size_t)p * ldx);
+    if (pool_sum) {                                   // sums already accumulated by gcssl_in_act_fwd(pool=...)
+        if (ty == 0) s = pool_sum[(size_t)n * 64 + tx];
+    } else {
+        const T* xp = x + (size_t)n * HW * ldx + tx;
+        for (int p = ty; p < HW; p += 4) s += Elem<T>::ld(xp + (size_t)p * ldx);
+    }
     sm[ty][tx] = s;
     __syncthreads();
     if (ty == 0) { const float pm = (sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx]) / HW; pl[tx] = pm; pooled[(size_t)n * 64 + tx] = pm; }
@@ -307,26 +312,31 @@ __global__ __launch_bounds__(256) void pool_fc_tanh_kernel(const T* __restrict__
     }
 }
 
-// head backward: dy = g_delta*scale*(1-t^2); dW = dy^T pooled; db = sum dy; da_bcast[n][c] = (dy W)[c] / HW
+// head backward: dy = g_delta*scale*(1-t^2); dW += dy^T pooled; db += sum dy (atomic, caller zeroes);
+// da_bcast[n][c] = (dy W)[c] / HW.  One workgroup per 16 samples: 256 threads = 4 outputs x 64 channels.
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ g_delta, const float* __restrict__ traw,
                                                       const float* __restrict__ pooled, const float* __restrict__ w, float scale,
                                                       int B, int HW, float* __restrict__ dw, float* __restrict__ db,
                                                       float* __restrict__ da_bcast) {
-    // single block: 256 threads = 4 outputs x 64 channels
+    __shared__ float dy[16][4];
+    const int n0 = blockIdx.x * 16, nn = min(16, B - n0);
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x >> 2, k = threadIdx.x & 3;
+        float v = 0.f;
+        if (i < nn) { const float t = traw[(n0 + i) * 4 + k]; v = g_delta[(n0 + i) * 4 + k] * scale * (1.f - t * t); }
+        dy[i][k] = v;
+    }
+    __syncthreads();
     const int j = threadIdx.x >> 6, c = threadIdx.x & 63;
     float acc = 0.f, accb = 0.f;
-    for (int n = 0; n < B; ++n) {
-        const float t = traw[n * 4 + j];
-        const float dy = g_delta[n * 4 + j] * scale * (1.f - t * t);
-        acc += dy * pooled[(size_t)n * 64 + c];
-        accb += dy;
-    }
-    dw[j * 64 + c] = acc;
-    if (c == 0) db[j] = accb;
-    for (int n = j; n < B; n += 4) {
+    for (int i = 0; i < nn; ++i) { acc += dy[i][j] * pooled[(size_t)(n0 + i) * 64 + c]; accb += dy[i][j]; }
+    atomicAdd(dw + j * 64 + c, acc);
+    if (c == 0) atomicAdd(db + j, accb);
+    for (int i = j; i < nn; i += 4) {
         float s = 0.f;
-        for (int k = 0; k < 4; ++k) { const float t = traw[n * 4 + k]; s += g_delta[n * 4 + k] * scale * (1.f - t * t) * w[k * 64 + c]; }
-        da_bcast[(size_t)n * 64 + c] = s / HW;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += dy[i][k] * w[k * 64 + c];
+        da_bcast[(size_t)(n0 + i) * 64 + c] = s / HW;
     }
 }
 
@@ -568,13 +578,13 @@ int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* stat
     return gcssl_launch_status();
 }
 
-int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, const float* w, const float* bias, float scale,
-                           float* pooled, float* traw, float* delta, int B, int HW, int C, void* stream) {
-    if (!x || !w || !bias || !pooled || !traw || !delta) return GCSSL_ENULL;
+int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, const float* pool_sum, const float* w, const float* bias,
+                           float scale, float* pooled, float* traw, float* delta, int B, int HW, int C, void* stream) {
+    if ((!x && !pool_sum) || !w || !bias || !pooled || !traw || !delta) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (B <= 0 || HW <= 0 || C != 64 || ldx < C) return GCSSL_EBADSHAPE;
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(pool_fc_tanh_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, w, bias, scale, pooled, traw, delta, HW);
-    else hipLaunchKernelGGL(pool_fc_tanh_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, w, bias, scale, pooled, traw, delta, HW);
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(pool_fc_tanh_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, pool_sum, w, bias, scale, pooled, traw, delta, HW);
+    else hipLaunchKernelGGL(pool_fc_tanh_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, pool_sum, w, bias, scale, pooled, traw, delta, HW);
     return gcssl_launch_status();
 }
 
@@ -582,7 +592,7 @@ int gcssl_head_bwd(const float* g_delta, const float* traw, const float* pooled,
                    int HW, float* dw, float* db, float* da_bcast, void* stream) {
     if (!g_delta || !traw || !pooled || !w || !dw || !db || !da_bcast) return GCSSL_ENULL;
     if (B <= 0 || HW <= 0) return GCSSL_EBADSHAPE;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, g_delta, traw, pooled, w, scale, B, HW, dw, db, da_bcast);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, g_delta, traw, pooled, w, scale, B, HW, dw, db, da_bcast);
     return gcssl_launch_status();
 }
 

@@ -39,30 +39,171 @@ __device__ __forceinline__ void combine(float (&v)[NV], float (*sm)[RG][CW], int
 __device__ __forceinline__ float act_fwd(float x, int act) { return act == 1 ? lrelu_f(x) : (x > 0.f ? x : 0.f); }
 __device__ __forceinline__ float act_grad(float xhat, int act) { return xhat > 0.f ? 1.f : (act == 1 ? 0.2f : 0.f); }
 
-// a = act((z - mean) * rstd) [* keep * 2];  writes mean/rstd [N][C]
+// ------------------------------------------------------------------------------------------------------------
+// Vectorised layout shared by the forward/backward kernels: a workgroup = 64 channels x 16 row groups, every lane
+// owns 4 consecutive channels (one 16-byte load of the fp32 z / incoming gradient per row, 8-byte bf16 stores).
+//   small maps (H*W <= 64): one fused kernel, the <=4 rows of a lane stay in registers -> z is read ONCE, two-pass
+//                           exact statistics;
+//   large maps:             stats (shifted sums, atomics) -> finalize -> apply, all fully parallel over H*W chunks.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int VC = 4, CGN = 16, RGN = 16, MAXR = 4, SMALL_HW = RGN * MAXR;
+
+template <int NV>
+__device__ __forceinline__ void combine16(float (&v)[NV][VC], float (*sm)[RGN][CW], int tx, int ty) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < VC; ++j) sm[i][ty][tx * VC + j] = v[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < VC; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < RGN; ++g) s += sm[i][g][tx * VC + j];
+            v[i][j] = s;
+        }
+}
+
+__device__ __forceinline__ void ld4(const float* p, float (&o)[VC]) {
+    const float4 t = *reinterpret_cast<const float4*>(p); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float (&v)[VC]);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v)[VC]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&v)[VC]) {
+    uint2 w;
+    w.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+    w.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = w;
+}
+__device__ __forceinline__ void keep4(const uint8_t* mp, float (&k)[VC]) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(mp);
+#pragma unroll
+    for (int j = 0; j < VC; ++j) k[j] = ((w >> (8 * j)) & 0xFF) ? 2.f : 0.f;
+}
+
+// ---- forward, small maps: a = act((z - mean) * rstd) [* keep * 2]; writes mean/rstd [N][C]
 template <typename T>
-__global__ __launch_bounds__(CW * RG) void in_act_fwd_kernel(const float* __restrict__ z, int ldz, T* __restrict__ a, int lda,
-                                                            float* __restrict__ mean, float* __restrict__ rstd,
-                                                            const uint8_t* __restrict__ mask, int HW, int C, int act) {
-    __shared__ float sm[1][RG][CW];
-    const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
-    const int c = blockIdx.x * CW + tx, n = blockIdx.y;
+__global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(const float* __restrict__ z, int ldz, T* __restrict__ a, int lda,
+                                                                float* __restrict__ mean, float* __restrict__ rstd,
+                                                                const uint8_t* __restrict__ mask, int HW, int C, int act) {
+    __shared__ float sm[1][RGN][CW];
+    const int tx = threadIdx.x % CGN, ty = threadIdx.x / CGN;
+    const int c = blockIdx.x * CW + tx * VC, n = blockIdx.y;
     const float* zp = z + (size_t)n * HW * ldz + c;
-    float s[1] = {0.f};
-    for (int p = ty; p < HW; p += RG) s[0] += zp[(size_t)p * ldz];
-    combine<1>(s, sm, tx, ty);
-    const float mu = s[0] / HW;
-    s[0] = 0.f;
-    for (int p = ty; p < HW; p += RG) { const float d = zp[(size_t)p * ldz] - mu; s[0] += d * d; }
-    combine<1>(s, sm, tx, ty);
-    const float r = 1.0f / sqrtf(s[0] / HW + IN_EPS);
-    if (ty == 0) { mean[(size_t)n * C + c] = mu; rstd[(size_t)n * C + c] = r; }
+    float v[MAXR][VC];
+    float s[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int p = ty + RGN * i;
+        if (p < HW) {
+            ld4(zp + (size_t)p * ldz, v[i]);
+#pragma unroll
+            for (int j = 0; j < VC; ++j) s[0][j] += v[i][j];
+        }
+    }
+    combine16<1>(s, sm, tx, ty);
+    float mu[VC], r[VC];
+#pragma unroll
+    for (int j = 0; j < VC; ++j) { mu[j] = s[0][j] / HW; s[0][j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i)
+        if (ty + RGN * i < HW) {
+#pragma unroll
+            for (int j = 0; j < VC; ++j) { const float d = v[i][j] - mu[j]; s[0][j] += d * d; }
+        }
+    combine16<1>(s, sm, tx, ty);
+#pragma unroll
+    for (int j = 0; j < VC; ++j) r[j] = 1.0f / sqrtf(s[0][j] / HW + IN_EPS);
+    if (ty == 0) {
+        st4<float>(mean + (size_t)n * C + c, mu);
+        st4<float>(rstd + (size_t)n * C + c, r);
+    }
     T* ap = a + (size_t)n * HW * lda + c;
-    const uint8_t* mp = mask ? mask + (size_t)n * HW * C + c : nullptr;
-    for (int p = ty; p < HW; p += RG) {
-        float v = act_fwd((zp[(size_t)p * ldz] - mu) * r, act);
-        if (mp) v *= mp[(size_t)p * C] ? 2.f : 0.f;
-        Elem<T>::st(ap + (size_t)p * lda, v);
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int p = ty + RGN * i;
+        if (p >= HW) continue;
+        float o[VC], k[VC] = {1.f, 1.f, 1.f, 1.f};
+        if (mask) keep4(mask + ((size_t)n * HW + p) * C + c, k);
+#pragma unroll
+        for (int j = 0; j < VC; ++j) o[j] = act_fwd((v[i][j] - mu[j]) * r[j], act) * k[j];
+        st4<T>(ap + (size_t)p * lda, o);
+    }
+}
+
+// ---- forward, large maps.  (1) shifted sums: s1 += sum(z - z0), s2 += sum((z - z0)^2), z0 = z[n, 0, c]
+__global__ __launch_bounds__(CGN * RGN) void in_stats_kernel(const float* __restrict__ z, int ldz, float* __restrict__ s1,
+                                                            float* __restrict__ s2, int HW, int C) {
+    __shared__ float sm[2][RGN][CW];
+    const int tx = threadIdx.x % CGN, ty = threadIdx.x / CGN;
+    const int c = blockIdx.x * CW + tx * VC, n = blockIdx.y;
+    const float* zp = z + (size_t)n * HW * ldz + c;
+    float z0[VC]; ld4(zp, z0);
+    float s[2][VC] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int p0 = blockIdx.z * SMALL_HW;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int p = p0 + ty + RGN * i;
+        if (p >= HW) continue;
+        float v[VC]; ld4(zp + (size_t)p * ldz, v);
+#pragma unroll
+        for (int j = 0; j < VC; ++j) { const float d = v[j] - z0[j]; s[0][j] += d; s[1][j] += d * d; }
+    }
+    combine16<2>(s, sm, tx, ty);
+    if (ty == 0) {
+#pragma unroll
+        for (int j = 0; j < VC; ++j) { atomicAdd(s1 + (size_t)n * C + c + j, s[0][j]); atomicAdd(s2 + (size_t)n * C + c + j, s[1][j]); }
+    }
+}
+// (2) mean = z0 + s1/HW; var = s2/HW - (s1/HW)^2
+__global__ void in_finalize_kernel(const float* __restrict__ z, int ldz, float* __restrict__ mean, float* __restrict__ rstd,
+                                   int N, int HW, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * C) return;
+    const int n = i / C, c = i % C;
+    const float z0 = z[(size_t)n * HW * ldz + c];
+    const float m = mean[i] / HW;
+    const float var = fmaxf(rstd[i] / HW - m * m, 0.f);
+    mean[i] = z0 + m;
+    rstd[i] = 1.0f / sqrtf(var + IN_EPS);
+}
+// (3) apply (+ optional global-average-pool partial sums: pool[n][c] += sum a)
+template <typename T>
+__global__ __launch_bounds__(CGN * RGN) void in_apply_kernel(const float* __restrict__ z, int ldz, T* __restrict__ a, int lda,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const uint8_t* __restrict__ mask, float* __restrict__ pool,
+                                                            int HW, int C, int act) {
+    __shared__ float sm[1][RGN][CW];
+    const int tx = threadIdx.x % CGN, ty = threadIdx.x / CGN;
+    const int c = blockIdx.x * CW + tx * VC, n = blockIdx.y;
+    const float* zp = z + (size_t)n * HW * ldz + c;
+    T* ap = a + (size_t)n * HW * lda + c;
+    float mu[VC], r[VC];
+    ld4(mean + (size_t)n * C + c, mu); ld4(rstd + (size_t)n * C + c, r);
+    float ps[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
+    const int p0 = blockIdx.z * SMALL_HW;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int p = p0 + ty + RGN * i;
+        if (p >= HW) continue;
+        float v[VC], o[VC], k[VC] = {1.f, 1.f, 1.f, 1.f};
+        ld4(zp + (size_t)p * ldz, v);
+        if (mask) keep4(mask + ((size_t)n * HW + p) * C + c, k);
+#pragma unroll
+        for (int j = 0; j < VC; ++j) { o[j] = act_fwd((v[j] - mu[j]) * r[j], act) * k[j]; ps[0][j] += o[j]; }
+        st4<T>(ap + (size_t)p * lda, o);
+    }
+    if (pool) {
+        combine16<1>(ps, sm, tx, ty);
+        if (ty == 0) {
+#pragma unroll
+            for (int j = 0; j < VC; ++j) atomicAdd(pool + (size_t)n * C + c + j, ps[0][j]);
+        }
     }
 }
 
@@ -82,55 +223,102 @@ struct InBwdParams {
     int HW, C, act;
 };
 
-// dn = act'(xhat) (da + da2) [*2 keep];  dz = rstd (dn - mean(dn) - xhat mean(dn xhat)) [+ zt]
-template <typename T>
-__global__ __launch_bounds__(CW * RG) void in_act_bwd_kernel(InBwdParams q) {
-    __shared__ float sm[2][RG][CW];
-    __shared__ float red[CW * RG / 64];
-    const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
-    const int c = blockIdx.x * CW + tx, n = blockIdx.y;
+// dn = act'(xhat) (da + da2 + da_bcast) [*2 keep];  dz = rstd (dn - mean(dn) - xhat mean(dn xhat)) [+ zt]
+// MODE 0: fused small-map kernel (rows in registers); MODE 1: large maps, sums only (ws[n][c][0..1] += sum dn, sum dn xhat);
+// MODE 2: large maps, apply (reads the sums from ws).
+template <typename T, int MODE>
+__global__ __launch_bounds__(CGN * RGN) void in_bwd_kernel(InBwdParams q, float* __restrict__ ws) {
+    __shared__ float sm[2][RGN][CW];
+    __shared__ float red[CGN * RGN / 64];
+    const int tx = threadIdx.x % CGN, ty = threadIdx.x / CGN;
+    const int c = blockIdx.x * CW + tx * VC, n = blockIdx.y;
     const int HW = q.HW, C = q.C;
     const float* zp = q.z + (size_t)n * HW * q.ldz + c;
     const float* dap = q.da ? q.da + (size_t)n * HW * q.ldda + c : nullptr;
     const float* da2p = q.da2 ? q.da2 + (size_t)n * HW * q.ldda2 + c : nullptr;
     const uint8_t* mp = q.mask ? q.mask + (size_t)n * HW * C + c : nullptr;
-    const float mu = q.mean[(size_t)n * C + c], r = q.rstd[(size_t)n * C + c];
-    const float dab = q.da_bcast ? q.da_bcast[(size_t)n * C + c] : 0.f;
-    auto dn_at = [&](int p, float xh) {
-        float d = dab;
-        if (dap) d += dap[(size_t)p * q.ldda];
-        if (da2p) d += da2p[(size_t)p * q.ldda2];
-        if (mp) d *= mp[(size_t)p * C] ? 2.f : 0.f;
-        return d * act_grad(xh, q.act);
-    };
-    float s[2] = {0.f, 0.f};
-    for (int p = ty; p < HW; p += RG) {
-        const float xh = (zp[(size_t)p * q.ldz] - mu) * r;
-        const float dn = dn_at(p, xh);
-        s[0] += dn; s[1] += dn * xh;
+    float mu[VC], r[VC], dab[VC] = {0.f, 0.f, 0.f, 0.f};
+    ld4(q.mean + (size_t)n * C + c, mu); ld4(q.rstd + (size_t)n * C + c, r);
+    if (q.da_bcast) ld4(q.da_bcast + (size_t)n * C + c, dab);
+    const int p0 = MODE == 0 ? 0 : blockIdx.z * SMALL_HW;
+    float zv[MAXR][VC], dn[MAXR][VC];
+    float s[2][VC] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int p = p0 + ty + RGN * i;
+        if (p >= HW) continue;
+        ld4(zp + (size_t)p * q.ldz, zv[i]);
+        float d[VC] = {dab[0], dab[1], dab[2], dab[3]};
+        if (dap) {
+            float t[VC]; ld4(dap + (size_t)p * q.ldda, t);
+#pragma unroll
+            for (int j = 0; j < VC; ++j) d[j] += t[j];
+        }
+        if (da2p) {
+            float t[VC]; ld4(da2p + (size_t)p * q.ldda2, t);
+#pragma unroll
+            for (int j = 0; j < VC; ++j) d[j] += t[j];
+        }
+        float k[VC] = {1.f, 1.f, 1.f, 1.f};
+        if (mp) keep4(mp + (size_t)p * C, k);
+#pragma unroll
+        for (int j = 0; j < VC; ++j) {
+            const float xh = (zv[i][j] - mu[j]) * r[j];
+            dn[i][j] = d[j] * k[j] * act_grad(xh, q.act);
+            s[0][j] += dn[i][j]; s[1][j] += dn[i][j] * xh;
+        }
     }
-    combine<2>(s, sm, tx, ty);
-    const float m1 = s[0] / HW, m2 = s[1] / HW;
+    if (MODE == 1) {
+        combine16<2>(s, sm, tx, ty);
+        if (ty == 0) {
+#pragma unroll
+            for (int j = 0; j < VC; ++j) {
+                atomicAdd(ws + ((size_t)n * C + c + j) * 2, s[0][j]);
+                atomicAdd(ws + ((size_t)n * C + c + j) * 2 + 1, s[1][j]);
+            }
+        }
+        return;
+    }
+    float m1[VC], m2[VC];
+    if (MODE == 0) {
+        combine16<2>(s, sm, tx, ty);
+#pragma unroll
+        for (int j = 0; j < VC; ++j) { m1[j] = s[0][j] / HW; m2[j] = s[1][j] / HW; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VC; ++j) { m1[j] = ws[((size_t)n * C + c + j) * 2] / HW; m2[j] = ws[((size_t)n * C + c + j) * 2 + 1] / HW; }
+    }
     const float gs = q.gscale ? q.gscale[n / q.group_n] : 1.f;
     const float* ztp = (q.zt && n >= q.zt_n0) ? q.zt + (size_t)(n - q.zt_n0) * HW * C + c : nullptr;
     T* op = static_cast<T*>(q.dzs) + (size_t)n * HW * q.lddz + c;
-    const float b = q.bias ? q.bias[c] : 0.f;
-    float sb = 0.f, sd = 0.f;
-    for (int p = ty; p < HW; p += RG) {
-        const float zv = zp[(size_t)p * q.ldz];
-        const float xh = (zv - mu) * r;
-        float dz = r * (dn_at(p, xh) - m1 - xh * m2);
-        if (ztp) dz += ztp[(size_t)p * C];
-        sb += dz; sd += dz * gs * (zv - b);
-        Elem<T>::st(op + (size_t)p * q.lddz, dz * gs);
+    float b[VC] = {0.f, 0.f, 0.f, 0.f};
+    if (q.bias) ld4(q.bias + c, b);
+    float sb[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
+    float sd = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int p = p0 + ty + RGN * i;
+        if (p >= HW) continue;
+        float t[VC] = {0.f, 0.f, 0.f, 0.f}, o[VC];
+        if (ztp) ld4(ztp + (size_t)p * C, t);
+#pragma unroll
+        for (int j = 0; j < VC; ++j) {
+            const float xh = (zv[i][j] - mu[j]) * r[j];
+            const float dz = r[j] * (dn[i][j] - m1[j] - xh * m2[j]) + t[j];
+            sb[0][j] += dz; sd += dz * gs * (zv[i][j] - b[j]);
+            o[j] = dz * gs;
+        }
+        st4<T>(op + (size_t)p * q.lddz, o);
     }
     if (q.dbias) {
-        float v[1] = {sb};
-        combine<1>(v, reinterpret_cast<float(*)[RG][CW]>(sm), tx, ty);
-        if (ty == 0) atomicAdd(q.dbias + c, v[0]);
+        combine16<1>(sb, reinterpret_cast<float(*)[RGN][CW]>(sm), tx, ty);
+        if (ty == 0) {
+#pragma unroll
+            for (int j = 0; j < VC; ++j) atomicAdd(q.dbias + c + j, sb[0][j]);
+        }
     }
     if (q.cdot) {
-        const float tot = block_sum<CW * RG / 64>(sd, red);
+        const float tot = block_sum<CGN * RGN / 64>(sd, red);
         if (threadIdx.x == 0) atomicAdd(q.cdot + n / q.group_n, tot);
     }
 }
@@ -258,33 +446,56 @@ bool bad_dtype(int dt) { return dt != GCSSL_F32 && dt != GCSSL_BF16; }
 extern "C" {
 
 int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float* mean, float* rstd,
-                     const uint8_t* mask, int N, int HW, int C, int act, void* stream) {
+                     const uint8_t* mask, float* pool, int N, int HW, int C, int act, void* stream) {
     if (!z || !a || !mean || !rstd) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lda < C || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
-    dim3 grid(C / CW, N);
-    if (dtype == GCSSL_F32)
-        hipLaunchKernelGGL(in_act_fwd_kernel<float>, grid, dim3(CW * RG), 0, (hipStream_t)stream, z, ldz,
-                           (float*)a, lda, mean, rstd, mask, HW, C, act);
-    else
-        hipLaunchKernelGGL(in_act_fwd_kernel<bf16_t>, grid, dim3(CW * RG), 0, (hipStream_t)stream, z, ldz,
-                           (bf16_t*)a, lda, mean, rstd, mask, HW, C, act);
+    if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lda < C || ldz % 4 || lda % 4 || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
+    if (!aligned16(z) || (((uintptr_t)a) & 7)) return GCSSL_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (HW <= SMALL_HW && !pool) {
+        dim3 grid(C / CW, N);
+        if (dtype == GCSSL_F32) hipLaunchKernelGGL(in_fwd_small_kernel<float>, grid, dim3(CGN * RGN), 0, st, z, ldz, (float*)a, lda, mean, rstd, mask, HW, C, act);
+        else hipLaunchKernelGGL(in_fwd_small_kernel<bf16_t>, grid, dim3(CGN * RGN), 0, st, z, ldz, (bf16_t*)a, lda, mean, rstd, mask, HW, C, act);
+        return gcssl_launch_status();
+    }
+    dim3 grid(C / CW, N, (HW + SMALL_HW - 1) / SMALL_HW);
+    hipMemsetAsync(mean, 0, sizeof(float) * (size_t)N * C, st);
+    hipMemsetAsync(rstd, 0, sizeof(float) * (size_t)N * C, st);
+    hipLaunchKernelGGL(in_stats_kernel, grid, dim3(CGN * RGN), 0, st, z, ldz, mean, rstd, HW, C);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((unsigned)(((size_t)N * C + 255) / 256)), dim3(256), 0, st, z, ldz, mean, rstd, N, HW, C);
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(CGN * RGN), 0, st, z, ldz, (float*)a, lda, mean, rstd, mask, pool, HW, C, act);
+    else hipLaunchKernelGGL(in_apply_kernel<bf16_t>, grid, dim3(CGN * RGN), 0, st, z, ldz, (bf16_t*)a, lda, mean, rstd, mask, pool, HW, C, act);
     return gcssl_launch_status();
 }
 
 int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const float* da_bcast,
                      const float* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask,
                      const float* zt, int zt_n0, const float* gscale, int group_n, const float* bias,
-                     void* dzs, int lddz, float* dbias, float* cdot, int N, int HW, int C, int act, void* stream) {
+                     void* dzs, int lddz, float* dbias, float* cdot, float* ws, int N, int HW, int C, int act, void* stream) {
     if ((!da && !da_bcast) || !z || !mean || !rstd || !dzs) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lddz < C || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
+    if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lddz < C || ldz % 4 || lddz % 4 || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
+    if ((da && ldda % 4) || (da2 && ldda2 % 4)) return GCSSL_EBADSHAPE;
     if ((gscale || cdot) && group_n <= 0) return GCSSL_EBADSHAPE;
+    if (HW > SMALL_HW && !ws) return GCSSL_ENULL;
     InBwdParams q{da, ldda, da2, ldda2, da_bcast, z, ldz, mean, rstd, mask, zt, zt_n0, gscale,
                   group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, HW, C, act};
-    dim3 grid(C / CW, N);
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(in_act_bwd_kernel<float>, grid, dim3(CW * RG), 0, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL(in_act_bwd_kernel<bf16_t>, grid, dim3(CW * RG), 0, (hipStream_t)stream, q);
+    hipStream_t st = (hipStream_t)stream;
+    if (HW <= SMALL_HW) {
+        dim3 grid(C / CW, N);
+        if (dtype == GCSSL_F32) hipLaunchKernelGGL((in_bwd_kernel<float, 0>), grid, dim3(CGN * RGN), 0, st, q, ws);
+        else hipLaunchKernelGGL((in_bwd_kernel<bf16_t, 0>), grid, dim3(CGN * RGN), 0, st, q, ws);
+        return gcssl_launch_status();
+    }
+    dim3 grid(C / CW, N, (HW + SMALL_HW - 1) / SMALL_HW);
+    hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)N * C, st);
+    if (dtype == GCSSL_F32) {
+        hipLaunchKernelGGL((in_bwd_kernel<float, 1>), grid, dim3(CGN * RGN), 0, st, q, ws);
+        hipLaunchKernelGGL((in_bwd_kernel<float, 2>), grid, dim3(CGN * RGN), 0, st, q, ws);
+    } else {
+        hipLaunchKernelGGL((in_bwd_kernel<bf16_t, 1>), grid, dim3(CGN * RGN), 0, st, q, ws);
+        hipLaunchKernelGGL((in_bwd_kernel<bf16_t, 2>), grid, dim3(CGN * RGN), 0, st, q, ws);
+    }
     return gcssl_launch_status();
 }
 

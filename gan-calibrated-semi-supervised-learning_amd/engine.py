@@ -213,6 +213,8 @@ class StepEngine:
                         torch.empty(B, S // 8, S // 8, 256, device=dev, dtype=torch.uint8),
                         torch.empty(B, S // 4, S // 4, 128, device=dev, dtype=torch.uint8)]
         self.g_pooled = torch.empty(B, 64, **f32)
+        self.g_poolsum = torch.zeros(B, 64, **f32)                 # sum over H*W of u4, accumulated by up4's IN apply pass
+        self.ws = torch.empty(2 * N3 * 512, **f32)                 # scratch of the large-map InstanceNorm backward
         self.g_traw = torch.empty(B, 4, **f32)
         self.g_delta = torch.empty(B, 4, **f32)
         self.g_gdelta = torch.empty(B, 4, **f32)
@@ -313,13 +315,14 @@ class StepEngine:
         ops.in_act_fwd(self.g_zd[3], self.g_d4, self.g_dmean[3], self.g_drstd[3], 512, LRELU, mask=mk[0])
         ins = [self.g_d4, self.g_cat1, self.g_cat2, self.g_cat3]
         outs = [self.g_cat1[..., :256], self.g_cat2[..., :128], self.g_cat3[..., :64], self.g_u4]
+        self.g_poolsum.zero_()
         for k, (cint, coutt) in enumerate(G_UP):
             self._conv(f"G.up{k + 1}.fwd", conv_flops(B, S >> (3 - k), coutt, cint), ops.conv_dgrad, ins[k],
                        self.gu_wt[k], self.g_zu[k], coutt, cint)
             ops.in_act_fwd(self.g_zu[k], outs[k], self.g_umean[k], self.g_urstd[k], coutt, RELU,
-                           mask=mk[k + 1] if k < 2 else None)
+                           mask=mk[k + 1] if k < 2 else None, pool=self.g_poolsum if k == 3 else None)
         ops.pool_fc_tanh_fwd(self.g_u4, self.G.views["fc_delta.1.weight"], self.G.views["fc_delta.1.bias"],
-                             self.delta_scale, self.g_pooled, self.g_traw, self.g_delta)
+                             self.delta_scale, self.g_pooled, self.g_traw, self.g_delta, pool_sum=self.g_poolsum)
         return self.g_delta
 
     def generator_delta(self, pred: torch.Tensor, masks=None, train: bool = True) -> torch.Tensor:
@@ -372,7 +375,7 @@ class StepEngine:
         for l in (3, 2, 1):
             cin, cout = D_CH[l]
             ops.in_act_bwd(self.d_z[l][I], self.d_mean[l][I], self.d_rstd[l][I], self.gb_zs[l], cout, LRELU,
-                           da=self.gb_a[l], gscale=isig[l, 2:3], group_n=B)
+                           da=self.gb_a[l], gscale=isig[l, 2:3], group_n=B, ws=self.ws)
             self._conv(f"D.c{l + 1}.gp_dgrad", conv_flops(B, S >> l, cin, cout), ops.conv_dgrad, self.gb_zs[l],
                        self.d_wt[l], self.gb_a[l - 1], cin, cout)
         ops.act_bwd(self.gb_a[0], self.d_a[0][I], self.gb_zs[0], 64, gscale=isig[0, 2:3], group_n=B)
@@ -409,7 +412,7 @@ class StepEngine:
             if l > 0:
                 ops.in_act_bwd(self.d_z[l], self.d_mean[l], self.d_rstd[l], self.d_dzs[l], cout, LRELU,
                                da=self.d_da[l], zt=self.zt[l], zt_n0=2 * B, gscale=isig[l], group_n=B, bias=bias,
-                               dbias=gbias, cdot=self.cdot[l])
+                               dbias=gbias, cdot=self.cdot[l], ws=self.ws)
             else:
                 ops.act_bwd(self.d_da[0], self.d_a[0], self.d_dzs[0], 64, gscale=isig[0], group_n=B, bias=bias,
                             dbias=gbias, cdot=self.cdot[0])
@@ -418,7 +421,7 @@ class StepEngine:
             fl = conv_flops(N3, S >> l, cin, cout)
             self._conv(f"D.c{l + 1}.wgrad", fl, ops.conv_wgrad, xin, self.d_dzs[l], self.d_slab[l][nc:], cp, cout)
             ops.wgrad_reduce(self.d_slab[l], nc + nf, self.D.gviews[f"model.{i}.weight_orig"], cout, cp, cin,
-                             coef=self.cdot[l], u=self.sn.u_hist[l], v=self.sn.v_hist[l], nrank=3)
+                             coef=self.cdot[l], u=self.sn.u_hist[l], v=self.sn.v_hist[l], nrank=3, accumulate="zeroed")
             if l > 0:
                 self._conv(f"D.c{l + 1}.dgrad", fl, ops.conv_dgrad, self.d_dzs[l], self.d_wt[l], self.d_da[l - 1], cin, cout)
 
@@ -463,14 +466,14 @@ class StepEngine:
             key = f"up{k + 1}.model.0.weight" if k < 3 else "up4.0.weight"
             if k == 3:
                 ops.in_act_bwd(self.g_zu[3], self.g_umean[3], self.g_urstd[3], self.g_dzu[3], coutt, RELU,
-                               da_bcast=self.g_dab)
+                               da_bcast=self.g_dab, ws=self.ws)
             else:
                 ops.in_act_bwd(self.g_zu[k], self.g_umean[k], self.g_urstd[k], self.g_dzu[k], coutt, RELU,
-                               da=dcat[k + 1][..., :coutt], mask=self.g_masks[k + 1] if k < 2 else None)
+                               da=dcat[k + 1][..., :coutt], mask=self.g_masks[k + 1] if k < 2 else None, ws=self.ws)
             fl = conv_flops(B, S >> (3 - k), coutt, cint)
             self._conv(f"G.up{k + 1}.wgrad", fl, ops.conv_wgrad, self.g_dzu[k], ins[k], self.g_slab_u[k], coutt,
                        cint)                                                            # roles swapped (ConvTranspose)
-            ops.wgrad_reduce(self.g_slab_u[k], self.g_ns_u[k], gW[key], cint, coutt, coutt)
+            ops.wgrad_reduce(self.g_slab_u[k], self.g_ns_u[k], gW[key], cint, coutt, coutt, accumulate="zeroed")
             self._conv(f"G.up{k + 1}.dgrad", fl, ops.conv_fwd, self.g_dzu[k], self.gu_wf[k], dcat[k], coutt, cint)
         d_act = [self.g_cat3[..., 64:], self.g_cat2[..., 128:], self.g_cat1[..., 256:]]            # d1, d2, d3
         dskip = [self.g_dcat3[..., 64:], self.g_dcat2[..., 128:], self.g_dcat1[..., 256:]]
@@ -479,16 +482,17 @@ class StepEngine:
             cp = _pad8(cin)
             if k == 3:
                 ops.in_act_bwd(self.g_zd[3], self.g_dmean[3], self.g_drstd[3], self.g_dzd[3], 512, LRELU,
-                               da=self.g_dd4, mask=self.g_masks[0])
+                               da=self.g_dd4, mask=self.g_masks[0], ws=self.ws)
             elif k > 0:
                 ops.in_act_bwd(self.g_zd[k], self.g_dmean[k], self.g_drstd[k], self.g_dzd[k], cout, LRELU,
-                               da=self.g_dd[k + 1], da2=dskip[k])
+                               da=self.g_dd[k + 1], da2=dskip[k], ws=self.ws)
             else:
                 ops.act_bwd(self.g_dd[1], d_act[0], self.g_dzd[0], 64, da2=dskip[0])
             xin = self.x0[:B] if k == 0 else d_act[k - 1]
             fl = conv_flops(B, S >> k, cin, cout)
             self._conv(f"G.down{k + 1}.wgrad", fl, ops.conv_wgrad, xin, self.g_dzd[k], self.g_slab_d[k], cp, cout)
-            ops.wgrad_reduce(self.g_slab_d[k], self.g_ns_d[k], gW[f"down{k + 1}.model.0.weight"], cout, cp, cin)
+            ops.wgrad_reduce(self.g_slab_d[k], self.g_ns_d[k], gW[f"down{k + 1}.model.0.weight"], cout, cp, cin,
+                             accumulate="zeroed")
             if k > 0:
                 self._conv(f"G.down{k + 1}.dgrad", fl, ops.conv_dgrad, self.g_dzd[k], self.gd_wt[k], self.g_dd[k], cin, cout)
 

@@ -81,7 +81,8 @@ def wgrad_reduce(slab, nsplit, dw, cout, cin, cin_real, coef=None, cscale=None, 
                  accumulate=False):
     """u, v: 2-D [nrank][>=cout] / [nrank][>=cin_real*16] (row strides are taken from the tensors)."""
     call("gcssl_wgrad_reduce", slab, nsplit, dw, cout, cin, cin_real, coef, cscale, u,
-         u.stride(0) if u is not None else 0, v, v.stride(0) if v is not None else 0, nrank, int(accumulate))
+         u.stride(0) if u is not None else 0, v, v.stride(0) if v is not None else 0, nrank,
+         2 if accumulate == "zeroed" else int(accumulate))
 
 
 # ---- critic head
@@ -104,19 +105,19 @@ def c5_wgrad(x, dw, C, dout=None, consts=(0.0, 0.0, 0.0), group_n=1):
 
 
 # ---- norm / activation
-def in_act_fwd(z, a, mean, rstd, C, act, mask=None):
+def in_act_fwd(z, a, mean, rstd, C, act, mask=None, pool=None):
     """z: fp32 pre-norm tensor; a: activation output in the compute dtype."""
     N, H, W, _ = z.shape
     assert z.dtype == torch.float32
-    call("gcssl_in_act_fwd", code(a), z, _ld(z), a, _ld(a), mean, rstd, mask, N, H * W, C, act)
+    call("gcssl_in_act_fwd", code(a), z, _ld(z), a, _ld(a), mean, rstd, mask, pool, N, H * W, C, act)
 
 
 def in_act_bwd(z, mean, rstd, dzs, C, act, da=None, da2=None, da_bcast=None, mask=None, zt=None, zt_n0=0,
-               gscale=None, group_n=0, bias=None, dbias=None, cdot=None):
+               gscale=None, group_n=0, bias=None, dbias=None, cdot=None, ws=None):
     N, H, W, _ = z.shape
     assert z.dtype == torch.float32 and all(t is None or t.dtype == torch.float32 for t in (da, da2, zt))
     call("gcssl_in_act_bwd", code(dzs), da, _ld(da) if da is not None else 0, da2, _ld(da2) if da2 is not None else 0,
-         da_bcast, z, _ld(z), mean, rstd, mask, zt, zt_n0, gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot,
+         da_bcast, z, _ld(z), mean, rstd, mask, zt, zt_n0, gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot, ws,
          N, H * W, C, act)
 
 
@@ -186,9 +187,9 @@ def clip_adam(p, g, m, v, state, lr, b1, b2, eps=1e-8, max_norm=1.0, write_clipp
          float(max_norm), int(write_clipped))
 
 
-def pool_fc_tanh_fwd(x, w, bias, scale, pooled, traw, delta):
+def pool_fc_tanh_fwd(x, w, bias, scale, pooled, traw, delta, pool_sum=None):
     N, H, W, _ = x.shape
-    call("gcssl_pool_fc_tanh_fwd", code(x), x, _ld(x), w, bias, float(scale), pooled, traw, delta, N, H * W, 64)
+    call("gcssl_pool_fc_tanh_fwd", code(x), x, _ld(x), pool_sum, w, bias, float(scale), pooled, traw, delta, N, H * W, 64)
 
 
 def head_bwd(g_delta, traw, pooled, w, scale, B, HW, dw, db, da_bcast):

@@ -67,7 +67,9 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
                           int Wi, int Cin, int Cout, void* stream);
 /* dw[Cout][Cin_real][4][4] (=|+=) sum_s slab[s] - sum_k coef[k]*cscale[k] u_k[co] v_k[ci*16+tap]: split-K reduction
  * fused with the spectral-norm quotient rule d(W/sigma) (sigma = u^T W v; cgan/models.py:237-238).
- * u: nrank rows of stride ustride (>= Cout); v: nrank rows of stride vstride (>= Cin_real*16); cscale nullable. */
+ * u: nrank rows of stride ustride (>= Cout); v: nrank rows of stride vstride (>= Cin_real*16); cscale nullable.
+ * accumulate: 0 dw = result; 1 dw += result; 2 dw was zeroed by the caller and may be accumulated atomically (lets the
+ * reduction run in parallel over groups of slabs). */
 int gcssl_wgrad_reduce(const float* slab, int nsplit, float* dw, int Cout, int Cin, int Cin_real, const float* coef,
                        const float* cscale, const float* u, int ustride, const float* v, int vstride, int nrank,
                        int accumulate, void* stream);
@@ -86,7 +88,9 @@ int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dou
  * The pre-norm tensor z and every incoming gradient (da, da2, gb_a, qz, zt) are ALWAYS fp32 (z - mean(z) and
  * dn - mean(dn) over 4..64 elements cancel a bf16 mantissa); tensors that feed an MFMA (a, dzs, gt_a, gb_zs) are `dtype`. */
 int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float* mean, float* rstd, const uint8_t* mask,
-                     int N, int HW, int C, int act, void* stream);
+                     float* pool, int N, int HW, int C, int act, void* stream);
+/* pool (nullable): [N][C] fp32, += sum over H*W of the activation output (AdaptiveAvgPool2d(1) of cgan/models.py:118,
+ * fused; caller zeroes it and divides by H*W). */
 /* first-order backward: dn = act'(xhat) (da + da2 + da_bcast) [*2 keep]; dz = rstd (dn - mean dn - xhat mean(dn xhat))
  * (+ zt for samples n >= zt_n0: the double-backward term); dzs = dz * gscale[n/group_n];
  * dbias[c] += sum dz; cdot[n/group_n] += sum dzs (z - bias[c]) -- the coefficient <dW_sn, W_orig>/sigma^2 of the
@@ -94,7 +98,8 @@ int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float
 int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const float* da_bcast,
                      const float* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask, const float* zt,
                      int zt_n0, const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias,
-                     float* cdot, int N, int HW, int C, int act, void* stream);
+                     float* cdot, float* ws, int N, int HW, int C, int act, void* stream);
+/* ws: caller-owned scratch of 2*N*C floats, required when H*W > 64 (two-kernel path), else may be NULL. */
 /* second-order backward (create_graph=True, cgan/losses.py:213-220): adjoint of dz=IN_bwd(z, act'*gb_a) for an
  * incoming adjoint qz: gt_a = act'(xhat) * d/d(dn), zt = d/dz; cdot += sum gb_zs*qz. */
 int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, int ldq, const void* gb_zs, int ldgz,
@@ -124,8 +129,10 @@ int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* stat
                     double eps, double max_norm, int write_clipped, void* stream);
 
 /* ---- generator head (cgan/models.py:118-123,139-141) and box/EIoU loss (cgan/losses.py:19-73,99-150) ------------- */
-int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, const float* w, const float* bias, float scale,
-                           float* pooled, float* traw, float* delta, int B, int HW, int C, void* stream);
+/* pool_sum (nullable): [B][64] sums over H*W already accumulated by gcssl_in_act_fwd(pool=...); then x is not read. */
+int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, const float* pool_sum, const float* w, const float* bias,
+                           float scale, float* pooled, float* traw, float* delta, int B, int HW, int C, void* stream);
+/* dw [4][64] and db [4] are accumulated atomically (caller zeroes them). */
 int gcssl_head_bwd(const float* g_delta, const float* traw, const float* pooled, const float* w, float scale, int B,
                    int HW, float* dw, float* db, float* da_bcast, void* stream);
 int gcssl_eiou_fwd_bwd(const float* pred_box, const float* delta, const float* delta_true, int B, float lambda_iou,

@@ -115,13 +115,17 @@ def test_conv_wgrad(ops, dt, tol, N, Hi, Cin, CinP, Cout):
     v = rnd(2, Cin * 16, seed=9).cuda()
     ops.wgrad_reduce(slab, ns, dw, Cout, CinP, Cin, coef=coef, cscale=torch.tensor([2.0, 0.5], device="cuda"), u=u, v=v, nrank=2)
     torch.cuda.synchronize()
+    dw2 = torch.zeros((Cout, Cin, 4, 4), device="cuda")      # pre-zeroed, split-parallel atomic reduction
+    ops.wgrad_reduce(slab, ns, dw2, Cout, CinP, Cin, coef=coef, cscale=torch.tensor([2.0, 0.5], device="cuda"), u=u, v=v, nrank=2,
+                     accumulate="zeroed")
     ref = conv2d_weight(x, (Cout, Cin, 4, 4), dy, 2, 1)
     corr = sum(float(coef[k]) * (2.0, 0.5)[k] * torch.outer(u[k].cpu(), v[k].cpu()).view(Cout, Cin, 4, 4) for k in range(2))
     assert rel_err(dw.cpu(), ref - corr) < tol
+    assert rel_err(dw2.cpu(), ref - corr) < tol
 
 
 @pytest.mark.parametrize("dt,tol", DTS)
-@pytest.mark.parametrize("N,H,C,act", [(3, 8, 128, 1), (2, 2, 512, 1), (2, 32, 64, 2), (4, 4, 256, 2)])
+@pytest.mark.parametrize("N,H,C,act", [(3, 8, 128, 1), (2, 2, 512, 1), (2, 32, 64, 2), (4, 4, 256, 2), (3, 16, 128, 1)])
 def test_instance_norm_fwd_bwd_dbl(ops, dt, tol, N, H, C, act):
     from oracle import manual_step as M
     z = rnd(N, C, H, H, seed=10, scale=2.0) + 0.3          # the pre-norm tensor is fp32 in both modes
@@ -141,14 +145,22 @@ def test_instance_norm_fwd_bwd_dbl(ops, dt, tol, N, H, C, act):
     assert rel_err(mean.cpu(), mu.view(N, C)) < 1e-5 and rel_err(rstd.cpu(), r.view(N, C)) < 1e-5
     assert rel_err(nchw(a), aref) < tol
     assert float(wide[..., :C].abs().max()) == 0.0
+    # fused global-average-pool sums (large-map path is forced by pool=...)
+    pool = torch.zeros(N, C, device="cuda")
+    a2 = torch.empty(N, H, H, C, device="cuda", dtype=dt)
+    ops.in_act_fwd(zd, a2, mean, rstd, C, act, mask=maskd, pool=pool)
+    assert rel_err(nchw(a2), aref) < tol
+    assert rel_err(rstd.cpu(), r.view(N, C)) < 1e-5
+    assert rel_err(pool.cpu(), q(aref, dt).sum(dim=(2, 3))) < max(tol, 1e-5)
     # backward (with dropout mask, group scale, bias/cdot bookkeeping)
     bias = rnd(C, seed=13, scale=0.1)
     gsc = torch.tensor([1.5, 0.5], device="cuda")
     group_n = (N + 1) // 2
     dzs = torch.empty(N, H, H, C, device="cuda", dtype=dt)
     dbias = torch.zeros(C, device="cuda"); cdot = torch.zeros(2, device="cuda")
+    ws = torch.empty(2 * N * C, device="cuda")
     ops.in_act_bwd(zd, mean, rstd, dzs, C, act, da=dad, mask=maskd, gscale=gsc, group_n=group_n, bias=bias.cuda(),
-                   dbias=dbias, cdot=cdot)
+                   dbias=dbias, cdot=cdot, ws=ws)
     torch.cuda.synchronize()
     ag = torch.where(xh > 0, torch.ones_like(xh), torch.full_like(xh, 0.2 if act == 1 else 0.0))
     dn = da * mask.float() * 2 * ag
@@ -316,7 +328,7 @@ def test_clip_adam_matches_torch(ops):
 def test_generator_head_and_eiou(ops):
     from oracle import manual_step as M
     from conftest import load_golden
-    B, S = 6, 16
+    B, S = 21, 16
     x = rnd(B, 64, S, S, seed=90)
     w, b = rnd(4, 64, seed=91, scale=0.125), rnd(4, seed=92, scale=0.125)
     pooled = torch.empty(B, 64, device="cuda"); traw = torch.empty(B, 4, device="cuda"); delta = torch.empty(B, 4, device="cuda")
@@ -324,7 +336,7 @@ def test_generator_head_and_eiou(ops):
     pr = x.mean(dim=(2, 3)); tr = torch.tanh(pr @ w.t() + b)
     assert rel_err(pooled.cpu(), pr) < 1e-5 and rel_err(delta.cpu(), tr * 0.3) < 1e-5
     gd = rnd(B, 4, seed=93)
-    dw = torch.empty(4, 64, device="cuda"); db = torch.empty(4, device="cuda"); dab = torch.empty(B, 64, device="cuda")
+    dw = torch.zeros(4, 64, device="cuda"); db = torch.zeros(4, device="cuda"); dab = torch.empty(B, 64, device="cuda")
     ops.head_bwd(gd.cuda(), traw, pooled, w.cuda(), 0.3, B, S * S, dw, db, dab)
     dy = gd * 0.3 * (1 - tr * tr)
     assert rel_err(dw.cpu(), dy.t() @ pr) < 1e-5 and rel_err(db.cpu(), dy.sum(0)) < 1e-5
