@@ -4,7 +4,8 @@
 
 Parameters live in ordinary ``nn.Parameter``s in PyTorch layout (so ``state_dict()`` / ``load_state_dict()`` /
 optimisers work unchanged); ``forward`` packs them for the kernels and runs the same launch sequences as the step
-engine.  See ``autograd_nets.py`` for the differentiable (first- and second-order) wrappers.
+engine.  ``autograd_nets.py`` holds the differentiable (first- and second-order) wrappers; ``engine.StepEngine`` is the
+preallocated, batched, graph-captured fast path for the whole training iteration.
 """
 from __future__ import annotations
 
@@ -71,6 +72,9 @@ class _Holder(nn.Module):
         for k, v in children.items():
             self.add_module(str(k), v)
 
+    def __getitem__(self, idx):
+        return getattr(self, str(idx))
+
 
 class GeneratorUNet(nn.Module):
     """4-down / 4-up U-Net -> 4-d box correction (cgan/models.py:89-141)."""
@@ -91,7 +95,7 @@ class GeneratorUNet(nn.Module):
             self.add_module(f"up{k}", blk)
         self.up4 = _Holder({0: ConvT4x4(128, 64)})
         self.fc_delta = _Holder({1: nn.Linear(64, 4)})
-        self._net = None
+        self.compute_dtype = "fp32"      # "bf16": bf16 MFMA operands (throughput mode); fp32 is the parity mode
 
     def forward(self, x: torch.Tensor, masks=None) -> torch.Tensor:
         from .autograd_nets import generator_forward
@@ -111,6 +115,7 @@ class Discriminator(nn.Module):
             layers[idx] = Conv4x4(ci, co, bias=True, spectral=self.spectral_norm)
         layers[11] = Conv4x4(512, 1)
         self.model = _Holder(layers)
+        self.compute_dtype = "fp32"
 
     def forward(self, pred_patch: torch.Tensor, other_patch: torch.Tensor) -> torch.Tensor:
         from .autograd_nets import discriminator_forward

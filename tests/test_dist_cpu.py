@@ -1,0 +1,98 @@
+"""Data-parallel semantics on CPU (gloo, world size 2): the average of the shard gradients produced by the step's
+math equals the single-process full-batch gradient, through the package's own all-reduce hook (dist.GradAverager)
+operating on a flat gradient bucket -- exactly what the engine does on GPUs with RCCL."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+PKG = "gan-calibrated-semi-supervised-learning_amd"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    import importlib
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist_mod = importlib.import_module(PKG + ".dist")
+    synth = importlib.import_module(PKG + ".synth")
+    from oracle import manual_step as M
+    r, w, _ = dist_mod.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    T = torch.from_numpy
+    seed, B, S = 11, 4, 32
+    d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+    inp = synth.step_inputs(seed, B, S, 1, tag="dp")
+    full = [T(inp[k]) for k in ("pred", "gt")] + [T(inp["refined"][0]), T(inp["alpha"][0])]
+    mine = [dist_mod.shard(t, rank, world) for t in full]
+    # replicas start identical (rank 0 broadcasts) ...
+    dl = {k: v.clone() for k, v in d.items()}
+    if rank != 0:
+        for v in dl.values():
+            v.zero_()
+    dist_mod.broadcast_state(list(dl.values()), src=0)
+    assert all(torch.equal(dl[k], d[k]) for k in d)
+    # ... each rank computes the critic gradients of ITS shard, flattens them into one bucket and averages
+    grads, log = M.d_step_grads(dl, *mine, 1.0)
+    keys = sorted(grads)
+    flat = torch.cat([grads[k].reshape(-1) for k in keys])
+    dist_mod.GradAverager()(flat)
+    # generator: same exercise
+    masks = [dist_mod.shard(T(m), rank, world) for m in inp["masks"][1]]
+    _, _, gg = M.g_forward_backward(g, mine[0], 0.3, masks, dist_mod.shard(T(inp["pred_box"]), rank, world),
+                                    dist_mod.shard(T(inp["delta_true"]), rank, world))
+    gkeys = sorted(gg)
+    gflat = torch.cat([gg[k].reshape(-1) for k in gkeys])
+    dist_mod.GradAverager()(gflat)
+    # spectral-norm buffers stay identical across ranks without any exchange
+    u = dl["model.5.weight_u"].clone()
+    gathered = [torch.zeros_like(u) for _ in range(world)]
+    torch.distributed.all_gather(gathered, u)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    if rank == 0:
+        ref, _ = M.d_step_grads({k: v.clone() for k, v in d.items()}, *full, 1.0)
+        ref_flat = torch.cat([ref[k].reshape(-1) for k in keys])
+        _, _, rg = M.g_forward_backward(g, full[0], 0.3, [T(m) for m in inp["masks"][1]], T(inp["pred_box"]),
+                                        T(inp["delta_true"]))
+        rg_flat = torch.cat([rg[k].reshape(-1) for k in gkeys])
+        np.save(os.path.join(out_dir, "err.npy"),
+                np.array([float((flat - ref_flat).abs().max() / ref_flat.abs().max()),
+                          float((gflat - rg_flat).abs().max() / rg_flat.abs().max())]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_gradient_average_equals_full_batch(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    err = np.load(tmp_path / "err.npy")
+    assert err[0] < 2e-4, err      # critic: GP is a per-sample norm then a batch mean -> shard means average exactly
+    assert err[1] < 2e-4, err      # generator (EIoU mean)
+
+
+def test_shard_requires_even_split():
+    import importlib
+    sys.path.insert(0, str(ROOT))
+    dist_mod = importlib.import_module(PKG + ".dist")
+    t = torch.arange(10).view(5, 2)
+    with pytest.raises(ValueError):
+        dist_mod.shard(t, 0, 2)
+    assert torch.equal(dist_mod.shard(torch.arange(8).view(4, 2), 1, 2), torch.arange(4, 8).view(2, 2))
+    avg = dist_mod.GradAverager()          # no process group: identity
+    x = torch.ones(3)
+    avg(x)
+    assert torch.equal(x, torch.ones(3))

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Training harness with the reference's surface (cgan/cgan_train_enhanced.py:139-168,256-261,481-489): same
+argument names and defaults (read from config.yaml), Adam(lr, (beta1, beta2)) for both nets, the same logged scalars
+and the same checkpoint dict keys {'generator','discriminator','epoch','delta_iou','config'} -- driving the MI355X
+step engine.  Data: the reference reads image crops through CalibratorDataset + a PIL re-crop stage (out of scope
+this round); here a synthetic source with the same tensor contract feeds the
+loop, or any iterable yielding (pred_patch, gt_patch, delta_true, pred_box, refine_fn).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+from pathlib import Path
+
+import torch
+import yaml
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+PKG = "gan-calibrated-semi-supervised-learning_amd"
+
+
+def build_parser(config: dict) -> argparse.ArgumentParser:
+    """Argument surface of cgan/cgan_train_enhanced.py:145-168 (+ the MI355X-specific switches at the end)."""
+    p = argparse.ArgumentParser()
+    p.add_argument("--data_dir", type=str, default=config["data_dir"])
+    p.add_argument("--img_size", type=int, default=config["img_size"])
+    p.add_argument("--batch_size", type=int, default=config["batch_size"])
+    p.add_argument("--n_epochs", type=int, default=config["n_epochs"])
+    p.add_argument("--lr", type=float, default=config["lr"])
+    p.add_argument("--beta1", type=float, default=config["beta1"])
+    p.add_argument("--beta2", type=float, default=config["beta2"])
+    p.add_argument("--lambda_iou", type=float, default=config["lambda_iou"])
+    p.add_argument("--use_eiou", action="store_true", default=config.get("use_eiou", True))
+    p.add_argument("--pure_eiou", action="store_true", default=config.get("pure_eiou", True))
+    p.add_argument("--spectral_norm", action="store_true", default=config["spectral_norm"])
+    p.add_argument("--delta_scale", type=float, default=config["delta_scale"])
+    p.add_argument("--generator_type", type=str, default=config["generator_type"])
+    p.add_argument("--patience", type=int, default=config["early_stop"]["patience"])
+    p.add_argument("--min_delta", type=float, default=config["early_stop"]["min_delta"])
+    p.add_argument("--train_split", type=float, default=config["train_split"])
+    p.add_argument("--val_split", type=float, default=config["val_split"])
+    p.add_argument("--save_dir", type=str, default=config["save_dir"])
+    p.add_argument("--seed", type=int, default=config["seed"])
+    p.add_argument("--lambda_gp", type=float, default=config.get("lambda_gp", 10.0))
+    p.add_argument("--n_critic", type=int, default=config.get("n_critic", 5))
+    # MI355X-specific
+    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--iters_per_epoch", type=int, default=20, help="synthetic source: iterations per epoch")
+    return p
+
+
+def load_config() -> dict:
+    with open(ROOT / PKG / "config.yaml", "r", encoding="utf-8") as f:
+        return yaml.safe_load(f)
+
+
+def synthetic_source(synth, seed, batch, size, n_critic, device, iters):
+    T = torch.from_numpy
+    for it in range(iters):
+        inp = synth.step_inputs(seed + it, batch, size, n_critic, tag="train")
+        refined = [T(r).to(device) for r in inp["refined"]]
+        yield (T(inp["pred"]).to(device), T(inp["gt"]).to(device), T(inp["delta_true"]).to(device),
+               T(inp["pred_box"]).to(device), lambda delta, k, r=refined: r[k])
+
+
+def main(argv=None):
+    config = load_config()
+    args = build_parser(config).parse_args(argv)
+    if args.generator_type != "unet":
+        raise SystemExit("generator_type 'simple' (GeneratorSimpleRegressor) is a next-row item (SURVEY §8f f4)")
+    if not args.spectral_norm:
+        raise SystemExit("the step engine implements the reference default spectral_norm=true")
+    torch.manual_seed(args.seed)
+    if not torch.cuda.is_available():
+        raise SystemExit("train.py needs an MI355X (the HIP path has no CPU fallback)")
+    dist_mod = importlib.import_module(PKG + ".dist")
+    rank, world, local = dist_mod.init_from_env()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    models = importlib.import_module(PKG + ".models")
+    engine = importlib.import_module(PKG + ".engine")
+    losses = importlib.import_module(PKG + ".losses")
+    synth = importlib.import_module(PKG + ".synth")
+    netG = models.GeneratorUNet(delta_scale=args.delta_scale)
+    netD = models.Discriminator(spectral_norm=args.spectral_norm)
+    netG.apply(models.weights_init_normal); netD.apply(models.weights_init_normal)
+    if rank == 0:
+        print(f"Generator parameters: {sum(p.numel() for p in netG.parameters()):,}")
+        print(f"Discriminator parameters: {sum(p.numel() for p in netD.parameters()):,}")
+    eng = engine.StepEngine(netG.state_dict(), netD.state_dict(), batch=args.batch_size // world, size=args.img_size,
+                            n_critic=args.n_critic, dtype=args.compute_dtype, device=device, lr=args.lr,
+                            betas=(args.beta1, args.beta2), delta_scale=args.delta_scale, lambda_gp=args.lambda_gp,
+                            lambda_iou=args.lambda_iou, seed=args.seed + rank,
+                            allreduce=dist_mod.GradAverager() if world > 1 else None)
+    if world > 1:
+        dist_mod.broadcast_state([eng.D.p, eng.G.p] + eng.u + eng.v)
+    out_root = Path(args.save_dir); out_root.mkdir(parents=True, exist_ok=True)
+    ckpt_best = out_root / "G_best.pth"
+    best, history = -1.0, []
+    for epoch in range(1, args.n_epochs + 1):
+        stats = dict(loss_G=0.0, loss_D=0.0, loss_iou=0.0, loss_wgan=0.0, loss_gp=0.0, wasserstein_distance=0.0)
+        n = 0
+        iou_b = iou_a = 0.0
+        for pred, gt, delta_true, pred_box, refine in synthetic_source(synth, args.seed + 1000 * epoch + rank,
+                                                                       args.batch_size // world, args.img_size,
+                                                                       args.n_critic, device, args.iters_per_epoch):
+            log = eng.iteration(pred, gt, delta_true, pred_box, refine)
+            stats["loss_D"] += sum(log["d_loss"]) / args.n_critic
+            stats["loss_gp"] += sum(log["gp"]) / args.n_critic
+            stats["wasserstein_distance"] += sum(log["wd"]) / args.n_critic
+            stats["loss_G"] += log["loss_g"]; stats["loss_iou"] += log["loss_iou"]; stats["loss_wgan"] += log["loss_wgan"]
+            n += 1
+            # validation metric of :395-420 on the training batch (eval-mode box transform + plain IoU)
+            gtb = losses.apply_delta_to_bbox(pred_box, delta_true, training=False)
+            cal = losses.apply_delta_to_bbox(pred_box, log["delta_pred"], training=False)
+            iou_b += float(losses.iou_metric(pred_box, gtb).mean()); iou_a += float(losses.iou_metric(cal, gtb).mean())
+        for k in stats:
+            stats[k] /= max(n, 1)
+        delta_iou = (iou_a - iou_b) / max(n, 1)
+        history.append(dict(epoch=epoch, delta_iou=delta_iou, **stats))
+        if rank == 0:
+            print(f"[Epoch {epoch}/{args.n_epochs}] G: {stats['loss_G']:.3f} D: {stats['loss_D']:.3f} EIoU: {stats['loss_iou']:.3f} "
+                  f"WGAN: {stats['loss_wgan']:.3f} GP: {stats['loss_gp']:.3f} WD: {stats['wasserstein_distance']:.3f} "
+                  f"dIoU: {delta_iou:.4f}")
+        if not all(map(lambda v: v == v and abs(v) != float("inf"), (stats["loss_G"], stats["loss_D"]))):
+            print("Warning: NaN or Inf detected in losses! Stopping."); break          # :473-478
+        if rank == 0 and delta_iou > best + args.min_delta:
+            best = delta_iou
+            gsd, dsd = eng.state_dicts()
+            torch.save({"generator": {k: v.cpu() for k, v in gsd.items()},
+                        "discriminator": {k: v.cpu() for k, v in dsd.items()},
+                        "epoch": epoch, "delta_iou": delta_iou, "config": config}, ckpt_best)   # :481-489
+    if rank == 0:
+        with open(out_root / "training_history.json", "w") as f:
+            json.dump(history, f, indent=2)
+        print(f"Training complete. Best Delta IoU = {best:.4f}")
+    return history
+
+
+if __name__ == "__main__":
+    main()
