@@ -15,10 +15,14 @@
 // gcssl_wgrad_reduce sums into the PyTorch-layout gradient.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
-constexpr int BK = 32;       // K elements per LDS tile
+// K elements per LDS tile: chosen so that one gathered row is a full 128-byte line in either dtype (64 B half-line
+// gathers measured at the per-CU L2 gather ceiling, MI355X_MICROARCH.md "Indexed rows: gather into LDS").
+template <typename T> struct BKOf { static constexpr int v = 32; };       // fp32: 32 x 4 B
+template <> struct BKOf<bf16_t> { static constexpr int v = 64; };          // bf16: 64 x 2 B
 constexpr int NT = 256;      // threads per workgroup: 4 waves as 2 (M) x 2 (N)
 
 // ------------------------------------------------------------------------------------------
@@ -29,6 +33,7 @@ constexpr int NT = 256;      // threads per workgroup: 4 waves as 2 (M) x 2 (N)
 // ------------------------------------------------------------------------------------------
 template <typename T, int ROWS> struct KMajor;
 template <int ROWS> struct KMajor<float, ROWS> {
+    static constexpr int BK = BKOf<float>::v;
     static constexpr int STRIDE = BK + 1;                     // conflict-free b32 fragment reads
     static constexpr int KSTEPS = BK / 2;
     typedef float Frag;
@@ -42,10 +47,13 @@ template <int ROWS> struct KMajor<float, ROWS> {
     }
 };
 template <int ROWS> struct KMajor<bf16_t, ROWS> {
+    static constexpr int BK = BKOf<bf16_t>::v;
     static constexpr int KSTEPS = BK / 16;
     typedef bf16x8 Frag;
-    uint4 d[ROWS * 4];                                        // 64-byte rows, 16-byte chunks XOR-swizzled
-    __device__ static int swz(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
+    uint4 d[ROWS * 8];                                        // 128-byte rows of 8 16-byte chunks, XOR-swizzled:
+    // a ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) reads one logical chunk of 16 rows; with
+    // chunk' = chunk ^ ((row>>1)&7) those land on 16 distinct 16-B slots of the 256-B bank row -> conflict-free.
+    __device__ static int swz(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
     __device__ void store_vec(int row, int chunk, const Vec16<bf16_t>& v) { d[swz(row, chunk)] = v.v; }
     __device__ Frag frag(int row0, int ks, int lane) const {
         return __builtin_bit_cast(bf16x8, d[swz(row0 + (lane & 31), ks * 2 + (lane >> 5))]);
@@ -54,6 +62,7 @@ template <int ROWS> struct KMajor<bf16_t, ROWS> {
 
 template <typename T, int ROWS> struct MMajor;
 template <int ROWS> struct MMajor<float, ROWS> {
+    static constexpr int BK = BKOf<float>::v;
     static constexpr int KSTEPS = BK / 2;
     typedef float Frag;
     float d[BK * ROWS];
@@ -65,6 +74,7 @@ template <int ROWS> struct MMajor<float, ROWS> {
     }
 };
 template <int ROWS> struct MMajor<bf16_t, ROWS> {
+    static constexpr int BK = BKOf<bf16_t>::v;
     static constexpr int KSTEPS = BK / 16;
     static constexpr int STRIDE = ROWS * 2 + 64;              // bytes; +64 B keeps the 4 rows of a tr block on distinct banks
     typedef bf16x8 Frag;
@@ -87,6 +97,22 @@ template <int ROWS> struct MMajor<bf16_t, ROWS> {
         return __builtin_bit_cast(bf16x8, r);
     }
 };
+
+// Branch-free gather loads.  hipcc turns `ok ? load(p) : 0` into an exec-mask branch per load (each with its own
+// vmcnt drain), which serialises the whole tile fetch; a raw buffer load with an out-of-range offset returns 0 in
+// hardware instead, so every lane always issues the load and validity is a single v_cndmask on the offset.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+template <typename T> __device__ __forceinline__ Vec16<T> bload(__amdgpu_buffer_rsrc_t r, unsigned off);
+template <> __device__ __forceinline__ Vec16<float> bload<float>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    Vec16<float> v; v.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); return v;
+}
+template <> __device__ __forceinline__ Vec16<bf16_t> bload<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    Vec16<bf16_t> v; v.v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); return v;
+}
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -132,6 +158,7 @@ struct ConvParams {
     int out_f32;        // fwd/dgrad: write fp32 regardless of T
     int ktiles_per_split;   // wgrad; fwd/dgrad when ksplit > 1
     int ksplit;             // fwd/dgrad: K is split over ksplit workgroups that atomically add into a zeroed fp32 output
+    unsigned x_bytes, w_bytes;   // extents of the two operand buffers (buffer-load bounds; < 2^31)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -140,6 +167,7 @@ struct ConvParams {
 // ------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
+    constexpr int BK = BKOf<T>::v;
     constexpr int KV = Elem<T>::KV, CH = BK / KV, RPT = NT / CH;   // rows covered per pass
     constexpr int NVA = BM / RPT, NVB = BN / RPT;
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -154,39 +182,44 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
     const int K = 16 * p.Cin;
     const int Ho = p.Hi >> 1, Wo = p.Wi >> 1;
 
-    int pixbase[NVA], iy0[NVA], ix0[NVA];
+    constexpr int ES = (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+    int rowoff[NVA]; unsigned rowmask[NVA];     // byte offset of pixel (2oy-1, 2ox-1); bit t = tap t is inside the image
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
         const int m = m0 + row_t + i * RPT;
+        rowoff[i] = 0; rowmask[i] = 0;
         if (m < p.M) {
             const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
-            const int oy = rem >> p.lgWo, ox = rem & (Wo - 1);
-            pixbase[i] = n * p.Hi * p.Wi; iy0[i] = 2 * oy - 1; ix0[i] = 2 * ox - 1;
-        } else { pixbase[i] = -1; iy0[i] = 0; ix0[i] = 0; }
+            const int iy0 = 2 * (rem >> p.lgWo) - 1, ix0 = 2 * (rem & (Wo - 1)) - 1;
+            rowoff[i] = ((n * p.Hi + iy0) * p.Wi + ix0) * p.ldx * ES;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if ((unsigned)(iy0 + (t >> 2)) < (unsigned)p.Hi && (unsigned)(ix0 + (t & 3)) < (unsigned)p.Wi) mk |= 1u << t;
+            rowmask[i] = mk;
+        }
     }
     (void)Ho;
-    Vec16<T> ra[NVA], rb[NVB];
-    auto gload = [&](int k0) {
+    unsigned wrow[NVB];
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) { const int co = n0 + row_t + j * RPT; wrow[j] = co < p.Cout ? (unsigned)(co * K * ES) : OOB; }
+    Vec16<T> ra[1][NVA], rb[1][NVB];
+    auto gload = [&](Vec16<T> (&qa)[NVA], Vec16<T> (&qb)[NVB], int k0) {
         const int k = k0 + chunk * KV;
         const int tap = k >> p.lgCin, ci = k & (p.Cin - 1);
-        const int ky = tap >> 2, kx = tap & 3;
+        const int tapoff = (((tap >> 2) * p.Wi + (tap & 3)) * p.ldx + ci) * ES;
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) {
-            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-            const bool ok = pixbase[i] >= 0 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            ra[i] = ok ? Vec16<T>::load(x + (size_t)(pixbase[i] + iy * p.Wi + ix) * p.ldx + ci) : Vec16<T>::zero();
-        }
+        for (int i = 0; i < NVA; ++i)
+            qa[i] = bload<T>(xr, ((rowmask[i] >> tap) & 1u) ? (unsigned)(rowoff[i] + tapoff) : OOB);
 #pragma unroll
-        for (int j = 0; j < NVB; ++j) {
-            const int co = n0 + row_t + j * RPT;
-            rb[j] = co < p.Cout ? Vec16<T>::load(w + (size_t)co * K + k) : Vec16<T>::zero();
-        }
+        for (int j = 0; j < NVB; ++j) qb[j] = bload<T>(wr, wrow[j] + (unsigned)(k * ES));
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const Vec16<T> (&qa)[NVA], const Vec16<T> (&qb)[NVB], int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) As[buf].store_vec(row_t + i * RPT, chunk, ra[i]);
+        for (int i = 0; i < NVA; ++i) As[buf].store_vec(row_t + i * RPT, chunk, qa[i]);
 #pragma unroll
-        for (int j = 0; j < NVB; ++j) Bs[buf].store_vec(row_t + j * RPT, chunk, rb[j]);
+        for (int j = 0; j < NVB; ++j) Bs[buf].store_vec(row_t + j * RPT, chunk, qb[j]);
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -200,13 +233,17 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
     const int ks = p.ksplit > 1 ? (int)blockIdx.z : 0;
     const int t_beg = p.ksplit > 1 ? ks * p.ktiles_per_split : 0;
     const int t_end = p.ksplit > 1 ? min(nk_all, t_beg + p.ktiles_per_split) : nk_all;
+    // Software pipeline: LDS double buffer + two register sets.  While the MFMAs consume tile t from LDS, tile t+1 is
+    // landing in one register set (issued a whole iteration ago) and tile t+2 is being issued into the other.
+    // (A two-tiles-ahead variant with a second register set was measured 1.5-1.9x SLOWER on the 128-wide tiles: it
+    //  pushed them to 130-194 VGPRs and the lost occupancy cost more than the extra overlap bought.)
     if (t_beg < t_end) {
-        gload(t_beg * BK); lstore(0); __syncthreads();
+        gload(ra[0], rb[0], t_beg * BK); lstore(ra[0], rb[0], 0); __syncthreads();
         for (int t = t_beg; t < t_end; ++t) {
             const int b = (t - t_beg) & 1;
-            if (t + 1 < t_end) gload((t + 1) * BK);
+            if (t + 1 < t_end) gload(ra[0], rb[0], (t + 1) * BK);
             mma_slab<TM, TN>(As[b], Bs[b], wm0, wn0, lane, acc);
-            if (t + 1 < t_end) lstore(b ^ 1);
+            if (t + 1 < t_end) lstore(ra[0], rb[0], b ^ 1);
             __syncthreads();
         }
     }
@@ -246,6 +283,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
 // ------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
+    constexpr int BK = BKOf<T>::v;
     constexpr int KV = Elem<T>::KV, CH = BK / KV, RPT = NT / CH;
     constexpr int NVA = BM / RPT, NVB = BN / RPT;
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -263,38 +301,45 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
     const int Ho = p.Hi >> 1, Wo = p.Wi >> 1;
     const int K = 4 * p.Cout;
 
-    int pixbase[NVA], yy[NVA], xx[NVA];
+    constexpr int ES = (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+    int rowoff[NVA]; unsigned rowmask[NVA];     // byte offset of dy pixel (iy'+py, ix'+px); bit t=(ty,tx): (oy,ox)=(..-ty,..-tx) inside
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
         const int m = m0 + row_t + i * RPT;
+        rowoff[i] = 0; rowmask[i] = 0;
         if (m < p.M) {
             const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
-            pixbase[i] = n * Ho * Wo; yy[i] = (rem >> p.lgWo) + py; xx[i] = (rem & (Wo - 1)) + px;
-        } else { pixbase[i] = -1; yy[i] = 0; xx[i] = 0; }
+            const int yy = (rem >> p.lgWo) + py, xx = (rem & (Wo - 1)) + px;
+            rowoff[i] = ((n * Ho + yy) * Wo + xx) * p.ldx * ES;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if ((unsigned)(yy - (t >> 1)) < (unsigned)Ho && (unsigned)(xx - (t & 1)) < (unsigned)Wo) mk |= 1u << t;
+            rowmask[i] = mk;
+        }
     }
-    Vec16<T> ra[NVA], rb[NVB];
-    auto gload = [&](int k0) {
+    unsigned wrow[NVB];
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) { const int ci = n0 + row_t + j * RPT; wrow[j] = ci < p.Cin ? (unsigned)(ci * 16 * p.Cout * ES) : OOB; }
+    Vec16<T> ra[1][NVA], rb[1][NVB];
+    auto gload = [&](Vec16<T> (&qa)[NVA], Vec16<T> (&qb)[NVB], int k0) {
         const int k = k0 + chunk * KV;
         const int t = k >> p.lgCout, co = k & (p.Cout - 1);
         const int ty = t >> 1, tx = t & 1;
         const int tap = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
+        const int tapoff = (co - (ty * Wo + tx) * p.ldx) * ES;
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) {
-            const int oy = yy[i] - ty, ox = xx[i] - tx;
-            const bool ok = pixbase[i] >= 0 && (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo;
-            ra[i] = ok ? Vec16<T>::load(dy + (size_t)(pixbase[i] + oy * Wo + ox) * p.ldx + co) : Vec16<T>::zero();
-        }
+        for (int i = 0; i < NVA; ++i)
+            qa[i] = bload<T>(xr, ((rowmask[i] >> t) & 1u) ? (unsigned)(rowoff[i] + tapoff) : OOB);
 #pragma unroll
-        for (int j = 0; j < NVB; ++j) {
-            const int ci = n0 + row_t + j * RPT;
-            rb[j] = ci < p.Cin ? Vec16<T>::load(wt + ((size_t)ci * 16 + tap) * p.Cout + co) : Vec16<T>::zero();
-        }
+        for (int j = 0; j < NVB; ++j) qb[j] = bload<T>(wr, wrow[j] + (unsigned)((tap * p.Cout + co) * ES));
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const Vec16<T> (&qa)[NVA], const Vec16<T> (&qb)[NVB], int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) As[buf].store_vec(row_t + i * RPT, chunk, ra[i]);
+        for (int i = 0; i < NVA; ++i) As[buf].store_vec(row_t + i * RPT, chunk, qa[i]);
 #pragma unroll
-        for (int j = 0; j < NVB; ++j) Bs[buf].store_vec(row_t + j * RPT, chunk, rb[j]);
+        for (int j = 0; j < NVB; ++j) Bs[buf].store_vec(row_t + j * RPT, chunk, qb[j]);
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -306,13 +351,17 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
     const int nk_all = K / BK;
     const int t_beg = p.ksplit > 1 ? ks * p.ktiles_per_split : 0;
     const int t_end = p.ksplit > 1 ? min(nk_all, t_beg + p.ktiles_per_split) : nk_all;
+    // Software pipeline: LDS double buffer + two register sets.  While the MFMAs consume tile t from LDS, tile t+1 is
+    // landing in one register set (issued a whole iteration ago) and tile t+2 is being issued into the other.
+    // (A two-tiles-ahead variant with a second register set was measured 1.5-1.9x SLOWER on the 128-wide tiles: it
+    //  pushed them to 130-194 VGPRs and the lost occupancy cost more than the extra overlap bought.)
     if (t_beg < t_end) {
-        gload(t_beg * BK); lstore(0); __syncthreads();
+        gload(ra[0], rb[0], t_beg * BK); lstore(ra[0], rb[0], 0); __syncthreads();
         for (int t = t_beg; t < t_end; ++t) {
             const int b = (t - t_beg) & 1;
-            if (t + 1 < t_end) gload((t + 1) * BK);
+            if (t + 1 < t_end) gload(ra[0], rb[0], (t + 1) * BK);
             mma_slab<TM, TN>(As[b], Bs[b], wm0, wn0, lane, acc);
-            if (t + 1 < t_end) lstore(b ^ 1);
+            if (t + 1 < t_end) lstore(ra[0], rb[0], b ^ 1);
             __syncthreads();
         }
     }
@@ -340,6 +389,172 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 forward / dgrad with LDS-DMA staging (MODE 0 = forward conv, 1 = dgrad / transposed conv).
+// Same GEMM as conv_fwd_kernel / conv_dgrad_kernel, different pipeline: `buffer_load_dwordx4 ... lds` writes the
+// gathered 16-byte channel vectors straight into a 3-slot LDS ring (no VGPR staging, no ds_write, no registers spent
+// on prefetch), tiles t+1 and t+2 are in flight while the MFMAs consume tile t, and each K-step costs one raw
+// s_barrier behind a COUNTED s_waitcnt vmcnt (never 0 inside the loop).
+//   * The DMA destination is wave-uniform base + lane*16, i.e. lane-linear, so the XOR swizzle of KMajor<bf16> is
+//     applied to the SOURCE: the lane that fills physical chunk pc of row r fetches logical chunk pc ^ ((r>>1)&7).
+//   * Out-of-image taps / rows use an out-of-range buffer offset: the hardware returns 0 and the DMA writes zeros.
+//   * All LDS lives in ONE __shared__ array (a second object makes hipcc drain vmcnt(0) before the ds_reads).
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_p;
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(NT) void conv_dma_kernel(ConvParams p) {
+    typedef bf16_t T;
+    constexpr int BK = 64, ES = 2, KV = 8, CH = 8, RPT = NT / CH;         // 32 tile rows per pass of the 256 threads
+    constexpr int NVA = BM / RPT, NVB = BN / RPT, NL = NVA + NVB;          // DMA instructions per wave per K-tile
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int cls = MODE == 1 ? (p.ksplit > 1 ? (int)blockIdx.z / p.ksplit : (int)blockIdx.z) : 0;
+    const int ks = p.ksplit > 1 ? (MODE == 1 ? (int)blockIdx.z % p.ksplit : (int)blockIdx.z) : 0;
+    const int py = cls >> 1, px = cls & 1;
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int Ho = p.Hi >> 1, Wo = p.Wi >> 1;
+    const int K = MODE == 0 ? 16 * p.Cin : 4 * p.Cout;
+    const int row_t = tid / CH;
+    const int lc = (tid % CH) ^ ((row_t >> 1) & 7);                        // logical chunk this lane fetches
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+
+    int rowoff[NVA]; unsigned rowmask[NVA];
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+        const int m = m0 + row_t + i * RPT;
+        rowoff[i] = 0; rowmask[i] = 0;
+        if (m < p.M) {
+            const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
+            unsigned mk = 0;
+            if (MODE == 0) {
+                const int iy0 = 2 * (rem >> p.lgWo) - 1, ix0 = 2 * (rem & (Wo - 1)) - 1;
+                rowoff[i] = ((n * p.Hi + iy0) * p.Wi + ix0) * p.ldx * ES;
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    if ((unsigned)(iy0 + (t >> 2)) < (unsigned)p.Hi && (unsigned)(ix0 + (t & 3)) < (unsigned)p.Wi) mk |= 1u << t;
+            } else {
+                const int yy = (rem >> p.lgWo) + py, xx = (rem & (Wo - 1)) + px;
+                rowoff[i] = ((n * Ho + yy) * Wo + xx) * p.ldx * ES;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if ((unsigned)(yy - (t >> 1)) < (unsigned)Ho && (unsigned)(xx - (t & 1)) < (unsigned)Wo) mk |= 1u << t;
+            }
+            rowmask[i] = mk;
+        }
+    }
+    unsigned wrow[NVB];
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+        const int r = n0 + row_t + j * RPT;
+        if (MODE == 0) wrow[j] = r < p.Cout ? (unsigned)(r * K * ES) : OOB;
+        else wrow[j] = r < p.Cin ? (unsigned)(r * 16 * p.Cout * ES) : OOB;
+    }
+    auto issue = [&](int t, int slot) {
+        const int k = t * BK + lc * KV;
+        unsigned char* base = lds + slot * STAGE + wave * 1024;
+        int tapbit, tapoff; unsigned woff;
+        if (MODE == 0) {
+            const int tap = k >> p.lgCin, ci = k & (p.Cin - 1);
+            tapbit = tap; tapoff = (((tap >> 2) * p.Wi + (tap & 3)) * p.ldx + ci) * ES; woff = (unsigned)(k * ES);
+        } else {
+            const int t4 = k >> p.lgCout, co = k & (p.Cout - 1);
+            const int ty = t4 >> 1, tx = t4 & 1;
+            const int tap = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
+            tapbit = t4; tapoff = (co - (ty * Wo + tx) * p.ldx) * ES; woff = (unsigned)((tap * p.Cout + co) * ES);
+        }
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const unsigned off = ((rowmask[i] >> tapbit) & 1u) ? (unsigned)(rowoff[i] + tapoff) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_p)(base + i * 4096), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NVB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_p)(base + A_BYTES + j * 4096), 16, wrow[j] + woff, 0, 0, 0);
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto frag = [&](const unsigned char* tile, int row0, int kstep) -> bf16x8 {
+        const int row = row0 + (lane & 31), c = kstep * 2 + (lane >> 5);
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)));
+    };
+    const int nk_all = K / BK;
+    const int t_beg = p.ksplit > 1 ? ks * p.ktiles_per_split : 0;
+    const int t_end = p.ksplit > 1 ? min(nk_all, t_beg + p.ktiles_per_split) : nk_all;
+    if (t_beg < t_end) {
+        issue(t_beg, 0);
+        if (t_beg + 1 < t_end) issue(t_beg + 1, 1);
+        int slot = 0;
+        for (int t = t_beg; t < t_end; ++t) {
+            // tile t has landed once at most the NL younger DMA instructions (tile t+1) are still outstanding
+            if (t + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // everyone's part of tile t landed; everyone is done reading tile t-1
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < t_end) issue(t + 2, slot == 0 ? 2 : slot - 1);     // slot of tile t-1 == (slot+2)%3
+            const unsigned char* At = lds + slot * STAGE;
+            const unsigned char* Bt = At + A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = frag(At, wm0 + 32 * i, kk);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = frag(Bt, wn0 + 32 * j, kk);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
+            }
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
+    // ---- epilogue (identical to the register-staged kernels)
+    float* y32 = static_cast<float*>(p.y);
+    T* yt = static_cast<T*>(p.y);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm0 + 32 * i + crow(r, lane);
+            if (m >= p.M) continue;
+            const int n = m >> p.lgHoWo;
+            size_t pix = (size_t)m;
+            if (MODE == 1) {
+                const int rem = m & ((1 << p.lgHoWo) - 1);
+                const int iy = 2 * (rem >> p.lgWo) + py, ix = 2 * (rem & (Wo - 1)) + px;
+                pix = (size_t)(n * p.Hi + iy) * p.Wi + ix;
+            }
+            const float sc = p.gscale ? p.gscale[n / p.group_n] : 1.f;
+            const int ncols = MODE == 0 ? p.Cout : p.Cin;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn0 + 32 * j + (lane & 31);
+                if (col >= ncols) continue;
+                float v = acc[i][j][r] * sc;
+                if (p.ksplit > 1) {
+                    if (MODE == 0 && p.bias && ks == 0) v += p.bias[col];
+                    atomicAdd(y32 + pix * p.ldy + col, v);
+                    continue;
+                }
+                if (MODE == 0) {
+                    if (p.bias) v += p.bias[col];
+                    if (p.act == 1) v = lrelu_f(v);
+                }
+                if (p.out_f32) y32[pix * p.ldy + col] = v;
+                else Elem<T>::st(yt + pix * p.ldy + col, v);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // wgrad: slab[split][co][tap][ci] = sum_{k in split} dy[k][co] * x[n, 2oy-1+ky, 2ox-1+kx, ci],  k = (n,oy,ox)
 // GEMM M = Cout, N = (tap, ci), K = N*Ho*Wo split over blockIdx.z.  blockIdx.y = tap * (Cin/BN) + ci-tile.
 // Both operands arrive row(k)-major with channels contiguous -> MMajor tiles, transposed LDS reads.
@@ -347,6 +562,7 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
 // SMALLC (first layers, Cin padded to 8): the N tile is all 16 taps x 8 channels (BN must be 128).
 template <typename T, int BM, int BN, bool SMALLC>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
+    constexpr int BK = BKOf<T>::v;
     constexpr int KV = Elem<T>::KV;
     static_assert(!SMALLC || BN == 128, "SMALLC covers 16 taps x 8 channels");
     constexpr int CHA = BM / KV, CHB = BN / KV;               // vectors per k-row
@@ -370,13 +586,15 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
     const int nkt = (Ktot + BK - 1) / BK;
     if (kt_end > nkt) kt_end = nkt;
 
-    Vec16<T> ra[NVA], rb[NVB];
-    auto gload = [&](int k0) {
+    constexpr int ES = (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), dr = make_rsrc(p.w, p.w_bytes);
+    Vec16<T> ra[1][NVA], rb[1][NVB];
+    auto gload = [&](Vec16<T> (&qa)[NVA], Vec16<T> (&qb)[NVB], int k0) {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int v = tid + i * NT, kr = v / CHA, c = v % CHA;
-            const int k = k0 + kr;
-            ra[i] = k < Ktot ? Vec16<T>::load(dy + (size_t)k * p.ldw + co0 + c * KV) : Vec16<T>::zero();
+            const int k = k0 + kr;                                 // rows k >= Ktot fall outside the dy buffer -> 0
+            qa[i] = bload<T>(dr, k < Ktot ? (unsigned)((k * p.ldw + co0 + c * KV) * ES) : OOB);
         }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
@@ -387,14 +605,14 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
             if (SMALLC) { const int tp = (c * KV) >> 3; kyy = tp >> 2; kxx = tp & 3; coff = (c * KV) & 7; }
             const int iy = 2 * (rem >> p.lgWo) - 1 + kyy, ix = 2 * (rem & (Wo - 1)) - 1 + kxx;
             const bool ok = k < Ktot && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            rb[i] = ok ? Vec16<T>::load(x + ((size_t)(n * p.Hi + iy) * p.Wi + ix) * p.ldx + coff) : Vec16<T>::zero();
+            qb[i] = bload<T>(xr, ok ? (unsigned)((((n * p.Hi + iy) * p.Wi + ix) * p.ldx + coff) * ES) : OOB);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const Vec16<T> (&qa)[NVA], const Vec16<T> (&qb)[NVB], int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) { const int v = tid + i * NT; As[buf].store_vec(v / CHA, v % CHA, ra[i]); }
+        for (int i = 0; i < NVA; ++i) { const int v = tid + i * NT; As[buf].store_vec(v / CHA, v % CHA, qa[i]); }
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) { const int v = tid + i * NT; Bs[buf].store_vec(v / CHB, v % CHB, rb[i]); }
+        for (int i = 0; i < NVB; ++i) { const int v = tid + i * NT; Bs[buf].store_vec(v / CHB, v % CHB, qb[i]); }
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -404,12 +622,12 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if (kt_beg < kt_end) {
-        gload(kt_beg * BK); lstore(0); __syncthreads();
+        gload(ra[0], rb[0], kt_beg * BK); lstore(ra[0], rb[0], 0); __syncthreads();
         for (int t = kt_beg; t < kt_end; ++t) {
             const int b = (t - kt_beg) & 1;
-            if (t + 1 < kt_end) gload((t + 1) * BK);
+            if (t + 1 < kt_end) gload(ra[0], rb[0], (t + 1) * BK);
             mma_slab<TM, TN>(As[b], Bs[b], wm0, wn0, lane, acc);
-            if (t + 1 < kt_end) lstore(b ^ 1);
+            if (t + 1 < kt_end) lstore(ra[0], rb[0], b ^ 1);
             __syncthreads();
         }
     }
@@ -483,16 +701,22 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     if (wt) Elem<T>::st(wt + ((size_t)ci * 16 + tap) * Cout + co, val);
 }
 
+bool use_dma() {
+    static bool v = [] { const char* e = getenv("GCSSL_CONV_DMA"); return !(e && e[0] == '0'); }();
+    return v;
+}
 template <typename T, int BM, int BN>
 int launch_fwd(const ConvParams& p, hipStream_t st) {
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
-    hipLaunchKernelGGL((conv_fwd_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
+    if (std::is_same<T, bf16_t>::value && use_dma()) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, 0>), grid, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((conv_fwd_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
 }
 template <typename T, int BM, int BN>
 int launch_dgrad(const ConvParams& p, hipStream_t st) {
     dim3 grid((p.M + BM - 1) / BM, (p.Cin + BN - 1) / BN, 4 * (p.ksplit > 1 ? p.ksplit : 1));
-    hipLaunchKernelGGL((conv_dgrad_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
+    if (std::is_same<T, bf16_t>::value && use_dma()) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, 1>), grid, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((conv_dgrad_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
 }
 
@@ -501,6 +725,14 @@ int check_geom(int N, int Hi, int Wi, int Cin, int Cout) {
         return GCSSL_EBADSHAPE;
     if (Cin < 8 || Cout < 8) return GCSSL_EBADSHAPE;
     return GCSSL_OK;
+}
+
+// operand extents in bytes for the buffer-load bounds check; false if a tensor does not fit 31-bit byte offsets
+bool fill_bytes(ConvParams& p, size_t x_elems, size_t w_elems, int es) {
+    const size_t xb = x_elems * es, wb = w_elems * es;
+    if (xb >= 0x7FFFFFFFull || wb >= 0x7FFFFFFFull) return false;
+    p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+    return true;
 }
 
 void fill_geom(ConvParams& p, int N, int Hi, int Wi, int Cin, int Cout) {
@@ -515,6 +747,12 @@ void fill_geom(ConvParams& p, int N, int Hi, int Wi, int Cin, int Cout) {
 // 64..128-deep serial K loop each: they are latency-bound, not MFMA-bound.  When the output is fp32 and the epilogue
 // linear, split K across workgroups and accumulate with fp32 atomics into a zeroed output (128-B contiguous per
 // half-wave: the full-rate atomic shape of MI355X_MICROARCH.md "Global float atomics").
+// a bigger tile is only chosen when it still yields this many workgroups (occupancy hides the gather latency)
+long tile_threshold() {
+    static long v = [] { const char* e = getenv("GCSSL_TILE_WGS"); return e ? atol(e) : 256L; }();
+    return v;
+}
+
 int pick_ksplit(long tiles, int nk, bool allowed) {
     if (!allowed || tiles >= 384 || nk < 16) return 1;
     int ks = (int)((512 + tiles - 1) / tiles);
@@ -531,10 +769,10 @@ int zero_output(const ConvParams& p, long rows, int cols, hipStream_t st) {
 template <typename T>
 int dispatch_fwd(ConvParams p, hipStream_t st) {
     const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-    if (p.Cout >= 128 && t128 >= 256) return launch_fwd<T, 128, 128>(p, st);
-    if (p.Cout >= 64 && (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64) >= 256) return launch_fwd<T, 128, 64>(p, st);
+    if (p.Cout >= 128 && t128 >= tile_threshold()) return launch_fwd<T, 128, 128>(p, st);
+    if (p.Cout >= 64 && (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64) >= tile_threshold()) return launch_fwd<T, 128, 64>(p, st);
     const long t64 = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64);
-    const int nk = 16 * p.Cin / BK;
+    const int nk = 16 * p.Cin / BKOf<T>::v;
     const bool f32out = p.out_f32 || std::is_same<T, float>::value;
     p.ksplit = pick_ksplit(t64, nk, f32out && p.act == 0);
     if (p.ksplit > 1) {
@@ -547,10 +785,10 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
 template <typename T>
 int dispatch_dgrad(ConvParams p, hipStream_t st) {
     const long t128 = 4L * ((p.M + 127) / 128) * ((p.Cin + 127) / 128);
-    if (p.Cin >= 128 && t128 >= 256) return launch_dgrad<T, 128, 128>(p, st);
-    if (p.Cin >= 64 && 4L * ((p.M + 127) / 128) * ((p.Cin + 63) / 64) >= 256) return launch_dgrad<T, 128, 64>(p, st);
+    if (p.Cin >= 128 && t128 >= tile_threshold()) return launch_dgrad<T, 128, 128>(p, st);
+    if (p.Cin >= 64 && 4L * ((p.M + 127) / 128) * ((p.Cin + 63) / 64) >= tile_threshold()) return launch_dgrad<T, 128, 64>(p, st);
     const long t64 = 4L * ((p.M + 63) / 64) * ((p.Cin + 63) / 64);
-    const int nk = 4 * p.Cout / BK;
+    const int nk = 4 * p.Cout / BKOf<T>::v;
     const bool f32out = p.out_f32 || std::is_same<T, float>::value;
     p.ksplit = pick_ksplit(t64, nk, f32out);
     if (p.ksplit > 1) {
@@ -577,6 +815,7 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
     ConvParams p{}; p.x = x; p.w = wf; p.y = y; p.bias = bias; p.gscale = gscale; p.group_n = group_n;
     p.ldx = ldx; p.ldy = ldy; p.act = act; p.out_f32 = out_f32;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
+    if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)Cout * 16 * Cin, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GCSSL_F32) return dispatch_fwd<float>(p, st);
     if (dtype == GCSSL_BF16) return dispatch_fwd<bf16_t>(p, st);
@@ -595,6 +834,7 @@ int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, c
     ConvParams p{}; p.x = dy; p.w = wt; p.y = dx; p.gscale = gscale; p.group_n = group_n;
     p.ldx = lddy; p.ldy = lddx; p.out_f32 = out_f32;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
+    if (!fill_bytes(p, (size_t)N * (Hi / 2) * (Wi / 2) * lddy, (size_t)Cin * 16 * Cout, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GCSSL_F32) return dispatch_dgrad<float>(p, st);
     if (dtype == GCSSL_BF16) return dispatch_dgrad<bf16_t>(p, st);
@@ -607,7 +847,7 @@ int gcssl_conv4x4s2_wgrad_splits(int N, int Hi, int Wi, int Cin, int Cout) {
     const int bm = Cout >= 128 ? 128 : 64, bn = Cin >= 128 ? 128 : (Cin >= 64 ? 64 : (Cin == 8 ? 8 : 0));
     if (!bn) return GCSSL_EBADSHAPE;
     const long tiles = (long)(Cout / bm) * 16 * (Cin / bn) / (Cin == 8 ? 16 : 1);
-    const int nkt = (N * (Hi / 2) * (Wi / 2) + BK - 1) / BK;
+    const int nkt = (N * (Hi / 2) * (Wi / 2) + 63) / 64;       // K granules of 64 output pixels (dtype independent)
     long want = (512 + tiles - 1) / tiles;                 // ~2 workgroups per CU
     if (want > 128) want = 128;                            // padded first layers have a single tile: bound the slab count
     if (want < 1) want = 1;
@@ -628,8 +868,9 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
     if (nsplit <= 0) return GCSSL_EBADSHAPE;
     ConvParams p{}; p.x = x; p.w = dy; p.y = slab; p.ldx = ldx; p.ldw = lddy;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
-    const int nkt = (p.M + BK - 1) / BK;
-    p.ktiles_per_split = (nkt + nsplit - 1) / nsplit;
+    if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)N * (Hi / 2) * (Wi / 2) * lddy, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
+    const int nkt = (p.M + 63) / 64;
+    p.ktiles_per_split = ((nkt + nsplit - 1) / nsplit) * (64 / (dtype == GCSSL_F32 ? BKOf<float>::v : BKOf<bf16_t>::v));
     hipStream_t st = (hipStream_t)stream;
     const int bm = Cout >= 128 ? 128 : 64, bn = Cin >= 128 ? 128 : 64;
     const bool smallc = Cin == 8;

@@ -1,0 +1,30 @@
+"""Standalone launcher of ONE conv configuration (for rocprofv3 --pmc / timing experiments).
+usage: python tools/conv_bench.py {fwd|dgrad|wgrad} N Hi Cin Cout [dtype] [reps]"""
+import importlib, sys, time, torch
+sys.path.insert(0, '.')
+ops = importlib.import_module("gan-calibrated-semi-supervised-learning_amd.ops")
+kind, N, Hi, Cin, Cout = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+dt = torch.bfloat16 if (len(sys.argv) < 7 or sys.argv[6] == "bf16") else torch.float32
+reps = int(sys.argv[7]) if len(sys.argv) > 7 else 20
+x = (torch.rand(N, Hi, Hi, Cin, device="cuda") * 2 - 1).to(dt)
+dy = (torch.rand(N, Hi // 2, Hi // 2, Cout, device="cuda") * 2 - 1).to(dt)
+w = torch.randn(Cout, Cin, 4, 4, device="cuda") * 0.05
+wf = torch.empty(Cout, 16, Cin, device="cuda", dtype=dt); wt = torch.empty(Cin, 16, Cout, device="cuda", dtype=dt)
+ops.prep_conv_weight(w, wf, wt, Cout, Cin, Cin, ops.code(wf))
+y = torch.empty(N, Hi // 2, Hi // 2, Cout, device="cuda", dtype=torch.float32)
+dx = torch.empty(N, Hi, Hi, Cin, device="cuda", dtype=torch.float32)
+ns = ops.wgrad_splits(N, Hi, Hi, Cin, Cout)
+slab = torch.empty(ns, Cout, 16, Cin, device="cuda")
+def run():
+    if kind == "fwd": ops.conv_fwd(x, wf, y, Cin, Cout)
+    elif kind == "dgrad": ops.conv_dgrad(dy, wt, dx, Cin, Cout)
+    else: ops.conv_wgrad(x, dy, slab, Cin, Cout)
+for _ in range(3): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps): run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+fl = 2.0 * N * (Hi // 2) ** 2 * Cout * 16 * Cin
+print(f"{kind} N={N} Hi={Hi} Cin={Cin} Cout={Cout} {dt}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF/s")
