@@ -401,20 +401,29 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_void_p;
 
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(NT) void conv_dma_kernel(ConvParams p) {
+// WM x WN waves per workgroup (4 or 8 waves); SMALLK: the K-tile spans several taps (first layer, Cin padded to 8),
+// otherwise the tap of a K-tile is wave-uniform and its address arithmetic runs on the scalar unit.
+template <int BM, int BN, int MODE, int WM, int WN, bool SMALLK>
+__global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
+    // The host pass only needs the launch stub; it silently marks this body invalid (device-only LDS-DMA builtin and
+    // inline asm with template-dependent operands) and then emits NO stub, so the body is device-pass only.
+#if defined(__HIP_DEVICE_COMPILE__)
     typedef bf16_t T;
-    constexpr int BK = 64, ES = 2, KV = 8, CH = 8, RPT = NT / CH;         // 32 tile rows per pass of the 256 threads
+    constexpr int NTH = WM * WN * 64;
+    constexpr int BK = 64, ES = 2, KV = 8, CH = 8, RPT = NTH / CH;        // tile rows per pass of the workgroup
     constexpr int NVA = BM / RPT, NVB = BN / RPT, NL = NVA + NVB;          // DMA instructions per wave per K-tile
-    constexpr int TM = BM / 64, TN = BN / 64;
+    static_assert(NVA >= 1 && NVB >= 1, "tile too small for this many waves");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int cls = MODE == 1 ? (p.ksplit > 1 ? (int)blockIdx.z / p.ksplit : (int)blockIdx.z) : 0;
     const int ks = p.ksplit > 1 ? (MODE == 1 ? (int)blockIdx.z % p.ksplit : (int)blockIdx.z) : 0;
     const int py = cls >> 1, px = cls & 1;
-    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
     const int Ho = p.Hi >> 1, Wo = p.Wi >> 1;
     const int K = MODE == 0 ? 16 * p.Cin : 4 * p.Cout;
     const int row_t = tid / CH;
@@ -443,6 +452,7 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(ConvParams p) {
                     if ((unsigned)(yy - (t >> 1)) < (unsigned)Ho && (unsigned)(xx - (t & 1)) < (unsigned)Wo) mk |= 1u << t;
             }
             rowmask[i] = mk;
+            if (!SMALLK) rowoff[i] += lc * KV * ES;                        // the lane's chunk offset never changes
         }
     }
     unsigned wrow[NVB];
@@ -451,28 +461,34 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(ConvParams p) {
         const int r = n0 + row_t + j * RPT;
         if (MODE == 0) wrow[j] = r < p.Cout ? (unsigned)(r * K * ES) : OOB;
         else wrow[j] = r < p.Cin ? (unsigned)(r * 16 * p.Cout * ES) : OOB;
+        if (!SMALLK && wrow[j] != OOB) wrow[j] += lc * KV * ES;
     }
+    // (plain ints on purpose: with value-dependent operands hipcc's HOST pass silently rejects the LDS-DMA builtin call,
+    //  marks the kernel invalid and emits no launch stub)
+    int vstride = NTH * 16, a_bytes = A_BYTES, stage = STAGE;
     auto issue = [&](int t, int slot) {
-        const int k = t * BK + lc * KV;
-        unsigned char* base = lds + slot * STAGE + wave * 1024;
+        unsigned char* base = lds + slot * stage + wave * 1024;
         int tapbit, tapoff; unsigned woff;
+        const int kb = SMALLK ? t * BK + lc * KV : t * BK;                 // !SMALLK: wave-uniform -> SALU
         if (MODE == 0) {
-            const int tap = k >> p.lgCin, ci = k & (p.Cin - 1);
-            tapbit = tap; tapoff = (((tap >> 2) * p.Wi + (tap & 3)) * p.ldx + ci) * ES; woff = (unsigned)(k * ES);
+            const int tap = kb >> p.lgCin, ci = kb & (p.Cin - 1);
+            tapbit = tap; tapoff = (((tap >> 2) * p.Wi + (tap & 3)) * p.ldx + ci) * ES; woff = (unsigned)(kb * ES);
         } else {
-            const int t4 = k >> p.lgCout, co = k & (p.Cout - 1);
+            const int t4 = kb >> p.lgCout, co = kb & (p.Cout - 1);
             const int ty = t4 >> 1, tx = t4 & 1;
             const int tap = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
             tapbit = t4; tapoff = (co - (ty * Wo + tx) * p.ldx) * ES; woff = (unsigned)((tap * p.Cout + co) * ES);
         }
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
-            const unsigned off = ((rowmask[i] >> tapbit) & 1u) ? (unsigned)(rowoff[i] + tapoff) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_p)(base + i * 4096), 16, off, 0, 0, 0);
+            // (the offset expression stays inline: it keeps the call type-dependent, so hipcc's HOST pass defers checking
+            //  this device-only builtin instead of silently invalidating the kernel and dropping its launch stub)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_p)(base + i * vstride), 16,
+                ((rowmask[i] >> tapbit) & 1u) ? (unsigned)(rowoff[i] + tapoff) : OOB, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NVB; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_p)(base + A_BYTES + j * 4096), 16, wrow[j] + woff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_p)(base + a_bytes + j * vstride), 16, wrow[j] + woff, 0, 0, 0);
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -552,6 +568,7 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(ConvParams p) {
                 else Elem<T>::st(yt + pix * p.ldy + col, v);
             }
         }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -705,17 +722,48 @@ bool use_dma() {
     static bool v = [] { const char* e = getenv("GCSSL_CONV_DMA"); return !(e && e[0] == '0'); }();
     return v;
 }
+// 8-wave workgroups on the 128-row tiles put 2-3 waves on every SIMD (the kernels are instruction-issue bound at
+// 1-1.5 waves/SIMD: ~115 non-MFMA instructions per 8 MFMAs); GCSSL_DMA_WAVES=4 forces the 4-wave form for A/B runs.
+int dma_waves() {
+    static int v = [] { const char* e = getenv("GCSSL_DMA_WAVES"); return e ? atoi(e) : 8; }();
+    return v;
+}
+template <int BM, int BN, int MODE> struct Dma8 {            // 8-wave form exists only for the 128-row tiles
+    static bool launch(const ConvParams&, dim3, hipStream_t) { return false; }
+};
+template <int MODE> struct Dma8<128, 128, MODE> {
+    static bool launch(const ConvParams& p, dim3 grid, hipStream_t st) {
+        hipLaunchKernelGGL((conv_dma_kernel<128, 128, MODE, 2, 4, false>), grid, dim3(512), 0, st, p);
+        return true;
+    }
+};
+template <int MODE> struct Dma8<128, 64, MODE> {
+    static bool launch(const ConvParams& p, dim3 grid, hipStream_t st) {
+        hipLaunchKernelGGL((conv_dma_kernel<128, 64, MODE, 4, 2, false>), grid, dim3(512), 0, st, p);
+        return true;
+    }
+};
+template <int BM, int BN, int MODE>
+void launch_dma(const ConvParams& p, dim3 grid, bool smallk, hipStream_t st) {
+    if (dma_waves() == 8 && !smallk && Dma8<BM, BN, MODE>::launch(p, grid, st)) return;
+    if (smallk) {
+        hipLaunchKernelGGL((conv_dma_kernel<BM, BN, MODE, 2, 2, true>), grid, dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((conv_dma_kernel<BM, BN, MODE, 2, 2, false>), grid, dim3(256), 0, st, p);
+    }
+}
+
 template <typename T, int BM, int BN>
 int launch_fwd(const ConvParams& p, hipStream_t st) {
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
-    if (std::is_same<T, bf16_t>::value && use_dma()) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, 0>), grid, dim3(NT), 0, st, p);
+    if (std::is_same<T, bf16_t>::value && use_dma()) launch_dma<BM, BN, 0>(p, grid, p.Cin < 64, st);
     else hipLaunchKernelGGL((conv_fwd_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
 }
 template <typename T, int BM, int BN>
 int launch_dgrad(const ConvParams& p, hipStream_t st) {
     dim3 grid((p.M + BM - 1) / BM, (p.Cin + BN - 1) / BN, 4 * (p.ksplit > 1 ? p.ksplit : 1));
-    if (std::is_same<T, bf16_t>::value && use_dma()) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, 1>), grid, dim3(NT), 0, st, p);
+    if (std::is_same<T, bf16_t>::value && use_dma()) launch_dma<BM, BN, 1>(p, grid, false, st);
     else hipLaunchKernelGGL((conv_dgrad_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
 }
