@@ -67,6 +67,31 @@ __device__ __forceinline__ void combine16(float (&v)[NV][VC], float (*sm)[RGN][C
         }
 }
 
+// Small maps (H*W <= 64): a lane owns 4 rows x 4 channels, RGN_ = ceil(HW/4) in {1,4,16} row-group lanes make up one
+// sample and 16/RGN_ samples share a 256-thread pass (so 2x2 and 4x4 maps still use every lane); a workgroup runs
+// several passes and keeps its bias / spectral-norm partial sums in registers -> ONE set of atomics per workgroup
+// (same-address float atomics serialise at ~12 ns each: 1536 workgroups on 3 addresses cost more than the data pass).
+template <int NV, int RG>
+__device__ __forceinline__ void combine_seg(float (&v)[NV][VC], float (*sm)[RGN][CW], int tx, int ty) {
+    if (RG == 1) return;                                   // the lane already holds its sample's full column sums
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < VC; ++j) sm[i][ty][tx * VC + j] = v[i][j];
+    __syncthreads();
+    const int g0 = (ty / RG) * RG;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < VC; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < RG; ++g) s += sm[i][g0 + g][tx * VC + j];
+            v[i][j] = s;
+        }
+}
+
 __device__ __forceinline__ void ld4(const float* p, float (&o)[VC]) {
     const float4 t = *reinterpret_cast<const float4*>(p); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
 }
@@ -80,6 +105,13 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (
     w.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
     *reinterpret_cast<uint2*>(p) = w;
 }
+template <typename T> __device__ __forceinline__ void ldT4(const T* p, float (&o)[VC]);
+template <> __device__ __forceinline__ void ldT4<float>(const float* p, float (&o)[VC]) { ld4(p, o); }
+template <> __device__ __forceinline__ void ldT4<bf16_t>(const bf16_t* p, float (&o)[VC]) {
+    const uint2 w = *reinterpret_cast<const uint2*>(p);
+    o[0] = bf16_bits_to_f32(w.x & 0xFFFFu); o[1] = bf16_bits_to_f32(w.x >> 16);
+    o[2] = bf16_bits_to_f32(w.y & 0xFFFFu); o[3] = bf16_bits_to_f32(w.y >> 16);
+}
 __device__ __forceinline__ void keep4(const uint8_t* mp, float (&k)[VC]) {
     const uint32_t w = *reinterpret_cast<const uint32_t*>(mp);
 #pragma unroll
@@ -87,52 +119,59 @@ __device__ __forceinline__ void keep4(const uint8_t* mp, float (&k)[VC]) {
 }
 
 // ---- forward, small maps: a = act((z - mean) * rstd) [* keep * 2]; writes mean/rstd [N][C]
-template <typename T>
+template <typename T, int RG>
 __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(const float* __restrict__ z, int ldz, T* __restrict__ a, int lda,
                                                                 float* __restrict__ mean, float* __restrict__ rstd,
-                                                                const uint8_t* __restrict__ mask, int HW, int C, int act) {
+                                                                const uint8_t* __restrict__ mask, int N, int HW, int C, int act,
+                                                                int spb) {
     __shared__ float sm[1][RGN][CW];
+    constexpr int SPP = RGN / RG;
     const int tx = threadIdx.x % CGN, ty = threadIdx.x / CGN;
-    const int c = blockIdx.x * CW + tx * VC, n = blockIdx.y;
-    const float* zp = z + (size_t)n * HW * ldz + c;
-    float v[MAXR][VC];
-    float s[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
+    const int slot = ty / RG, rg = ty % RG;
+    const int c = blockIdx.x * CW + tx * VC;
+    for (int n0 = blockIdx.y * spb; n0 < min(N, (int)(blockIdx.y + 1) * spb); n0 += SPP) {
+        const int n = n0 + slot;
+        const bool live = n < N;
+        const float* zp = z + (size_t)n * HW * ldz + c;
+        float v[MAXR][VC];
+        float s[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int i = 0; i < MAXR; ++i) {
-        const int p = ty + RGN * i;
-        if (p < HW) {
-            ld4(zp + (size_t)p * ldz, v[i]);
+        for (int i = 0; i < MAXR; ++i) {
+            const int p = rg + RG * i;
+            if (live && p < HW) {
+                ld4(zp + (size_t)p * ldz, v[i]);
 #pragma unroll
-            for (int j = 0; j < VC; ++j) s[0][j] += v[i][j];
+                for (int j = 0; j < VC; ++j) s[0][j] += v[i][j];
+            }
         }
-    }
-    combine16<1>(s, sm, tx, ty);
-    float mu[VC], r[VC];
+        combine_seg<1, RG>(s, sm, tx, ty);
+        float mu[VC], r[VC];
 #pragma unroll
-    for (int j = 0; j < VC; ++j) { mu[j] = s[0][j] / HW; s[0][j] = 0.f; }
+        for (int j = 0; j < VC; ++j) { mu[j] = s[0][j] / HW; s[0][j] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < MAXR; ++i)
-        if (ty + RGN * i < HW) {
+        for (int i = 0; i < MAXR; ++i)
+            if (live && rg + RG * i < HW) {
 #pragma unroll
-            for (int j = 0; j < VC; ++j) { const float d = v[i][j] - mu[j]; s[0][j] += d * d; }
+                for (int j = 0; j < VC; ++j) { const float d = v[i][j] - mu[j]; s[0][j] += d * d; }
+            }
+        combine_seg<1, RG>(s, sm, tx, ty);
+#pragma unroll
+        for (int j = 0; j < VC; ++j) r[j] = 1.0f / sqrtf(s[0][j] / HW + IN_EPS);
+        if (live && rg == 0) {
+            st4<float>(mean + (size_t)n * C + c, mu);
+            st4<float>(rstd + (size_t)n * C + c, r);
         }
-    combine16<1>(s, sm, tx, ty);
+        T* ap = a + (size_t)n * HW * lda + c;
 #pragma unroll
-    for (int j = 0; j < VC; ++j) r[j] = 1.0f / sqrtf(s[0][j] / HW + IN_EPS);
-    if (ty == 0) {
-        st4<float>(mean + (size_t)n * C + c, mu);
-        st4<float>(rstd + (size_t)n * C + c, r);
-    }
-    T* ap = a + (size_t)n * HW * lda + c;
+        for (int i = 0; i < MAXR; ++i) {
+            const int p = rg + RG * i;
+            if (!live || p >= HW) continue;
+            float o[VC], k[VC] = {1.f, 1.f, 1.f, 1.f};
+            if (mask) keep4(mask + ((size_t)n * HW + p) * C + c, k);
 #pragma unroll
-    for (int i = 0; i < MAXR; ++i) {
-        const int p = ty + RGN * i;
-        if (p >= HW) continue;
-        float o[VC], k[VC] = {1.f, 1.f, 1.f, 1.f};
-        if (mask) keep4(mask + ((size_t)n * HW + p) * C + c, k);
-#pragma unroll
-        for (int j = 0; j < VC; ++j) o[j] = act_fwd((v[i][j] - mu[j]) * r[j], act) * k[j];
-        st4<T>(ap + (size_t)p * lda, o);
+            for (int j = 0; j < VC; ++j) o[j] = act_fwd((v[i][j] - mu[j]) * r[j], act) * k[j];
+            st4<T>(ap + (size_t)p * lda, o);
+        }
     }
 }
 
@@ -222,6 +261,97 @@ struct InBwdParams {
     float* cdot;                       // [ngroups] += sum dzs (z - bias) = <G_k, W_orig>/sigma_k^2 (atomic), nullable
     int HW, C, act;
 };
+
+// small maps: fused backward, several samples per pass and several passes per workgroup (see combine_seg)
+template <typename T, int RG>
+__global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, int N, int spb, int mixed_groups) {
+    __shared__ float sm[2][RGN][CW];
+    __shared__ float red[CGN * RGN / 64];
+    constexpr int SPP = RGN / RG;
+    const int tx = threadIdx.x % CGN, ty = threadIdx.x / CGN;
+    const int slot = ty / RG, rg = ty % RG;
+    const int c = blockIdx.x * CW + tx * VC;
+    const int HW = q.HW, C = q.C;
+    float b[VC] = {0.f, 0.f, 0.f, 0.f};
+    if (q.bias) ld4(q.bias + c, b);
+    float sb[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
+    float sd = 0.f;
+    const int nb = blockIdx.y * spb;
+    for (int n0 = nb; n0 < min(N, nb + spb); n0 += SPP) {
+        const int n = n0 + slot;
+        const bool live = n < N;
+        const float* zp = q.z + (size_t)n * HW * q.ldz + c;
+        const float* dap = q.da ? q.da + (size_t)n * HW * q.ldda + c : nullptr;
+        const float* da2p = q.da2 ? q.da2 + (size_t)n * HW * q.ldda2 + c : nullptr;
+        const uint8_t* mp = q.mask ? q.mask + (size_t)n * HW * C + c : nullptr;
+        float mu[VC] = {0.f, 0.f, 0.f, 0.f}, r[VC] = {0.f, 0.f, 0.f, 0.f}, dab[VC] = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            ld4(q.mean + (size_t)n * C + c, mu); ld4(q.rstd + (size_t)n * C + c, r);
+            if (q.da_bcast) ld4(q.da_bcast + (size_t)n * C + c, dab);
+        }
+        float zv[MAXR][VC], dn[MAXR][VC];
+        float s[2][VC] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int p = rg + RG * i;
+            if (!live || p >= HW) continue;
+            ld4(zp + (size_t)p * q.ldz, zv[i]);
+            float d[VC] = {dab[0], dab[1], dab[2], dab[3]};
+            if (dap) {
+                float t[VC]; ld4(dap + (size_t)p * q.ldda, t);
+#pragma unroll
+                for (int j = 0; j < VC; ++j) d[j] += t[j];
+            }
+            if (da2p) {
+                float t[VC]; ld4(da2p + (size_t)p * q.ldda2, t);
+#pragma unroll
+                for (int j = 0; j < VC; ++j) d[j] += t[j];
+            }
+            float k[VC] = {1.f, 1.f, 1.f, 1.f};
+            if (mp) keep4(mp + (size_t)p * C, k);
+#pragma unroll
+            for (int j = 0; j < VC; ++j) {
+                const float xh = (zv[i][j] - mu[j]) * r[j];
+                dn[i][j] = d[j] * k[j] * act_grad(xh, q.act);
+                s[0][j] += dn[i][j]; s[1][j] += dn[i][j] * xh;
+            }
+        }
+        combine_seg<2, RG>(s, sm, tx, ty);
+        const float gs = (q.gscale && live) ? q.gscale[n / q.group_n] : 1.f;
+        const float* ztp = (q.zt && live && n >= q.zt_n0) ? q.zt + (size_t)(n - q.zt_n0) * HW * C + c : nullptr;
+        T* op = static_cast<T*>(q.dzs) + (size_t)n * HW * q.lddz + c;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int p = rg + RG * i;
+            if (!live || p >= HW) continue;
+            float t[VC] = {0.f, 0.f, 0.f, 0.f}, o[VC];
+            if (ztp) ld4(ztp + (size_t)p * C, t);
+#pragma unroll
+            for (int j = 0; j < VC; ++j) {
+                const float xh = (zv[i][j] - mu[j]) * r[j];
+                const float dz = r[j] * (dn[i][j] - s[0][j] / HW - xh * (s[1][j] / HW)) + t[j];
+                sb[0][j] += dz; sd += dz * gs * (zv[i][j] - b[j]);
+                o[j] = dz * gs;
+            }
+            st4<T>(op + (size_t)p * q.lddz, o);
+        }
+        if (mixed_groups && q.cdot) {          // tiny batches only: a pass may straddle sample groups
+            if (live && sd != 0.f) atomicAdd(q.cdot + n / q.group_n, sd);
+            sd = 0.f;
+        }
+    }
+    if (q.dbias) {
+        combine16<1>(sb, reinterpret_cast<float(*)[RGN][CW]>(sm), tx, ty);
+        if (ty == 0) {
+#pragma unroll
+            for (int j = 0; j < VC; ++j) atomicAdd(q.dbias + c + j, sb[0][j]);
+        }
+    }
+    if (q.cdot && !mixed_groups) {
+        const float tot = block_sum<CGN * RGN / 64>(sd, red);
+        if (threadIdx.x == 0) atomicAdd(q.cdot + nb / q.group_n, tot);     // all samples of a workgroup share a group
+    }
+}
 
 // dn = act'(xhat) (da + da2 + da_bcast) [*2 keep];  dz = rstd (dn - mean(dn) - xhat mean(dn xhat)) [+ zt]
 // MODE 0: fused small-map kernel (rows in registers); MODE 1: large maps, sums only (ws[n][c][0..1] += sum dn, sum dn xhat);
@@ -377,6 +507,76 @@ __global__ __launch_bounds__(CW * RG) void in_dbl_bwd_kernel(InDblParams q) {
     }
 }
 
+// small maps, vectorised double backward (same math as in_dbl_bwd_kernel)
+template <typename T, int RG>
+__global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, int N, int spb) {
+    __shared__ float sm[5][RGN][CW];
+    __shared__ float red[CGN * RGN / 64];
+    constexpr int SPP = RGN / RG;
+    const int tx = threadIdx.x % CGN, ty = threadIdx.x / CGN;
+    const int slot = ty / RG, rg = ty % RG;
+    const int c = blockIdx.x * CW + tx * VC;
+    const int HW = q.HW, C = q.C;
+    float sd = 0.f;
+    const int nb = blockIdx.y * spb;
+    for (int n0 = nb; n0 < min(N, nb + spb); n0 += SPP) {
+        const int n = n0 + slot;
+        const bool live = n < N;
+        const float* zp = q.z + (size_t)n * HW * q.ldz + c;
+        const float* gp = q.gb_a + (size_t)n * HW * q.ldgb + c;
+        const float* qp = q.qz + (size_t)n * HW * q.ldq + c;
+        const T* gzp = q.gb_zs ? static_cast<const T*>(q.gb_zs) + (size_t)n * HW * q.ldgz + c : nullptr;
+        float mu[VC] = {0.f, 0.f, 0.f, 0.f}, r[VC] = {0.f, 0.f, 0.f, 0.f};
+        if (live) { ld4(q.mean + (size_t)n * C + c, mu); ld4(q.rstd + (size_t)n * C + c, r); }
+        float xh[MAXR][VC], dn[MAXR][VC], qq[MAXR][VC], ag[MAXR][VC];
+        float s[5][VC];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < VC; ++j) s[i][j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int p = rg + RG * i;
+            if (!live || p >= HW) continue;
+            float zv[VC], g[VC];
+            ld4(zp + (size_t)p * q.ldz, zv); ld4(gp + (size_t)p * q.ldgb, g); ld4(qp + (size_t)p * q.ldq, qq[i]);
+            float gz[VC] = {0.f, 0.f, 0.f, 0.f};
+            if (gzp) ldT4<T>(gzp + (size_t)p * q.ldgz, gz);
+#pragma unroll
+            for (int j = 0; j < VC; ++j) {
+                xh[i][j] = (zv[j] - mu[j]) * r[j];
+                ag[i][j] = act_grad(xh[i][j], q.act);
+                dn[i][j] = ag[i][j] * g[j];
+                s[0][j] += dn[i][j]; s[1][j] += dn[i][j] * xh[i][j]; s[2][j] += qq[i][j];
+                s[3][j] += qq[i][j] * xh[i][j]; s[4][j] += qq[i][j] * dn[i][j];
+                sd += gz[j] * qq[i][j];
+            }
+        }
+        combine_seg<5, RG>(s, sm, tx, ty);
+        const float inv = 1.f / HW;
+        T* gap = static_cast<T*>(q.gt_a) + (size_t)n * HW * q.ldga + c;
+        float* ztp = q.zt + (size_t)n * HW * C + c;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int p = rg + RG * i;
+            if (!live || p >= HW) continue;
+            float o[VC], zt[VC];
+#pragma unroll
+            for (int j = 0; j < VC; ++j) {
+                const float m1 = s[0][j] * inv, m2 = s[1][j] * inv, mq = s[2][j] * inv, mqx = s[3][j] * inv, mqd = s[4][j] * inv;
+                o[j] = ag[i][j] * r[j] * (qq[i][j] - mq - xh[i][j] * mqx);
+                zt[j] = r[j] * r[j] * (-xh[i][j] * (mqd - mq * m1 - 3.f * mqx * m2) - m2 * (qq[i][j] - mq) - mqx * (dn[i][j] - m1));
+            }
+            st4<T>(gap + (size_t)p * q.ldga, o);
+            st4<float>(ztp + (size_t)p * C, zt);
+        }
+    }
+    if (q.cdot) {
+        const float tot = block_sum<CGN * RGN / 64>(sd, red);
+        if (threadIdx.x == 0) atomicAdd(q.cdot, tot);
+    }
+}
+
 // ---- layers without a norm (D.c1, G.down1): a = lrelu(z) was fused in the conv epilogue; backward is elementwise
 struct ActBwdParams {
     const float* da; int ldda; const float* da2; int ldda2;      // incoming gradients, fp32
@@ -441,6 +641,17 @@ __global__ void dot_accum_kernel(const T* __restrict__ x, int ldx, const float* 
 
 bool bad_dtype(int dt) { return dt != GCSSL_F32 && dt != GCSSL_BF16; }
 
+// row-group lanes per sample for a small map, and samples per workgroup (a multiple of the samples per pass that keeps
+// >= ~256 workgroups and, when per-group sums are accumulated, never straddles a sample group)
+int small_rg(int HW) { return HW <= 4 ? 1 : (HW <= 16 ? 4 : 16); }
+int small_spb(int N, int C, int rg, int group_n) {
+    const int spp = RGN / rg;
+    int spb = spp;
+    while (spb * 2 <= 64 && (long)(C / CW) * ((N + spb * 2 - 1) / (spb * 2)) >= 256 &&
+           (group_n <= 0 || group_n % (spb * 2) == 0)) spb *= 2;
+    return spb;
+}
+
 }  // namespace
 
 extern "C" {
@@ -453,9 +664,12 @@ int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float
     if (!aligned16(z) || (((uintptr_t)a) & 7)) return GCSSL_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     if (HW <= SMALL_HW && !pool) {
-        dim3 grid(C / CW, N);
-        if (dtype == GCSSL_F32) hipLaunchKernelGGL(in_fwd_small_kernel<float>, grid, dim3(CGN * RGN), 0, st, z, ldz, (float*)a, lda, mean, rstd, mask, HW, C, act);
-        else hipLaunchKernelGGL(in_fwd_small_kernel<bf16_t>, grid, dim3(CGN * RGN), 0, st, z, ldz, (bf16_t*)a, lda, mean, rstd, mask, HW, C, act);
+        const int rg = small_rg(HW), spb = small_spb(N, C, rg, 0);
+        dim3 grid(C / CW, (N + spb - 1) / spb);
+#define FWD_SMALL(T, RG) hipLaunchKernelGGL((in_fwd_small_kernel<T, RG>), grid, dim3(CGN * RGN), 0, st, z, ldz, (T*)a, lda, mean, rstd, mask, N, HW, C, act, spb)
+        if (dtype == GCSSL_F32) { if (rg == 1) FWD_SMALL(float, 1); else if (rg == 4) FWD_SMALL(float, 4); else FWD_SMALL(float, 16); }
+        else { if (rg == 1) FWD_SMALL(bf16_t, 1); else if (rg == 4) FWD_SMALL(bf16_t, 4); else FWD_SMALL(bf16_t, 16); }
+#undef FWD_SMALL
         return gcssl_launch_status();
     }
     dim3 grid(C / CW, N, (HW + SMALL_HW - 1) / SMALL_HW);
@@ -482,9 +696,13 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
                   group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, HW, C, act};
     hipStream_t st = (hipStream_t)stream;
     if (HW <= SMALL_HW) {
-        dim3 grid(C / CW, N);
-        if (dtype == GCSSL_F32) hipLaunchKernelGGL((in_bwd_kernel<float, 0>), grid, dim3(CGN * RGN), 0, st, q, ws);
-        else hipLaunchKernelGGL((in_bwd_kernel<bf16_t, 0>), grid, dim3(CGN * RGN), 0, st, q, ws);
+        const int rg = small_rg(HW), spb = small_spb(N, C, rg, cdot ? q.group_n : 0);
+        const int mixed = (cdot && q.group_n % spb) ? 1 : 0;
+        dim3 grid(C / CW, (N + spb - 1) / spb);
+#define BWD_SMALL(T, RG) hipLaunchKernelGGL((in_bwd_small_kernel<T, RG>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed)
+        if (dtype == GCSSL_F32) { if (rg == 1) BWD_SMALL(float, 1); else if (rg == 4) BWD_SMALL(float, 4); else BWD_SMALL(float, 16); }
+        else { if (rg == 1) BWD_SMALL(bf16_t, 1); else if (rg == 4) BWD_SMALL(bf16_t, 4); else BWD_SMALL(bf16_t, 16); }
+#undef BWD_SMALL
         return gcssl_launch_status();
     }
     dim3 grid(C / CW, N, (HW + SMALL_HW - 1) / SMALL_HW);
@@ -506,6 +724,16 @@ int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, in
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || ldgb < C || ldq < C || ldga < C) return GCSSL_EBADSHAPE;
     InDblParams q{gb_a, ldgb, qz, ldq, gb_zs, ldgz, z, ldz, mean, rstd, gt_a, ldga, zt, cdot, HW, C, act};
+    if (HW <= SMALL_HW && !(ldgb % 4) && !(ldq % 4) && !(ldz % 4) && !(ldga % 4) && (!gb_zs || !(ldgz % 4))) {
+        const int rg = small_rg(HW), spb = small_spb(N, C, rg, 0);
+        dim3 sgrid(C / CW, (N + spb - 1) / spb);
+        hipStream_t st = (hipStream_t)stream;
+#define DBL_SMALL(T, RG) hipLaunchKernelGGL((in_dbl_small_kernel<T, RG>), sgrid, dim3(CGN * RGN), 0, st, q, N, spb)
+        if (dtype == GCSSL_F32) { if (rg == 1) DBL_SMALL(float, 1); else if (rg == 4) DBL_SMALL(float, 4); else DBL_SMALL(float, 16); }
+        else { if (rg == 1) DBL_SMALL(bf16_t, 1); else if (rg == 4) DBL_SMALL(bf16_t, 4); else DBL_SMALL(bf16_t, 16); }
+#undef DBL_SMALL
+        return gcssl_launch_status();
+    }
     dim3 grid(C / CW, N);
     if (dtype == GCSSL_F32) hipLaunchKernelGGL(in_dbl_bwd_kernel<float>, grid, dim3(CW * RG), 0, (hipStream_t)stream, q);
     else hipLaunchKernelGGL(in_dbl_bwd_kernel<bf16_t>, grid, dim3(CW * RG), 0, (hipStream_t)stream, q);
