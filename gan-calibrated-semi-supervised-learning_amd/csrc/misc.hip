@@ -147,19 +147,21 @@ __global__ void c5_wgrad_kernel(const T* __restrict__ x, int ldx, const float* _
 struct SnLayer { const float* w; float* u; float* v; float* t; float* s; int rows, cols; };
 struct SnBatch { SnLayer l[4]; int nl; float* sigma; float* isig; float* u_hist; float* v_hist; int hist_stride_u, hist_stride_v; int slot, nslots; };
 
-// t = W^T u : block = 64 columns x 4 row groups
+// t += W^T u : block = 64 columns x 4 row groups over a 64-row slab (blockIdx.z); t is zeroed by the launcher.
+// Row slabs give every layer >= 8x more workgroups than a column-only split (the 512x4096 layer: 512 instead of 64).
 __global__ __launch_bounds__(256) void sn_wtu_kernel(SnBatch b) {
     const SnLayer L = b.l[blockIdx.y];
     __shared__ float sm[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + tx;
-    if (blockIdx.x * 64 >= L.cols) return;
+    const int r0 = blockIdx.z * 64, r1 = min(L.rows, r0 + 64);
+    if (blockIdx.x * 64 >= L.cols || r0 >= L.rows) return;
     float s = 0.f;
     if (col < L.cols)
-        for (int r = ty; r < L.rows; r += 4) s += L.w[(size_t)r * L.cols + col] * L.u[r];
+        for (int r = r0 + ty; r < r1; r += 4) s += L.w[(size_t)r * L.cols + col] * L.u[r];
     sm[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && col < L.cols) L.t[col] = sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx];
+    if (ty == 0 && col < L.cols) atomicAdd(L.t + col, sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx]);
 }
 
 // s = W (t / max(|t|, eps)); block 0 also publishes v.  One wave per row, 4 rows per block.
@@ -509,7 +511,7 @@ int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dou
     if (!x || !dw) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || ldx < C || (!dout && group_n <= 0)) return GCSSL_EBADSHAPE;
-    int zs = N / 8; if (zs < 1) zs = 1; if (zs > 64) zs = 64;
+    int zs = N / 96; if (zs < 1) zs = 1; if (zs > 16) zs = 16;      // few sample chunks: the result is accumulated atomically
     dim3 grid((C + 255) / 256, 16, zs);
     if (dtype == GCSSL_F32) hipLaunchKernelGGL(c5_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C);
     else hipLaunchKernelGGL(c5_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C);
@@ -537,7 +539,12 @@ int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* c
     b.hist_stride_u = hist_stride_u; b.hist_stride_v = hist_stride_v; b.slot = slot; b.nslots = nslots;
     hipStream_t st = (hipStream_t)stream;
     if (iterate) {
-        hipLaunchKernelGGL(sn_wtu_kernel, dim3((maxc + 63) / 64, nl), dim3(256), 0, st, b);
+        bool contiguous = true;                        // SnState allocates the t scratch of all layers back to back
+        size_t total = cols[0];
+        for (int i = 1; i < nl; ++i) { contiguous = contiguous && (t[i] == t[i - 1] + cols[i - 1]); total += cols[i]; }
+        if (contiguous) hipMemsetAsync(t[0], 0, sizeof(float) * total, st);
+        else for (int i = 0; i < nl; ++i) hipMemsetAsync(t[i], 0, sizeof(float) * cols[i], st);
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3((maxc + 63) / 64, nl, (maxr + 63) / 64), dim3(256), 0, st, b);
         hipLaunchKernelGGL(sn_wv_kernel, dim3((maxr + 3) / 4, nl), dim3(256), 0, st, b);
         hipLaunchKernelGGL(sn_fin_kernel, dim3(nl), dim3(256), 0, st, b);
     } else {

@@ -587,40 +587,61 @@ struct ActBwdParams {
     float* dbias; float* cdot;
     int HW, C;
 };
+// grid: (C/64, sample blocks of `spb`, H*W chunks of `rows_per_chunk`); lanes own 4 channels x strided rows, the bias /
+// spectral-norm partial sums stay in registers across the samples of a workgroup (one set of atomics per workgroup)
 template <typename T>
-__global__ __launch_bounds__(CW * RG) void act_bwd_kernel(ActBwdParams q) {
-    __shared__ float sm[1][RG][CW];
-    __shared__ float red[CW * RG / 64];
-    const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
-    const int c = blockIdx.x * CW + tx, n = blockIdx.y;
+__global__ __launch_bounds__(CGN * RGN) void act_bwd_kernel(ActBwdParams q, int N, int spb, int rows_per_chunk, int mixed_groups) {
+    __shared__ float sm[1][RGN][CW];
+    __shared__ float red[CGN * RGN / 64];
+    const int tx = threadIdx.x % CGN, ty = threadIdx.x / CGN;
+    const int c = blockIdx.x * CW + tx * VC;
     const int HW = q.HW;
-    const T* ap = static_cast<const T*>(q.a) + (size_t)n * HW * q.lda + c;
-    const float* dap = q.da + (size_t)n * HW * q.ldda + c;
-    const float* da2p = q.da2 ? q.da2 + (size_t)n * HW * q.ldda2 + c : nullptr;
-    T* op = static_cast<T*>(q.dzs) + (size_t)n * HW * q.lddz + c;
-    const float gs = q.gscale ? q.gscale[n / q.group_n] : 1.f;
-    const float b = q.bias ? q.bias[c] : 0.f;
-    float sb = 0.f, sd = 0.f;
-    // HW is split over blockIdx.z chunks to keep enough workgroups in flight on big maps
-    const int chunk = (HW + gridDim.z - 1) / gridDim.z;
-    const int p0 = blockIdx.z * chunk, p1 = min(HW, p0 + chunk);
-    for (int p = p0 + ty; p < p1; p += RG) {
-        const float av = Elem<T>::ld(ap + (size_t)p * q.lda);
-        float d = dap[(size_t)p * q.ldda];
-        if (da2p) d += da2p[(size_t)p * q.ldda2];
-        const float dz = av > 0.f ? d : 0.2f * d;
-        const float zv = av > 0.f ? av : av * 5.0f;          // invert LeakyReLU(0.2)
-        sb += dz; sd += dz * gs * (zv - b);
-        Elem<T>::st(op + (size_t)p * q.lddz, dz * gs);
+    float b[VC] = {0.f, 0.f, 0.f, 0.f};
+    if (q.bias) ld4(q.bias + c, b);
+    float sb[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
+    float sd = 0.f;
+    const int p0 = blockIdx.z * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
+    const int nb = blockIdx.y * spb;
+    for (int n = nb; n < min(N, nb + spb); ++n) {
+        const T* ap = static_cast<const T*>(q.a) + (size_t)n * HW * q.lda + c;
+        const float* dap = q.da + (size_t)n * HW * q.ldda + c;
+        const float* da2p = q.da2 ? q.da2 + (size_t)n * HW * q.ldda2 + c : nullptr;
+        T* op = static_cast<T*>(q.dzs) + (size_t)n * HW * q.lddz + c;
+        const float gs = q.gscale ? q.gscale[n / q.group_n] : 1.f;
+        for (int p = p0 + ty; p < p1; p += RGN) {
+            float av[VC], d[VC], o[VC];
+            ldT4<T>(ap + (size_t)p * q.lda, av);
+            ld4(dap + (size_t)p * q.ldda, d);
+            if (da2p) {
+                float t[VC]; ld4(da2p + (size_t)p * q.ldda2, t);
+#pragma unroll
+                for (int j = 0; j < VC; ++j) d[j] += t[j];
+            }
+#pragma unroll
+            for (int j = 0; j < VC; ++j) {
+                const float dz = av[j] > 0.f ? d[j] : 0.2f * d[j];
+                const float zv = av[j] > 0.f ? av[j] : av[j] * 5.0f;          // invert LeakyReLU(0.2)
+                sb[0][j] += dz; sd += dz * gs * (zv - b[j]);
+                o[j] = dz * gs;
+            }
+            st4<T>(op + (size_t)p * q.lddz, o);
+        }
+        if (mixed_groups && q.cdot) {
+            const float tot = block_sum<CGN * RGN / 64>(sd, red);
+            if (threadIdx.x == 0) atomicAdd(q.cdot + n / q.group_n, tot);
+            sd = 0.f;
+        }
     }
     if (q.dbias) {
-        float v[1] = {sb};
-        combine<1>(v, sm, tx, ty);
-        if (ty == 0) atomicAdd(q.dbias + c, v[0]);
+        combine16<1>(sb, sm, tx, ty);
+        if (ty == 0) {
+#pragma unroll
+            for (int j = 0; j < VC; ++j) atomicAdd(q.dbias + c + j, sb[0][j]);
+        }
     }
-    if (q.cdot) {
-        const float tot = block_sum<CW * RG / 64>(sd, red);
-        if (threadIdx.x == 0) atomicAdd(q.cdot + n / q.group_n, tot);
+    if (q.cdot && !mixed_groups) {
+        const float tot = block_sum<CGN * RGN / 64>(sd, red);
+        if (threadIdx.x == 0) atomicAdd(q.cdot + nb / q.group_n, tot);
     }
 }
 
@@ -746,12 +767,19 @@ int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ld
     if (!da || !a || !dzs) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || HW <= 0 || C <= 0 || C % CW || lda < C || lddz < C || ldda < C) return GCSSL_EBADSHAPE;
+    if (lda % 4 || lddz % 4 || ldda % 4 || (da2 && ldda2 % 4)) return GCSSL_EBADSHAPE;
     if ((gscale || cdot) && group_n <= 0) return GCSSL_EBADSHAPE;
     ActBwdParams q{da, ldda, da2, ldda2, a, lda, gscale, group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, HW, C};
-    int zsplit = HW / 64; if (zsplit < 1) zsplit = 1; if (zsplit > 16) zsplit = 16;
-    dim3 grid(C / CW, N, zsplit);
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, grid, dim3(CW * RG), 0, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, grid, dim3(CW * RG), 0, (hipStream_t)stream, q);
+    // 64-row chunks of H*W x blocks of samples; grow the sample block while >= ~512 workgroups remain
+    int rows = HW < 64 ? HW : 64;
+    const int zc = (HW + rows - 1) / rows;
+    int spb = 1;
+    while (spb * 2 <= 32 && (long)(C / CW) * zc * ((N + spb * 2 - 1) / (spb * 2)) >= 512 &&
+           (!cdot || q.group_n % (spb * 2) == 0)) spb *= 2;
+    const int mixed = (cdot && q.group_n % spb) ? 1 : 0;
+    dim3 grid(C / CW, (N + spb - 1) / spb, zc);
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, grid, dim3(CGN * RGN), 0, (hipStream_t)stream, q, N, spb, rows, mixed);
+    else hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, grid, dim3(CGN * RGN), 0, (hipStream_t)stream, q, N, spb, rows, mixed);
     return gcssl_launch_status();
 }
 

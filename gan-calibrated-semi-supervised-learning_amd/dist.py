@@ -27,10 +27,13 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # GCSSL_DIST_BACKEND=gloo lets several ranks rehearse the DP path on ONE GPU (RCCL refuses duplicate devices)
+            backend = os.environ.get("GCSSL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if os.environ.get("GCSSL_SINGLE_DEVICE"):        # rehearsal mode: every rank drives cuda:0
+        local = 0
     return rank, world, local
 
 

@@ -153,7 +153,11 @@ class SnState:
         self.rows = [w.shape[0] for w in ws]
         self.cols = [w[0].numel() for w in ws]
         self.ws, self.us, self.vs = ws, us, vs
-        self.t = [torch.empty(c, device=device) for c in self.cols]
+        tbuf = torch.empty(sum(self.cols), device=device)          # contiguous: zeroed with one memset per iteration
+        self.t, off = [], 0
+        for c in self.cols:
+            self.t.append(tbuf[off:off + c]); off += c
+        self._tbuf = tbuf
         self.s = [torch.empty(r, device=device) for r in self.rows]
         self.nslots = nslots
         self.su, self.sv = max(self.rows), max(self.cols)
