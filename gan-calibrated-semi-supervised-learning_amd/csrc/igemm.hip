@@ -753,6 +753,21 @@ void launch_dma(const ConvParams& p, dim3 grid, bool smallk, hipStream_t st) {
     }
 }
 
+// several layers per launch (blockIdx.y = layer): the critic is re-packed after every optimiser step
+struct PrepLayer { const float* w; void* wf; void* wt; int Cout, Cin, CinP; };
+struct PrepBatch { PrepLayer l[8]; };
+template <typename T>
+__global__ void prep_weight_batch_kernel(PrepBatch b) {
+    const PrepLayer L = b.l[blockIdx.y];
+    const size_t total = (size_t)L.Cout * 16 * L.CinP;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ci = idx % L.CinP, tap = (idx / L.CinP) % 16, co = idx / ((size_t)L.CinP * 16);
+        const float val = ci < L.Cin ? L.w[((size_t)co * L.Cin + ci) * 16 + tap] : 0.f;
+        if (L.wf) Elem<T>::st(static_cast<T*>(L.wf) + idx, val);
+        if (L.wt) Elem<T>::st(static_cast<T*>(L.wt) + ((size_t)ci * 16 + tap) * L.Cout + co, val);
+    }
+}
+
 template <typename T, int BM, int BN>
 int launch_fwd(const ConvParams& p, hipStream_t st) {
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
@@ -896,7 +911,8 @@ int gcssl_conv4x4s2_wgrad_splits(int N, int Hi, int Wi, int Cin, int Cout) {
     if (!bn) return GCSSL_EBADSHAPE;
     const long tiles = (long)(Cout / bm) * 16 * (Cin / bn) / (Cin == 8 ? 16 : 1);
     const int nkt = (N * (Hi / 2) * (Wi / 2) + 63) / 64;       // K granules of 64 output pixels (dtype independent)
-    long want = (512 + tiles - 1) / tiles;                 // ~2 workgroups per CU
+    static const long target = [] { const char* e = getenv("GCSSL_WGRAD_WGS"); return e ? atol(e) : 512L; }();
+    long want = (target + tiles - 1) / tiles;              // ~2 workgroups per CU
     if (want > 128) want = 128;                            // padded first layers have a single tile: bound the slab count
     if (want < 1) want = 1;
     if (want > nkt) want = nkt;
@@ -947,6 +963,27 @@ int gcssl_wgrad_reduce(const float* slab, int nsplit, float* dw, int Cout, int C
     if (accumulate == 2) { zg = (nsplit + 15) / 16; if (zg > 16) zg = 16; }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + 63) / 64), (unsigned)Cout, (unsigned)zg), dim3(256), 0,
                        (hipStream_t)stream, slab, nsplit, dw, Cout, Cin, Cin_real, coef, cscale, u, ustride, v, vstride, nrank, accumulate);
+    return gcssl_launch_status();
+}
+
+int gcssl_prep_conv_weights(int dtype, int nl, const float* const* w, void* const* wf, void* const* wt, const int* Cout,
+                            const int* Cin, const int* CinP, void* stream) {
+    if (!w || !wf || !wt || !Cout || !Cin || !CinP) return GCSSL_ENULL;
+    if (nl < 1 || nl > 8) return GCSSL_EBADSHAPE;
+    PrepBatch b{};
+    size_t mx = 0;
+    for (int i = 0; i < nl; ++i) {
+        if (!w[i] || (!wf[i] && !wt[i])) return GCSSL_ENULL;
+        if (Cout[i] <= 0 || Cin[i] <= 0 || CinP[i] < Cin[i]) return GCSSL_EBADSHAPE;
+        b.l[i] = PrepLayer{w[i], wf[i], wt[i], Cout[i], Cin[i], CinP[i]};
+        const size_t t = (size_t)Cout[i] * 16 * CinP[i];
+        if (t > mx) mx = t;
+    }
+    unsigned gx = (unsigned)((mx + 255) / 256); if (gx > 1024) gx = 1024;
+    dim3 grid(gx, nl);
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(prep_weight_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, b);
+    else if (dtype == GCSSL_BF16) hipLaunchKernelGGL(prep_weight_batch_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, b);
+    else return GCSSL_EBADDTYPE;
     return gcssl_launch_status();
 }
 

@@ -112,32 +112,36 @@ __global__ void c5_dgrad_kernel(const float* __restrict__ dout, float g0, float 
     Elem<T>::st(dx + pix * lddx + c, s);
 }
 
-// dw[c][tap] += sum_{n,oy,ox} dout(n,oy,ox) x[n,oy-1+ky,ox-1+kx,c]   (atomic over blockIdx.z sample chunks)
+// dw[c][tap] += sum_{n,oy,ox} dout(n,oy,ox) x[n,oy-1+ky,ox-1+kx,c]
+// grid (C/64, 16 taps, sample chunks); block = 64 channels x 4 sample lanes, independent loads (no early-outs inside the
+// sample loop so they pipeline), LDS combine, one atomic per (channel, tap, chunk).
 template <typename T>
-__global__ void c5_wgrad_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ dout, float g0, float g1,
-                                float g2, int group_n, float* __restrict__ dw, int N, int Hi, int Wi, int C) {
+__global__ __launch_bounds__(256) void c5_wgrad_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ dout, float g0, float g1,
+                                float g2, int group_n, float* __restrict__ dw, int N, int Hi, int Wi, int C, int per) {
+    __shared__ float sm[4][64];
     const int Ho = Hi - 1, Wo = Wi - 1;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, tap = blockIdx.y;
-    if (c >= C) return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx, tap = blockIdx.y;
     const int ky = tap >> 2, kx = tap & 3;
-    const int per = (N + gridDim.z - 1) / gridDim.z;
     const int nb = blockIdx.z * per, ne = min(N, nb + per);
+    // valid output window for this tap: iy = oy-1+ky in [0,Hi)
+    const int oy0 = max(0, 1 - ky), oy1 = min(Ho, Hi + 1 - ky), ox0 = max(0, 1 - kx), ox1 = min(Wo, Wi + 1 - kx);
     float s = 0.f;
-    for (int n = nb; n < ne; ++n) {
-        float gconst = 0.f;
-        if (!dout) { const int g = n / group_n; gconst = g == 0 ? g0 : (g == 1 ? g1 : g2); if (gconst == 0.f) continue; }
-        for (int oy = 0; oy < Ho; ++oy) {
-            const int iy = oy - 1 + ky;
-            if ((unsigned)iy >= (unsigned)Hi) continue;
-            for (int ox = 0; ox < Wo; ++ox) {
-                const int ix = ox - 1 + kx;
-                if ((unsigned)ix >= (unsigned)Wi) continue;
-                const float d = dout ? dout[((size_t)n * Ho + oy) * Wo + ox] : gconst;
-                s += d * Elem<T>::ld(x + ((size_t)(n * Hi + iy) * Wi + ix) * ldx + c);
-            }
+    if (c < C) {
+#pragma unroll 4
+        for (int n = nb + ty; n < ne; n += 4) {
+            float gconst = 0.f;
+            if (!dout) { const int g = n / group_n; gconst = g == 0 ? g0 : (g == 1 ? g1 : g2); }
+            for (int oy = oy0; oy < oy1; ++oy)
+                for (int ox = ox0; ox < ox1; ++ox) {
+                    const float d = dout ? dout[((size_t)n * Ho + oy) * Wo + ox] : gconst;
+                    s += d * Elem<T>::ld(x + ((size_t)(n * Hi + oy - 1 + ky) * Wi + ox - 1 + kx) * ldx + c);
+                }
         }
     }
-    atomicAdd(dw + (size_t)c * 16 + tap, s);
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) atomicAdd(dw + (size_t)c * 16 + tap, sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx]);
 }
 
 // =========================================================================================
@@ -511,10 +515,11 @@ int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dou
     if (!x || !dw) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || ldx < C || (!dout && group_n <= 0)) return GCSSL_EBADSHAPE;
-    int zs = N / 96; if (zs < 1) zs = 1; if (zs > 16) zs = 16;      // few sample chunks: the result is accumulated atomically
-    dim3 grid((C + 255) / 256, 16, zs);
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(c5_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C);
-    else hipLaunchKernelGGL(c5_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C);
+    int zs = N / 48; if (zs < 1) zs = 1; if (zs > 16) zs = 16;
+    const int per = (N + zs - 1) / zs;
+    dim3 grid((C + 63) / 64, 16, zs);
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(c5_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C, per);
+    else hipLaunchKernelGGL(c5_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C, per);
     return gcssl_launch_status();
 }
 

@@ -105,6 +105,7 @@ class StepEngine:
         self._d_dirty = True
         self._g_dirty = True
         self.mask_counter = torch.zeros(1, device=dev, dtype=torch.float64)
+        self._prep_d_batch = self._prep_g_batch = None
         self.probe = None          # {label: {"events": [(start, stop)...], "flops": f}} when profiling is enabled
 
     # ------------------------------------------------------------------------------------------ in-situ kernel timing
@@ -245,21 +246,25 @@ class StepEngine:
     def _prep_d(self):
         if not self._d_dirty:
             return
-        for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX)):
-            ops.prep_conv_weight(self.D.views[f"model.{i}.weight_orig"], self.d_wf[l], self.d_wt[l], cout, cin,
-                                 _pad8(cin), self.code)
+        if self._prep_d_batch is None:
+            self._prep_d_batch = ops.PrepBatch(
+                [(self.D.views[f"model.{i}.weight_orig"], self.d_wf[l], self.d_wt[l], cout, cin, _pad8(cin))
+                 for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX))], self.code)
+        self._prep_d_batch.run()
         ops.prep_c5_weight(self.D.views["model.11.weight"], self.d_w5p)
         self._d_dirty = False
 
     def _prep_g(self):
         if not self._g_dirty:
             return
-        for k, (cin, cout) in enumerate(G_DOWN):
-            ops.prep_conv_weight(self.G.views[f"down{k + 1}.model.0.weight"], self.gd_wf[k], self.gd_wt[k], cout, cin,
-                                 _pad8(cin), self.code)
-        for k, (cint, coutt) in enumerate(G_UP):
-            key = f"up{k + 1}.model.0.weight" if k < 3 else "up4.0.weight"
-            ops.prep_conv_weight(self.G.views[key], self.gu_wf[k], self.gu_wt[k], cint, coutt, coutt, self.code)
+        if self._prep_g_batch is None:
+            layers = [(self.G.views[f"down{k + 1}.model.0.weight"], self.gd_wf[k], self.gd_wt[k], cout, cin, _pad8(cin))
+                      for k, (cin, cout) in enumerate(G_DOWN)]
+            for k, (cint, coutt) in enumerate(G_UP):
+                key = f"up{k + 1}.model.0.weight" if k < 3 else "up4.0.weight"
+                layers.append((self.G.views[key], self.gu_wf[k], self.gu_wt[k], cint, coutt, coutt))
+            self._prep_g_batch = ops.PrepBatch(layers, self.code)
+        self._prep_g_batch.run()
         self._g_dirty = False
 
     # ------------------------------------------------------------------------------------------ critic forward

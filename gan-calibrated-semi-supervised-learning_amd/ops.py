@@ -45,6 +45,21 @@ def prep_conv_weight(w, wf, wt, cout, cin, cinp, dt):
     call("gcssl_prep_conv_weight", dt, w, wf, wt, cout, cin, cinp)
 
 
+class PrepBatch:
+    """Argument block for gcssl_prep_conv_weights: layers = [(w, wf, wt, cout, cin, cinp), ...] (<= 8)."""
+
+    def __init__(self, layers, dt):
+        self.n, self.dt = len(layers), dt
+        self._keep = layers
+        self._w = _lib.ptr_array([l[0] for l in layers])
+        self._wf = _lib.ptr_array([l[1] for l in layers])
+        self._wt = _lib.ptr_array([l[2] for l in layers])
+        self._co, self._ci, self._cp = (_lib.int_array([l[k] for l in layers]) for k in (3, 4, 5))
+
+    def run(self):
+        call("gcssl_prep_conv_weights", self.dt, self.n, self._w, self._wf, self._wt, self._co, self._ci, self._cp)
+
+
 def prep_c5_weight(w, wp):
     call("gcssl_prep_c5_weight", w, wp, wp.shape[1])
 

@@ -45,6 +45,9 @@ int gcssl_unpack_grad(const float* g, float* ga, float* gb, int B, int S, void* 
  * wf [Cout][16][CinP] (forward GEMM) and wt [CinP][16][Cout] (dgrad GEMM); channels Cin..CinP-1 are zero.
  * For a ConvTranspose2d weight [CinT][CoutT][4][4] pass Cout=CinT, Cin=CoutT.  Either output may be NULL. */
 int gcssl_prep_conv_weight(int dtype, const float* w, void* wf, void* wt, int Cout, int Cin, int CinP, void* stream);
+/* the same for nl <= 8 layers in ONE launch (host arrays of device pointers / sizes). */
+int gcssl_prep_conv_weights(int dtype, int nl, const float* const* w, void* const* wf, void* const* wt, const int* Cout,
+                            const int* Cin, const int* CinP, void* stream);
 /* critic head weight [1][C][4][4] -> fp32 [16][C]. */
 int gcssl_prep_c5_weight(const float* w, float* wp, int C, void* stream);
 
