@@ -87,7 +87,7 @@ def main():
     d = {k: T(v) for k, v in synth.discriminator_state(42).items()}
     averager = dist_mod.GradAverager() if world > 1 else None
     eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype=args.dtype, device=dev, seed=42 + rank,
-                            allreduce=averager)
+                            allreduce=averager, keep_clipped_grads=False)
     data, _ = synthetic_inputs(synth, 42 + rank, B, S, c, dev)          # resident in HBM before anything is timed
     refine = lambda delta, k: data["refined"][k]
     call = (data["pred"], data["gt"], data["delta_true"], data["pred_box"], refine)

@@ -678,30 +678,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     // blockIdx.z owns a group of splits (accumulate == 2: dw was zeroed by the caller, groups add atomically)
     const int per = (nsplit + gridDim.z - 1) / gridDim.z;
     const int k0 = blockIdx.z * per, k1 = min(nsplit, k0 + per);
-    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-        const int tap = e >> 6, cil = e & 63;
-        if (cil >= cw) continue;
-        const size_t idx = ((size_t)co * 16 + tap) * Cin + ci0 + cil;
-        float s = 0.f;
-        for (int k = k0; k < k1; ++k) s += slab[(size_t)k * total + idx];
-        tile[tap][cil] = s;
+    {   // 16-byte loads: thread -> (tap, 4 consecutive ci); 256 threads cover the 16 x 64 tile once
+        const int tap = threadIdx.x >> 4, cil = (threadIdx.x & 15) * 4;
+        if (cil < cw) {
+            const size_t idx = ((size_t)co * 16 + tap) * Cin + ci0 + cil;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int k = k0; k < k1; ++k) {
+                const float4 t = *reinterpret_cast<const float4*>(slab + (size_t)k * total + idx);
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            tile[tap][cil] = s.x; tile[tap][cil + 1] = s.y; tile[tap][cil + 2] = s.z; tile[tap][cil + 3] = s.w;
+        }
     }
     __syncthreads();
     float uk[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         uk[k] = (k < nrank && blockIdx.z == 0) ? coef[k] * (cscale ? cscale[k] : 1.f) * u[(size_t)k * ustride + co] : 0.f;
-    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-        const int cil = e >> 4, tap = e & 15;
-        const int ci = ci0 + cil;
-        if (cil >= cw || ci >= Cin_real) continue;
-        float s = tile[tap][cil];
+    // output: thread -> (ci, 4 consecutive taps): the 64 ci x 16 taps of one co are 4 KB contiguous in dw
+    const int cil = threadIdx.x >> 2, tp = (threadIdx.x & 3) * 4;
+    const int ci = ci0 + cil;
+    if (cil < cw && ci < Cin_real) {
+        float o[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < nrank) s -= uk[k] * v[(size_t)k * vstride + ci * 16 + tap];
-        float* o = dw + ((size_t)co * Cin_real + ci) * 16 + tap;
-        if (accumulate == 2) atomicAdd(o, s);
-        else *o = accumulate ? (*o + s) : s;
+        for (int j = 0; j < 4; ++j) {
+            float sv = tile[tp + j][cil];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nrank) sv -= uk[k] * v[(size_t)k * vstride + ci * 16 + tp + j];
+            o[j] = sv;
+        }
+        float* op = dw + ((size_t)co * Cin_real + ci) * 16 + tp;
+        if (accumulate == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(op + j, o[j]);
+        } else if (accumulate) {
+            float4 t = *reinterpret_cast<float4*>(op);
+            *reinterpret_cast<float4*>(op) = make_float4(t.x + o[0], t.y + o[1], t.z + o[2], t.w + o[3]);
+        } else {
+            *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 

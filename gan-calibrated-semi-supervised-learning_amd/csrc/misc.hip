@@ -255,8 +255,15 @@ __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __re
 // =========================================================================================
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* out) {
     __shared__ double red[4];
-    double s = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const double v = g[i]; s += v * v; }
+    // 16-byte loads, fp32 per-thread partials (a thread sees <= ~50 elements), fp64 from the wave reduction on
+    float sf = 0.f;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        sf += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; sf += v * v; }
+    double s = (double)sf;
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();

@@ -82,7 +82,7 @@ class StepEngine:
     def __init__(self, sd_g: Dict[str, torch.Tensor], sd_d: Dict[str, torch.Tensor], batch: int, size: int,
                  n_critic: int = 2, dtype="bf16", device="cuda", lr: float = 2e-4, betas=(0.5, 0.999),
                  delta_scale: float = 0.3, lambda_gp: float = 1.0, lambda_iou: float = 1.0, seed: int = 42,
-                 allreduce: Optional[Callable[[torch.Tensor], None]] = None):
+                 allreduce: Optional[Callable[[torch.Tensor], None]] = None, keep_clipped_grads: bool = True):
         if size < 32 or size & (size - 1):
             raise ValueError("img size must be a power of two >= 32 (the reference raises below 32: SURVEY §0)")
         self.B, self.S, self.c = batch, size, n_critic
@@ -93,6 +93,7 @@ class StepEngine:
         self.delta_scale, self.lambda_gp, self.lambda_iou = delta_scale, lambda_gp, lambda_iou
         self.seed = seed
         self.allreduce = allreduce
+        self.keep_clipped_grads = keep_clipped_grads     # write g*clip_coef back like clip_grad_norm_ does (not needed to step)
         _lib.lib()                                                  # fail loudly now if the HIP library is missing
         dev = self.dev
         f32 = dict(device=dev, dtype=torch.float32)
@@ -349,7 +350,7 @@ class StepEngine:
         if self.allreduce is not None:
             self.allreduce(self.D.g)
         ops.clip_adam(self.D.p, self.D.g, self.D.m, self.D.v, self.D.state, self.lr, self.betas[0], self.betas[1],
-                      write_clipped=True)
+                      write_clipped=self.keep_clipped_grads)
         self._d_dirty = True
 
     def d_compute(self, pred, gt, refine_fn, k: int, alpha: Optional[torch.Tensor], masks) -> None:
@@ -440,7 +441,7 @@ class StepEngine:
         if self.allreduce is not None:
             self.allreduce(self.G.g)
         ops.clip_adam(self.G.p, self.G.g, self.G.m, self.G.v, self.G.state, self.lr, self.betas[0], self.betas[1],
-                      write_clipped=True)                                               # :368-369
+                      write_clipped=self.keep_clipped_grads)                            # :368-369
         self._g_dirty = True
 
     def g_compute(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
