@@ -87,7 +87,8 @@ def main():
     d = {k: T(v) for k, v in synth.discriminator_state(42).items()}
     averager = dist_mod.GradAverager() if world > 1 else None
     eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype=args.dtype, device=dev, seed=42 + rank,
-                            allreduce=averager, keep_clipped_grads=False)
+                            allreduce=averager, keep_clipped_grads=False,
+                            overlap=int(os.environ.get("GCSSL_OVERLAP", "0")))
     data, _ = synthetic_inputs(synth, 42 + rank, B, S, c, dev)          # resident in HBM before anything is timed
     refine = lambda delta, k: data["refined"][k]
     call = (data["pred"], data["gt"], data["delta_true"], data["pred_box"], refine)
@@ -143,8 +144,14 @@ def main():
     conv_flops = sum(n * f for (n, _, f) in prof.values()) / args.probe_steps
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     ach = fl_dom / (ms_dom * 1e-3) / 1e12
+    # HBM bytes per launch of the dominant kernel: from the committed rocprofv3 --pmc passes (FETCH_SIZE x2-corrected +
+    # WRITE_SIZE, profiles/round1_pmc_G_up4_fwd.json) when this run is the configuration they were taken on, else null
+    traffic = None
+    pmc = ROOT / "profiles" / "round1_pmc_G_up4_fwd.json"
+    if dom == "G.up4.fwd" and (B, S, args.dtype) == (256, 32, "bf16") and pmc.exists():
+        traffic = json.loads(pmc.read_text())["hbm_bytes_per_launch"]
     roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                    traffic=None, launches=n_dom, avg_us=round(ms_dom * 1e3, 2),
+                    traffic=traffic, launches=n_dom, avg_us=round(ms_dom * 1e3, 2),
                     all_convs=dict(tflops=round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), ms_per_iter=round(conv_ms, 3),
                                    frac=round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4)))
     flop_iter = ((12 * c + 1) * F_D[S] + (c + 3) * F_G[S]) * B * world if S in F_D else None

@@ -667,17 +667,17 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
 //   dw[co][ci][tap] (+)= sum_s slab[s][co][tap][ci]  - sum_k coef[k]*cscale[k] u_k[co] v_k[ci*16+tap]
 // One workgroup = one co x 64 ci x 16 taps: slab reads are coalesced along ci, the [tap][ci] -> [ci][tap] transpose
 // goes through LDS, and the 4-KB output chunk dw[co][ci0..ci0+63][0..15] is written contiguously.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, float* __restrict__ dw,
+__device__ __forceinline__ void wgrad_reduce_body(float (*tile)[65], int co, int cx, int zi, int zn,
+                                    const float* __restrict__ slab, int nsplit, float* __restrict__ dw,
                                     int Cout, int Cin, int Cin_real, const float* coef, const float* cscale,
                                     const float* u, int ustride, const float* v, int vstride, int nrank,
                                     int accumulate) {
-    __shared__ float tile[16][65];
-    const int co = blockIdx.y, ci0 = blockIdx.x * 64;
+    const int ci0 = cx * 64;
     const int cw = min(64, Cin - ci0);                       // channels in this chunk (8 for the padded first layer)
     const size_t total = (size_t)Cout * 16 * Cin;
-    // blockIdx.z owns a group of splits (accumulate == 2: dw was zeroed by the caller, groups add atomically)
-    const int per = (nsplit + gridDim.z - 1) / gridDim.z;
-    const int k0 = blockIdx.z * per, k1 = min(nsplit, k0 + per);
+    // slab group zi of zn owns a group of splits (accumulate == 2: dw was zeroed by the caller, groups add atomically)
+    const int per = (nsplit + zn - 1) / zn;
+    const int k0 = zi * per, k1 = min(nsplit, k0 + per);
     {   // 16-byte loads: thread -> (tap, 4 consecutive ci); 256 threads cover the 16 x 64 tile once
         const int tap = threadIdx.x >> 4, cil = (threadIdx.x & 15) * 4;
         if (cil < cw) {
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     float uk[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        uk[k] = (k < nrank && blockIdx.z == 0) ? coef[k] * (cscale ? cscale[k] : 1.f) * u[(size_t)k * ustride + co] : 0.f;
+        uk[k] = (k < nrank && zi == 0) ? coef[k] * (cscale ? cscale[k] : 1.f) * u[(size_t)k * ustride + co] : 0.f;
     // output: thread -> (ci, 4 consecutive taps): the 64 ci x 16 taps of one co are 4 KB contiguous in dw
     const int cil = threadIdx.x >> 2, tp = (threadIdx.x & 3) * 4;
     const int ci = ci0 + cil;
@@ -720,6 +720,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, float* __restrict__ dw,
+                                    int Cout, int Cin, int Cin_real, const float* coef, const float* cscale,
+                                    const float* u, int ustride, const float* v, int vstride, int nrank,
+                                    int accumulate) {
+    __shared__ float tile[16][65];
+    wgrad_reduce_body(tile, blockIdx.y, blockIdx.x, blockIdx.z, gridDim.z, slab, nsplit, dw, Cout, Cin, Cin_real, coef, cscale,
+                      u, ustride, v, vstride, nrank, accumulate);
+}
+
+// up to 8 layers in one launch: the reductions of a whole backward pass are independent of each other and of the
+// dgrad chain, and the small ones (first layers) ride along with the big ones instead of paying a launch each
+struct RedLayer { const float* slab; float* dw; const float* coef; const float* u; const float* v;
+                  int nsplit, Cout, Cin, Cin_real, nrank, zg, blk0; };
+struct RedBatch { RedLayer l[8]; int nl, ustride, vstride, accumulate; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedBatch b) {
+    __shared__ float tile[16][65];
+    int li = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < b.nl && (int)blockIdx.x >= b.l[i].blk0) li = i;
+    const RedLayer& L = b.l[li];
+    const int local = blockIdx.x - L.blk0, nch = (L.Cin + 63) / 64;
+    const int cx = local % nch, co = (local / nch) % L.Cout, zi = local / (nch * L.Cout);
+    wgrad_reduce_body(tile, co, cx, zi, L.zg, L.slab, L.nsplit, L.dw, L.Cout, L.Cin, L.Cin_real, L.coef, nullptr, L.u, b.ustride,
+                      L.v, b.vstride, L.nrank, b.accumulate);
 }
 
 // fp32 PyTorch-layout weight [Cout][Cin][4][4] -> packed operand layouts in T
@@ -980,6 +1007,29 @@ int gcssl_wgrad_reduce(const float* slab, int nsplit, float* dw, int Cout, int C
     if (accumulate == 2) { zg = (nsplit + 15) / 16; if (zg > 16) zg = 16; }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + 63) / 64), (unsigned)Cout, (unsigned)zg), dim3(256), 0,
                        (hipStream_t)stream, slab, nsplit, dw, Cout, Cin, Cin_real, coef, cscale, u, ustride, v, vstride, nrank, accumulate);
+    return gcssl_launch_status();
+}
+
+int gcssl_wgrad_reduce_batch(int nl, const float* const* slab, const int* nsplit, float* const* dw, const int* Cout,
+                             const int* Cin, const int* Cin_real, const float* const* coef, const float* const* u,
+                             const float* const* v, int ustride, int vstride, int nrank, int accumulate, void* stream) {
+    if (!slab || !nsplit || !dw || !Cout || !Cin || !Cin_real) return GCSSL_ENULL;
+    if (nl < 1 || nl > 8 || nrank < 0 || nrank > 4 || accumulate < 0 || accumulate > 2) return GCSSL_EBADSHAPE;
+    if (nrank > 0 && (!coef || !u || !v)) return GCSSL_ENULL;
+    RedBatch b{};
+    int blk = 0;
+    for (int i = 0; i < nl; ++i) {
+        if (!slab[i] || !dw[i] || (nrank > 0 && (!coef[i] || !u[i] || !v[i]))) return GCSSL_ENULL;
+        if (nsplit[i] <= 0 || Cout[i] <= 0 || Cin[i] <= 0 || Cin_real[i] <= 0 || Cin_real[i] > Cin[i]) return GCSSL_EBADSHAPE;
+        if (nrank > 0 && (ustride < Cout[i] || vstride < Cin_real[i] * 16)) return GCSSL_EBADSHAPE;
+        int zg = 1;
+        if (accumulate == 2) { zg = (nsplit[i] + 15) / 16; if (zg > 16) zg = 16; }
+        b.l[i] = RedLayer{slab[i], dw[i], nrank ? coef[i] : nullptr, nrank ? u[i] : nullptr, nrank ? v[i] : nullptr,
+                          nsplit[i], Cout[i], Cin[i], Cin_real[i], nrank, zg, blk};
+        blk += ((Cin[i] + 63) / 64) * Cout[i] * zg;
+    }
+    b.nl = nl; b.ustride = ustride; b.vstride = vstride; b.accumulate = accumulate;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, b);
     return gcssl_launch_status();
 }
 

@@ -168,41 +168,61 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(SnBatch b) {
     if (ty == 0 && col < L.cols) atomicAdd(L.t + col, sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx]);
 }
 
-// s = W (t / max(|t|, eps)); block 0 also publishes v.  One wave per row, 4 rows per block.
+// Blocks-finished counters of sn_wv_kernel, one per layer slot; self-resetting.  One power iteration may be in flight
+// per process at a time (the engine issues them on one stream).
+__device__ unsigned g_sn_done[4];
+
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// s = W (t / max(|t|, eps)): one row per block, the four waves split the columns (16-byte loads); row 0 also publishes
+// v.  The last block of a layer to finish then closes the iteration: u = s / max(|s|, eps), sigma = u . s, and t is
+// zeroed again for the next call (every block of the layer has consumed it by then).
 __global__ __launch_bounds__(256) void sn_wv_kernel(SnBatch b) {
     const SnLayer L = b.l[blockIdx.y];
     __shared__ float red[4];
-    if ((int)blockIdx.x * 4 >= L.rows) return;
+    __shared__ int last;
+    const int row = blockIdx.x;
+    if (row >= L.rows) return;
+    const int c4 = (L.cols & 3) ? 0 : L.cols >> 2;          // vector part (all of it for the critic's shapes)
+    const float4* t4 = reinterpret_cast<const float4*>(L.t);
+    const float4* w4 = reinterpret_cast<const float4*>(L.w + (size_t)row * L.cols);
     float q = 0.f;
-    for (int c = threadIdx.x; c < L.cols; c += 256) { const float t = L.t[c]; q += t * t; }
-    const float nt = sqrtf(block_sum<4>(q, red));
-    const float inv = 1.f / fmaxf(nt, 1e-12f);
-    if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < c4; c += 256) { const float4 t = t4[c]; q += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w; }
+    for (int c = c4 * 4 + threadIdx.x; c < L.cols; c += 256) { const float t = L.t[c]; q += t * t; }
+    const float inv = 1.f / fmaxf(sqrtf(block_sum<4>(q, red)), 1e-12f);
+    if (row == 0) {
         float* vh = b.v_hist + ((size_t)blockIdx.y * b.nslots + b.slot) * b.hist_stride_v;
         for (int c = threadIdx.x; c < L.cols; c += 256) { const float vv = L.t[c] * inv; L.v[c] = vv; vh[c] = vv; }
     }
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= L.rows) return;
     float s = 0.f;
-    for (int c = lane; c < L.cols; c += 64) s += L.w[(size_t)row * L.cols + c] * (L.t[c] * inv);
-    s = wave_sum(s);
-    if (lane == 0) L.s[row] = s;
-}
-
-// u = s / max(|s|, eps); sigma = u . s
-__global__ __launch_bounds__(256) void sn_fin_kernel(SnBatch b) {
-    const SnLayer L = b.l[blockIdx.x];
-    __shared__ float red[4];
-    float q = 0.f;
-    for (int r = threadIdx.x; r < L.rows; r += 256) { const float s = L.s[r]; q += s * s; }
-    const float ss = block_sum<4>(q, red);
-    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
-    float* uh = b.u_hist + ((size_t)blockIdx.x * b.nslots + b.slot) * b.hist_stride_u;
-    for (int r = threadIdx.x; r < L.rows; r += 256) { const float uu = L.s[r] * inv; L.u[r] = uu; uh[r] = uu; }
+    for (int c = threadIdx.x; c < c4; c += 256) {
+        const float4 t = t4[c], w = w4[c];
+        s += w.x * (t.x * inv) + w.y * (t.y * inv) + w.z * (t.z * inv) + w.w * (t.w * inv);
+    }
+    for (int c = c4 * 4 + threadIdx.x; c < L.cols; c += 256) s += L.w[(size_t)row * L.cols + c] * (L.t[c] * inv);
+    __syncthreads();                                         // red[] is reused
+    s = block_sum<4>(s, red);
     if (threadIdx.x == 0) {
-        const float sg = ss * inv;
-        b.sigma[blockIdx.x * b.nslots + b.slot] = sg;
-        b.isig[blockIdx.x * b.nslots + b.slot] = 1.f / sg;
+        L.s[row] = s;
+        __threadfence();
+        last = atomicAdd(&g_sn_done[blockIdx.y], 1u) == (unsigned)(L.rows - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float qq = 0.f;
+    for (int r = threadIdx.x; r < L.rows; r += 256) { const float sv = ld_agent(L.s + r); qq += sv * sv; }
+    __syncthreads();
+    const float ss = block_sum<4>(qq, red);
+    const float uinv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    float* uh = b.u_hist + ((size_t)blockIdx.y * b.nslots + b.slot) * b.hist_stride_u;
+    for (int r = threadIdx.x; r < L.rows; r += 256) { const float uu = ld_agent(L.s + r) * uinv; L.u[r] = uu; uh[r] = uu; }
+    for (int c = threadIdx.x; c < L.cols; c += 256) L.t[c] = 0.f;
+    if (threadIdx.x == 0) {
+        const float sg = ss * uinv;
+        b.sigma[blockIdx.y * b.nslots + b.slot] = sg;
+        b.isig[blockIdx.y * b.nslots + b.slot] = 1.f / sg;
+        g_sn_done[blockIdx.y] = 0u;
     }
 }
 
@@ -253,45 +273,88 @@ __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __re
 // clip_grad_norm_(max_norm) + Adam over flat fp32 buffers
 // (torch.nn.utils.clip_grad_norm_ + torch.optim.Adam at cgan/cgan_train_enhanced.py:256-257,331-332,368-369)
 // =========================================================================================
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* out) {
+// state (8 doubles): [0] step count, [1] sum of squares accumulator (zero between calls), [2] last total norm,
+// [3] clip coefficient, [4] lr / (1 - b1^t), [5] sqrt(1 - b2^t), [6] blocks-finished counter (as u64), [7] spare.
+// Few blocks (same-address fp64 atomics serialise at ~12 ns each); the last block to finish advances the step and
+// derives the scalars of this update, following torch's single-tensor Adam (python doubles, cast to float where
+// they meet the tensor).
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* state, double lr, double b1,
+                                                    double b2, double max_norm) {
     __shared__ double red[4];
-    // 16-byte loads, fp32 per-thread partials (a thread sees <= ~50 elements), fp64 from the wave reduction on
-    float sf = 0.f;
-    const size_t n4 = n / 4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const float4 v = reinterpret_cast<const float4*>(g)[i];
-        sf += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    __shared__ int last;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // fp32 per-thread partials (<= ~100 elements each), fp64 from there
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = g4[i], b = g4[i + stride], c = g4[i + 2 * stride], d = g4[i + 3 * stride];
+        s0 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+        s1 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+        s2 += c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+        s3 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; sf += v * v; }
-    double s = (double)sf;
+    for (; i < n4; i += stride) { const float4 a = g4[i]; s0 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; s1 += v * v; }
+    double s = (double)s0 + (double)s1 + (double)s2 + (double)s3;
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        atomicAdd(state + 1, red[0] + red[1] + red[2] + red[3]);
+        __threadfence();
+        unsigned long long* cnt = reinterpret_cast<unsigned long long*>(state + 6);
+        last = atomicAdd(cnt, 1ull) == (unsigned long long)(gridDim.x - 1);
+        if (last) {
+            __threadfence();
+            const double ss = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double t = state[0] + 1.0;
+            const float total = (float)sqrt(ss);
+            state[0] = t;
+            state[2] = sqrt(ss);
+            state[3] = (double)fminf(1.0f, (float)max_norm / (total + 1e-6f));
+            state[4] = (double)(float)(lr / (1.0 - pow(b1, t)));
+            state[5] = (double)(float)sqrt(1.0 - pow(b2, t));
+            state[1] = 0.0;
+            *cnt = 0ull;
+        }
+    }
 }
 
-// state[0] = step count (as float64), state[1] = sum of squares of the gradient, state[2] = last total norm
-__global__ void adam_tick_kernel(double* state) { state[0] += 1.0; state[2] = sqrt(state[1]); }
+// after: 0 leave g, 1 write the clipped gradient back (what clip_grad_norm_ leaves in .grad), 2 zero g for the next
+// accumulation (replaces the separate zero_grad fill)
+__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, float coef, float step, float bc2s, float w1,
+                                         float b2f, float w2, float eps, int after) {
+    const float gi = g * coef;
+    const float mi = m + w1 * (gi - m);                           // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v * b2f + w2 * (gi * gi);                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    m = mi; v = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p = p - step * (mi / denom);
+    g = after == 2 ? 0.f : gi;
+}
 
-// scalar constants follow torch's single-tensor Adam: python doubles, cast to float where they meet the tensor
-__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, const double* __restrict__ state, double lr, double b1, double b2, double eps,
-                            double max_norm, int write_clipped) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double t = state[0];
-    const float total = (float)sqrt(state[1]);
-    const float coef = fminf(1.0f, (float)max_norm / (total + 1e-6f));
-    const float step = (float)(lr / (1.0 - pow(b1, t)));
-    const float bc2s = (float)sqrt(1.0 - pow(b2, t));
-    const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2);
-    const float gi = g[i] * coef;
-    const float mi = m[i] + w1 * (gi - m[i]);                     // exp_avg.lerp_(grad, 1-beta1)
-    const float vi = v[i] * b2f + w2 * (gi * gi);                 // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / bc2s + (float)eps;
-    p[i] = p[i] - step * (mi / denom);
-    if (write_clipped) g[i] = gi;
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, const double* __restrict__ state, double b1,
+                                                   double b2, double eps, int after) {
+    const float coef = (float)state[3], step = (float)state[4], bc2s = (float)state[5];
+    const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2), epsf = (float)eps;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n4 = n / 4;
+    if (i < n4) {
+        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+        adam_one(P.x, G.x, M.x, V.x, coef, step, bc2s, w1, b2f, w2, epsf, after);
+        adam_one(P.y, G.y, M.y, V.y, coef, step, bc2s, w1, b2f, w2, epsf, after);
+        adam_one(P.z, G.z, M.z, V.z, coef, step, bc2s, w1, b2f, w2, epsf, after);
+        adam_one(P.w, G.w, M.w, V.w, coef, step, bc2s, w1, b2f, w2, epsf, after);
+        reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
+        if (after) reinterpret_cast<float4*>(g)[i] = G;
+    } else if (i - n4 < (n & 3)) {
+        const size_t j = n4 * 4 + (i - n4);
+        float P = p[j], G = g[j], M = m[j], V = v[j];
+        adam_one(P, G, M, V, coef, step, bc2s, w1, b2f, w2, epsf, after);
+        p[j] = P; m[j] = M; v[j] = V;
+        if (after) g[j] = G;
+    }
 }
 
 // =========================================================================================
@@ -423,15 +486,24 @@ __global__ void eiou_kernel(const float* __restrict__ pred_box, const float* __r
 // =========================================================================================
 // dropout keep-masks (Bernoulli 0.5), counter-based hash (splitmix64) -- nn.Dropout(0.5) cgan/models.py:106,109,110
 // =========================================================================================
+// one hash per 8 mask bytes (bits 24..31 -> one byte each); a tail of n % 8 bytes is hashed per byte
 __global__ void mask_gen_kernel(uint8_t* __restrict__ out, size_t n, uint64_t seed, const double* counter) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const size_t n8 = n / 8;
+    if (i >= n8 + (n & 7)) return;
     uint64_t x = (uint64_t)i + seed * 0x9E3779B97F4A7C15ull + (counter ? (uint64_t)counter[0] * 0xD1B54A32D192ED03ull : 0ull);
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     x ^= x >> 31;
-    out[i] = (uint8_t)((x >> 40) & 1);
+    if (i < n8) {
+        uint64_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w |= ((x >> (24 + j)) & 1ull) << (8 * j);
+        reinterpret_cast<uint64_t*>(out)[i] = w;
+    } else {
+        out[n8 * 8 + (i - n8)] = (uint8_t)((x >> 40) & 1);
+    }
 }
 
 // mean of each of `groups` equal chunks of x
@@ -551,14 +623,9 @@ int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* c
     b.hist_stride_u = hist_stride_u; b.hist_stride_v = hist_stride_v; b.slot = slot; b.nslots = nslots;
     hipStream_t st = (hipStream_t)stream;
     if (iterate) {
-        bool contiguous = true;                        // SnState allocates the t scratch of all layers back to back
-        size_t total = cols[0];
-        for (int i = 1; i < nl; ++i) { contiguous = contiguous && (t[i] == t[i - 1] + cols[i - 1]); total += cols[i]; }
-        if (contiguous) hipMemsetAsync(t[0], 0, sizeof(float) * total, st);
-        else for (int i = 0; i < nl; ++i) hipMemsetAsync(t[i], 0, sizeof(float) * cols[i], st);
+        // t is zero on entry (caller allocates it zeroed) and sn_wv_kernel leaves it zero again
         hipLaunchKernelGGL(sn_wtu_kernel, dim3((maxc + 63) / 64, nl, (maxr + 63) / 64), dim3(256), 0, st, b);
-        hipLaunchKernelGGL(sn_wv_kernel, dim3((maxr + 3) / 4, nl), dim3(256), 0, st, b);
-        hipLaunchKernelGGL(sn_fin_kernel, dim3(nl), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(sn_wv_kernel, dim3(maxr, nl), dim3(256), 0, st, b);
     } else {
         hipLaunchKernelGGL(sn_sigma_kernel, dim3(nl), dim3(256), 0, st, b);
     }
@@ -583,17 +650,19 @@ int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long
     return gcssl_launch_status();
 }
 
-// state: 3 doubles {step, sumsq, last_total_norm}.  Caller zeroes state[1] before each use (gcssl_zero or memset).
+// state: 8 doubles, zero-initialised by the caller once (layout at sumsq_kernel); no per-call memset is needed.
 int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* state, double lr, double b1, double b2,
                     double eps, double max_norm, int write_clipped, void* stream) {
     if (!p || !g || !m || !v || !state) return GCSSL_ENULL;
-    if (n <= 0) return GCSSL_EBADSHAPE;
+    if (n <= 0 || write_clipped < 0 || write_clipped > 2) return GCSSL_EBADSHAPE;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return GCSSL_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(state + 1, 0, sizeof(double), st);
-    int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, (size_t)n, state + 1);
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, state);
-    hipLaunchKernelGGL(adam_kernel, GRID1(n), p, g, m, v, (size_t)n, state, lr, b1, b2, eps, max_norm, write_clipped);
+    const size_t n4 = (size_t)n / 4;
+    int blocks = (int)((n4 + 256 * 8 - 1) / (256 * 8)); if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, (size_t)n, state, lr, b1, b2, max_norm);
+    const size_t items = n4 + ((size_t)n & 3);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, g, m, v, (size_t)n, state, b1, b2,
+                       eps, write_clipped);
     return gcssl_launch_status();
 }
 
@@ -627,7 +696,8 @@ int gcssl_eiou_fwd_bwd(const float* pred_box, const float* delta, const float* d
 int gcssl_dropout_mask_gen(uint8_t* out, long n, unsigned long long seed, const double* counter, void* stream) {
     if (!out) return GCSSL_ENULL;
     if (n <= 0) return GCSSL_EBADSHAPE;
-    hipLaunchKernelGGL(mask_gen_kernel, GRID1(n), out, (size_t)n, (uint64_t)seed, counter);
+    if (((uintptr_t)out) & 7) return GCSSL_EALIGN;
+    hipLaunchKernelGGL(mask_gen_kernel, GRID1(n / 8 + (n & 7)), out, (size_t)n, (uint64_t)seed, counter);
     return gcssl_launch_status();
 }
 

@@ -47,6 +47,7 @@ __device__ __forceinline__ float act_grad(float xhat, int act) { return xhat > 0
 //   large maps:             stats (shifted sums, atomics) -> finalize -> apply, all fully parallel over H*W chunks.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int VC = 4, CGN = 16, RGN = 16, MAXR = 4, SMALL_HW = RGN * MAXR;
+constexpr int BIGR = 16, MID_HW = RGN * BIGR;   // 64 < H*W <= 256: same fused kernels with 16 rows per lane (forward, backward)
 
 template <int NV>
 __device__ __forceinline__ void combine16(float (&v)[NV][VC], float (*sm)[RGN][CW], int tx, int ty) {
@@ -119,7 +120,7 @@ __device__ __forceinline__ void keep4(const uint8_t* mp, float (&k)[VC]) {
 }
 
 // ---- forward, small maps: a = act((z - mean) * rstd) [* keep * 2]; writes mean/rstd [N][C]
-template <typename T, int RG>
+template <typename T, int RG, int MR = MAXR>
 __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(const float* __restrict__ z, int ldz, T* __restrict__ a, int lda,
                                                                 float* __restrict__ mean, float* __restrict__ rstd,
                                                                 const uint8_t* __restrict__ mask, int N, int HW, int C, int act,
@@ -133,10 +134,10 @@ __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(const float* __
         const int n = n0 + slot;
         const bool live = n < N;
         const float* zp = z + (size_t)n * HW * ldz + c;
-        float v[MAXR][VC];
+        float v[MR][VC];
         float s[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
+        for (int i = 0; i < MR; ++i) {
             const int p = rg + RG * i;
             if (live && p < HW) {
                 ld4(zp + (size_t)p * ldz, v[i]);
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(const float* __
 #pragma unroll
         for (int j = 0; j < VC; ++j) { mu[j] = s[0][j] / HW; s[0][j] = 0.f; }
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i)
+        for (int i = 0; i < MR; ++i)
             if (live && rg + RG * i < HW) {
 #pragma unroll
                 for (int j = 0; j < VC; ++j) { const float d = v[i][j] - mu[j]; s[0][j] += d * d; }
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(const float* __
         }
         T* ap = a + (size_t)n * HW * lda + c;
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
+        for (int i = 0; i < MR; ++i) {
             const int p = rg + RG * i;
             if (!live || p >= HW) continue;
             float o[VC], k[VC] = {1.f, 1.f, 1.f, 1.f};
@@ -263,7 +264,7 @@ struct InBwdParams {
 };
 
 // small maps: fused backward, several samples per pass and several passes per workgroup (see combine_seg)
-template <typename T, int RG>
+template <typename T, int RG, int MR = MAXR>
 __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, int N, int spb, int mixed_groups) {
     __shared__ float sm[2][RGN][CW];
     __shared__ float red[CGN * RGN / 64];
@@ -289,10 +290,10 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
             ld4(q.mean + (size_t)n * C + c, mu); ld4(q.rstd + (size_t)n * C + c, r);
             if (q.da_bcast) ld4(q.da_bcast + (size_t)n * C + c, dab);
         }
-        float zv[MAXR][VC], dn[MAXR][VC];
+        float zv[MR][VC], dn[MR][VC];
         float s[2][VC] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
+        for (int i = 0; i < MR; ++i) {
             const int p = rg + RG * i;
             if (!live || p >= HW) continue;
             ld4(zp + (size_t)p * q.ldz, zv[i]);
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
         const float* ztp = (q.zt && live && n >= q.zt_n0) ? q.zt + (size_t)(n - q.zt_n0) * HW * C + c : nullptr;
         T* op = static_cast<T*>(q.dzs) + (size_t)n * HW * q.lddz + c;
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
+        for (int i = 0; i < MR; ++i) {
             const int p = rg + RG * i;
             if (!live || p >= HW) continue;
             float t[VC] = {0.f, 0.f, 0.f, 0.f}, o[VC];
@@ -684,12 +685,17 @@ int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float
     if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lda < C || ldz % 4 || lda % 4 || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
     if (!aligned16(z) || (((uintptr_t)a) & 7)) return GCSSL_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    if (HW <= SMALL_HW && !pool) {
+    if (HW <= MID_HW && !pool) {
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, 0);
         dim3 grid(C / CW, (N + spb - 1) / spb);
-#define FWD_SMALL(T, RG) hipLaunchKernelGGL((in_fwd_small_kernel<T, RG>), grid, dim3(CGN * RGN), 0, st, z, ldz, (T*)a, lda, mean, rstd, mask, N, HW, C, act, spb)
-        if (dtype == GCSSL_F32) { if (rg == 1) FWD_SMALL(float, 1); else if (rg == 4) FWD_SMALL(float, 4); else FWD_SMALL(float, 16); }
-        else { if (rg == 1) FWD_SMALL(bf16_t, 1); else if (rg == 4) FWD_SMALL(bf16_t, 4); else FWD_SMALL(bf16_t, 16); }
+#define FWD_SMALL(T, RG, MR) hipLaunchKernelGGL((in_fwd_small_kernel<T, RG, MR>), grid, dim3(CGN * RGN), 0, st, z, ldz, (T*)a, lda, mean, rstd, mask, N, HW, C, act, spb)
+        if (dtype == GCSSL_F32) {
+            if (rg == 1) FWD_SMALL(float, 1, MAXR); else if (rg == 4) FWD_SMALL(float, 4, MAXR);
+            else if (HW <= SMALL_HW) FWD_SMALL(float, 16, MAXR); else FWD_SMALL(float, 16, BIGR);
+        } else {
+            if (rg == 1) FWD_SMALL(bf16_t, 1, MAXR); else if (rg == 4) FWD_SMALL(bf16_t, 4, MAXR);
+            else if (HW <= SMALL_HW) FWD_SMALL(bf16_t, 16, MAXR); else FWD_SMALL(bf16_t, 16, BIGR);
+        }
 #undef FWD_SMALL
         return gcssl_launch_status();
     }
@@ -712,17 +718,22 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
     if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lddz < C || ldz % 4 || lddz % 4 || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
     if ((da && ldda % 4) || (da2 && ldda2 % 4)) return GCSSL_EBADSHAPE;
     if ((gscale || cdot) && group_n <= 0) return GCSSL_EBADSHAPE;
-    if (HW > SMALL_HW && !ws) return GCSSL_ENULL;
+    if (HW > MID_HW && !ws) return GCSSL_ENULL;
     InBwdParams q{da, ldda, da2, ldda2, da_bcast, z, ldz, mean, rstd, mask, zt, zt_n0, gscale,
                   group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, HW, C, act};
     hipStream_t st = (hipStream_t)stream;
-    if (HW <= SMALL_HW) {
+    if (HW <= MID_HW) {
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, cdot ? q.group_n : 0);
         const int mixed = (cdot && q.group_n % spb) ? 1 : 0;
         dim3 grid(C / CW, (N + spb - 1) / spb);
-#define BWD_SMALL(T, RG) hipLaunchKernelGGL((in_bwd_small_kernel<T, RG>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed)
-        if (dtype == GCSSL_F32) { if (rg == 1) BWD_SMALL(float, 1); else if (rg == 4) BWD_SMALL(float, 4); else BWD_SMALL(float, 16); }
-        else { if (rg == 1) BWD_SMALL(bf16_t, 1); else if (rg == 4) BWD_SMALL(bf16_t, 4); else BWD_SMALL(bf16_t, 16); }
+#define BWD_SMALL(T, RG, MR) hipLaunchKernelGGL((in_bwd_small_kernel<T, RG, MR>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed)
+        if (dtype == GCSSL_F32) {
+            if (rg == 1) BWD_SMALL(float, 1, MAXR); else if (rg == 4) BWD_SMALL(float, 4, MAXR);
+            else if (HW <= SMALL_HW) BWD_SMALL(float, 16, MAXR); else BWD_SMALL(float, 16, BIGR);
+        } else {
+            if (rg == 1) BWD_SMALL(bf16_t, 1, MAXR); else if (rg == 4) BWD_SMALL(bf16_t, 4, MAXR);
+            else if (HW <= SMALL_HW) BWD_SMALL(bf16_t, 16, MAXR); else BWD_SMALL(bf16_t, 16, BIGR);
+        }
 #undef BWD_SMALL
         return gcssl_launch_status();
     }

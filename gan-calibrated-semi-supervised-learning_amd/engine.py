@@ -14,6 +14,7 @@ MI355X-first choices:
 """
 from __future__ import annotations
 
+import math
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -45,7 +46,8 @@ class FlatParams:
         self.g = torch.zeros(n, device=device)
         self.m = torch.zeros(n, device=device)
         self.v = torch.zeros(n, device=device)
-        self.state = torch.zeros(3, device=device, dtype=torch.float64)   # step, sumsq scratch, last grad norm
+        self.grads_zero = True                                            # g is all-zero (fresh, or zeroed by the last update)
+        self.state = torch.zeros(8, device=device, dtype=torch.float64)   # step, sumsq, last grad norm, ... (gcssl.h)
         self.views, self.gviews, off = {}, {}, 0
         for k in keys:
             t = sd[k]
@@ -82,7 +84,8 @@ class StepEngine:
     def __init__(self, sd_g: Dict[str, torch.Tensor], sd_d: Dict[str, torch.Tensor], batch: int, size: int,
                  n_critic: int = 2, dtype="bf16", device="cuda", lr: float = 2e-4, betas=(0.5, 0.999),
                  delta_scale: float = 0.3, lambda_gp: float = 1.0, lambda_iou: float = 1.0, seed: int = 42,
-                 allreduce: Optional[Callable[[torch.Tensor], None]] = None, keep_clipped_grads: bool = True):
+                 allreduce: Optional[Callable[[torch.Tensor], None]] = None, keep_clipped_grads: bool = True,
+                 overlap: int = 0):
         if size < 32 or size & (size - 1):
             raise ValueError("img size must be a power of two >= 32 (the reference raises below 32: SURVEY §0)")
         self.B, self.S, self.c = batch, size, n_critic
@@ -105,9 +108,38 @@ class StepEngine:
         self._alloc()
         self._d_dirty = True
         self._g_dirty = True
-        self.mask_counter = torch.zeros(1, device=dev, dtype=torch.float64)
         self._prep_d_batch = self._prep_g_batch = None
+        self._red_d = self._red_g = None
+        # Independent branches of the iteration run on a side HIP stream (hipGraph capture turns them into parallel
+        # graph branches): spectral-norm iterations + weight re-pack beside the no-grad generator forward, and every
+        # layer's wgrad + split-K reduce beside the dependent dgrad -> norm-backward chain.  None of these kernels
+        # fills 256 CUs on its own.
+        self.overlap = int(overlap)
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(2)] if overlap else []
         self.probe = None          # {label: {"events": [(start, stop)...], "flops": f}} when profiling is enabled
+
+    # ------------------------------------------------------------------------------------------ side-stream branches
+    def _on_side(self, fn, which: int = 0, level: int = 2):
+        """Run fn() on side stream `which`, ordered after everything enqueued so far on the current stream.
+        level 1 = the coarse branches (spectral norm + re-pack, the value-only critic forward), 2 = per-layer wgrads."""
+        if self.overlap < level or self.probe is not None:   # probing wants serial, attributable timings
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.side[which].wait_event(ev)
+        with torch.cuda.stream(self.side[which]):
+            fn()
+
+    def _join_side(self):
+        """Make the current stream wait for everything enqueued on the side stream."""
+        if not self.overlap or self.probe is not None:
+            return
+        for st in self.side:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            torch.cuda.current_stream().wait_event(ev)
 
     # ------------------------------------------------------------------------------------------ in-situ kernel timing
     def enable_probe(self, on: bool = True):
@@ -211,9 +243,10 @@ class StepEngine:
         self.g_drstd = [None] + [torch.empty(B, c, **f32) for c in (128, 256, 512)]
         self.g_umean = [torch.empty(B, c, **f32) for c in (256, 128, 64, 64)]
         self.g_urstd = [torch.empty(B, c, **f32) for c in (256, 128, 64, 64)]
-        self.g_masks = [torch.empty(B, S // 16, S // 16, 512, device=dev, dtype=torch.uint8),
-                        torch.empty(B, S // 8, S // 8, 256, device=dev, dtype=torch.uint8),
-                        torch.empty(B, S // 4, S // 4, 128, device=dev, dtype=torch.uint8)]
+        shapes = [(B, S // 16, S // 16, 512), (B, S // 8, S // 8, 256), (B, S // 4, S // 4, 128)]
+        sizes = [math.prod(sh) for sh in shapes]
+        self.g_maskbuf = torch.empty(sum(sizes), device=dev, dtype=torch.uint8)      # one launch draws all three
+        self.g_masks = [self.g_maskbuf[sum(sizes[:j]):sum(sizes[:j + 1])].view(sh) for j, sh in enumerate(shapes)]
         self.g_pooled = torch.empty(B, 64, **f32)
         self.g_poolsum = torch.zeros(B, 64, **f32)                 # sum over H*W of u4, accumulated by up4's IN apply pass
         self.ws = torch.empty(2 * N3 * 512, **f32)                 # scratch of the large-map InstanceNorm backward
@@ -243,6 +276,22 @@ class StepEngine:
             self.g_ns_u.append(ns)
             self.g_slab_u.append(torch.empty(ns, cint, 16, coutt, **f32))
 
+    def _reduce_batches(self):
+        """One launch reduces the split-K slabs of every layer of a backward pass (+ the spectral-norm rank-1 terms)."""
+        if self._red_d is None:
+            self._red_d = ops.ReduceBatch(
+                [dict(slab=self.d_slab[l], nsplit=sum(self.d_ns[l]), dw=self.D.gviews[f"model.{i}.weight_orig"], cout=cout,
+                      cin=_pad8(cin), cin_real=cin, coef=self.cdot[l], u=self.sn.u_hist[l], v=self.sn.v_hist[l])
+                 for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX))], nrank=3)
+            gW = self.G.gviews
+            up = [dict(slab=self.g_slab_u[k], nsplit=self.g_ns_u[k],
+                       dw=gW[f"up{k + 1}.model.0.weight" if k < 3 else "up4.0.weight"], cout=cint, cin=coutt, cin_real=coutt)
+                  for k, (cint, coutt) in enumerate(G_UP)]
+            down = [dict(slab=self.g_slab_d[k], nsplit=self.g_ns_d[k], dw=gW[f"down{k + 1}.model.0.weight"], cout=cout,
+                         cin=_pad8(cin), cin_real=cin) for k, (cin, cout) in enumerate(G_DOWN)]
+            self._red_g = ops.ReduceBatch(up + down)
+        return self._red_d, self._red_g
+
     # ------------------------------------------------------------------------------------------ weights
     def _prep_d(self):
         if not self._d_dirty:
@@ -269,9 +318,9 @@ class StepEngine:
         self._g_dirty = False
 
     # ------------------------------------------------------------------------------------------ critic forward
-    def _d_forward(self, n: int, gscale_of_layer, group_n: int):
-        """conv stack over the first n rows of the 3B buffers."""
-        x = self.x0[:n]
+    def _d_forward(self, n: int, gscale_of_layer, group_n: int, x: Optional[torch.Tensor] = None):
+        """conv stack over the first n rows of the 3B buffers (input: x, default the first n rows of x0)."""
+        x = self.x0[:n] if x is None else x
         for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX)):
             bias = self.D.views[f"model.{i}.bias"]
             fl = conv_flops(n, self.S >> l, cin, cout)
@@ -296,12 +345,12 @@ class StepEngine:
         return self.d_out[:B].reshape(B, 1, self.h5, self.h5)
 
     # ------------------------------------------------------------------------------------------ generator forward
-    def _set_masks(self, masks: Optional[Sequence[torch.Tensor]]):
-        """masks given as NCHW keep-masks (fixture/parity mode) or None -> drawn on the device."""
+    def _set_masks(self, masks: Optional[Sequence[torch.Tensor]], phase: int = 0):
+        """masks given as NCHW keep-masks (fixture/parity mode) or None -> drawn on the device.  The draw is keyed by
+        (seed, phase, critic step count): the step count lives on the device (Adam state), so graph replays draw fresh
+        masks; phase 0 = the forwards of the critic steps, 1 = the generator step, 2 = generator_delta()."""
         if masks is None:
-            for j, m in enumerate(self.g_masks):
-                ops.dropout_mask_gen(m, self.seed * 131 + j, self.mask_counter)
-            self.mask_counter += 1.0
+            ops.dropout_mask_gen(self.g_maskbuf, self.seed * 131 + phase, self.D.state)
         else:
             for m, src in zip(self.g_masks, masks):
                 m.copy_(src.permute(0, 2, 3, 1))
@@ -336,7 +385,7 @@ class StepEngine:
         self._prep_g()
         ops.pack_pair(pred, None, self.gt_x)          # gt_x doubles as the NHWC8 staging buffer outside a D step
         if train:
-            self._set_masks(masks)
+            self._set_masks(masks, 2)
         return self._g_forward(self.gt_x, train).clone()
 
     # ------------------------------------------------------------------------------------------ D step
@@ -347,10 +396,12 @@ class StepEngine:
 
     def d_update(self) -> None:
         """all-reduce (data parallel) -> clip_grad_norm_(1.0) -> Adam  (:331-332)."""
+        self._join_side()
         if self.allreduce is not None:
             self.allreduce(self.D.g)
         ops.clip_adam(self.D.p, self.D.g, self.D.m, self.D.v, self.D.state, self.lr, self.betas[0], self.betas[1],
-                      write_clipped=self.keep_clipped_grads)
+                      write_clipped=1 if self.keep_clipped_grads else 2)     # 2: the update also re-zeroes the bucket
+        self.D.grads_zero = not self.keep_clipped_grads
         self._d_dirty = True
 
     def d_compute(self, pred, gt, refine_fn, k: int, alpha: Optional[torch.Tensor], masks) -> None:
@@ -359,11 +410,15 @@ class StepEngine:
         B, S, N3 = self.B, self.S, 3 * self.B
         I = slice(2 * B, 3 * B)
         isig = self.sn.isig
-        self.D.g.zero_()
+        def sn_and_prep():
+            for slot in range(3):                                 # real, fake, interp forwards each iterate once
+                self.sn.iterate(slot, True)
+            self._prep_d()
+        self._on_side(sn_and_prep, 0, 1)                                # overlaps the generator forward below
+        if not self.D.grads_zero:                                 # optimizer.zero_grad() (:305) unless the last update did it
+            self.D.g.zero_()
+        self.D.grads_zero = False
         self.scal.zero_()
-        for slot in range(3):                                     # real, fake, interp forwards each iterate once
-            self.sn.iterate(slot, True)
-        self._prep_d()
         self._prep_g()
         # no-grad generator forward in train mode (:311-312) on the real-group input (channels 0-2 = pred)
         ops.pack_pair(pred, gt, self.x0[:B])
@@ -374,6 +429,7 @@ class StepEngine:
             alpha = torch.rand(B, device=self.dev)                 # cgan/losses.py:199
         ops.pack_pair(pred, refined, self.x0[B:2 * B])
         ops.pack_interp(pred, gt, refined, alpha, self.x0[I])
+        self._join_side()                                         # sigma, u/v history and packed weights are ready
         self._d_forward(N3, lambda l: isig[l], B)
         ops.group_mean(self.d_out, 3, self.means)
         # ---- GP first-order chain on the interpolated group (cgan/losses.py:213-220)
@@ -395,7 +451,8 @@ class StepEngine:
             fl = conv_flops(B, S >> l, cin, cout)
             self._conv(f"D.c{l + 1}.gp_rev_fwd", fl, ops.conv_fwd, src, self.d_wf[l], self.gt_z[l], cp, cout,
                        gscale=isig[l, 2:3], group_n=B)
-            self._conv(f"D.c{l + 1}.gp_rev_wgrad", fl, ops.conv_wgrad, src, self.gb_zs[l], self.d_slab[l], cp, cout)
+            self._on_side(lambda src=src, l=l, cp=cp, cout=cout, fl=fl: self._conv(
+                f"D.c{l + 1}.gp_rev_wgrad", fl, ops.conv_wgrad, src, self.gb_zs[l], self.d_slab[l], cp, cout))
             if l == 0:
                 ops.dot_accum(self.gb_zs[0], self.gt_z[0], 64, self.cdot[0, 2:3])
                 ops.act_bwd(self.gt_z[0], self.d_a[0][I], self.gt_a[0], 64)
@@ -425,11 +482,15 @@ class StepEngine:
             nc, nf = self.d_ns[l]
             xin = self.x0 if l == 0 else self.d_a[l - 1]
             fl = conv_flops(N3, S >> l, cin, cout)
-            self._conv(f"D.c{l + 1}.wgrad", fl, ops.conv_wgrad, xin, self.d_dzs[l], self.d_slab[l][nc:], cp, cout)
-            ops.wgrad_reduce(self.d_slab[l], nc + nf, self.D.gviews[f"model.{i}.weight_orig"], cout, cp, cin,
-                             coef=self.cdot[l], u=self.sn.u_hist[l], v=self.sn.v_hist[l], nrank=3, accumulate="zeroed")
+
+            def wgrad_branch(l=l, cout=cout, cp=cp, nc=nc, xin=xin, fl=fl):
+                self._conv(f"D.c{l + 1}.wgrad", fl, ops.conv_wgrad, xin, self.d_dzs[l], self.d_slab[l][nc:], cp, cout)
+            self._on_side(wgrad_branch)                           # beside the dgrad -> norm-backward chain
             if l > 0:
                 self._conv(f"D.c{l + 1}.dgrad", fl, ops.conv_dgrad, self.d_dzs[l], self.d_wt[l], self.d_da[l - 1], cin, cout)
+        self._join_side()                                         # all gradient branches are in before the segment ends
+        # dW_orig = sum_k G_k / sigma_k - sum_k c_k u_k v_k^T for the four spectrally-normalised layers, one launch
+        self._reduce_batches()[0].run()
 
     # ------------------------------------------------------------------------------------------ G step
     def g_step(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
@@ -438,10 +499,12 @@ class StepEngine:
         self.g_update()
 
     def g_update(self) -> None:
+        self._join_side()
         if self.allreduce is not None:
             self.allreduce(self.G.g)
         ops.clip_adam(self.G.p, self.G.g, self.G.m, self.G.v, self.G.state, self.lr, self.betas[0], self.betas[1],
-                      write_clipped=self.keep_clipped_grads)                            # :368-369
+                      write_clipped=1 if self.keep_clipped_grads else 2)                # :368-369
+        self.G.grads_zero = not self.keep_clipped_grads
         self._g_dirty = True
 
     def g_compute(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
@@ -449,19 +512,25 @@ class StepEngine:
         self.scal[13:].zero_()
         self._prep_g()
         ops.pack_pair(pred, None, self.x0[:B])
-        self._set_masks(masks)
+        self._set_masks(masks, 1)
         self._g_forward(self.x0[:B], True)                                             # :348
         ops.eiou_fwd_bwd(pred_box, self.g_delta, delta_true, self.lambda_iou, self.g_gdelta, self.g_cal,
                          self.eiou_acc)                                                # :351-355
         self.delta_pred = self.g_delta.clone()
         # D forward on (pred, refined_G): value only (zero gradient to G) but it advances u,v (:361)
         refined_g = refine_fn(self.delta_pred, self.c)                                 # :358-360
-        scores = self.critic_scores(pred, refined_g, train=True)
-        ops.group_mean(scores, 1, self.wgan_mean)                                      # loss_WGAN_G = -mean (:362)
+
+        def critic_branch():            # independent of G's backward: own input buffer, the critic's activations
+            self.sn.iterate(0, True)
+            self._prep_d()
+            ops.pack_pair(pred, refined_g, self.x0[B:2 * B])       # x0[:B] stays G's input for the down1 wgrad
+            self._d_forward(B, lambda l: self.sn.isig[l, 0:1], B, x=self.x0[B:2 * B])
+            ops.group_mean(self.d_out[:B], 1, self.wgan_mean)                          # loss_WGAN_G = -mean (:362)
+        self._on_side(critic_branch, 1, 1)
         # ---- backward of lambda_iou * EIoU through G (:365-366)
-        self.G.g.zero_()
-        # (critic_scores re-packed x0[:B] as (pred, refined): channels 0-2 are still pred, and the padded channels
-        #  3-7 are dropped by the down1 reduce via Cin_real=3)
+        if not self.G.grads_zero:
+            self.G.g.zero_()
+        self.G.grads_zero = False
         gW = self.G.gviews
         ops.head_bwd(self.g_gdelta, self.g_traw, self.g_pooled, self.G.views["fc_delta.1.weight"], self.delta_scale,
                      B, S * S, gW["fc_delta.1.weight"], gW["fc_delta.1.bias"], self.g_dab)
@@ -477,9 +546,11 @@ class StepEngine:
                 ops.in_act_bwd(self.g_zu[k], self.g_umean[k], self.g_urstd[k], self.g_dzu[k], coutt, RELU,
                                da=dcat[k + 1][..., :coutt], mask=self.g_masks[k + 1] if k < 2 else None, ws=self.ws)
             fl = conv_flops(B, S >> (3 - k), coutt, cint)
-            self._conv(f"G.up{k + 1}.wgrad", fl, ops.conv_wgrad, self.g_dzu[k], ins[k], self.g_slab_u[k], coutt,
-                       cint)                                                            # roles swapped (ConvTranspose)
-            ops.wgrad_reduce(self.g_slab_u[k], self.g_ns_u[k], gW[key], cint, coutt, coutt, accumulate="zeroed")
+
+            def up_wgrad(k=k, cint=cint, coutt=coutt, fl=fl):
+                self._conv(f"G.up{k + 1}.wgrad", fl, ops.conv_wgrad, self.g_dzu[k], ins[k], self.g_slab_u[k], coutt,
+                           cint)                                                        # roles swapped (ConvTranspose)
+            self._on_side(up_wgrad)
             self._conv(f"G.up{k + 1}.dgrad", fl, ops.conv_fwd, self.g_dzu[k], self.gu_wf[k], dcat[k], coutt, cint)
         d_act = [self.g_cat3[..., 64:], self.g_cat2[..., 128:], self.g_cat1[..., 256:]]            # d1, d2, d3
         dskip = [self.g_dcat3[..., 64:], self.g_dcat2[..., 128:], self.g_dcat1[..., 256:]]
@@ -496,11 +567,14 @@ class StepEngine:
                 ops.act_bwd(self.g_dd[1], d_act[0], self.g_dzd[0], 64, da2=dskip[0])
             xin = self.x0[:B] if k == 0 else d_act[k - 1]
             fl = conv_flops(B, S >> k, cin, cout)
-            self._conv(f"G.down{k + 1}.wgrad", fl, ops.conv_wgrad, xin, self.g_dzd[k], self.g_slab_d[k], cp, cout)
-            ops.wgrad_reduce(self.g_slab_d[k], self.g_ns_d[k], gW[f"down{k + 1}.model.0.weight"], cout, cp, cin,
-                             accumulate="zeroed")
+
+            def down_wgrad(k=k, cout=cout, cp=cp, xin=xin, fl=fl):
+                self._conv(f"G.down{k + 1}.wgrad", fl, ops.conv_wgrad, xin, self.g_dzd[k], self.g_slab_d[k], cp, cout)
+            self._on_side(down_wgrad)
             if k > 0:
                 self._conv(f"G.down{k + 1}.dgrad", fl, ops.conv_dgrad, self.g_dzd[k], self.gd_wt[k], self.g_dd[k], cin, cout)
+        self._join_side()
+        self._reduce_batches()[1].run()                           # all eight weight gradients, one launch
 
     # ------------------------------------------------------------------------------------------ iteration
     def run_iteration(self, pred, gt, delta_true, pred_box, refine_fn, alphas=None, masks=None, on_critic=None):

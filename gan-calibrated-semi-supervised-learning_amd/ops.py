@@ -100,6 +100,31 @@ def wgrad_reduce(slab, nsplit, dw, cout, cin, cin_real, coef=None, cscale=None, 
          2 if accumulate == "zeroed" else int(accumulate))
 
 
+class ReduceBatch:
+    """Argument block for gcssl_wgrad_reduce_batch: layers = [dict(slab, nsplit, dw, cout, cin, cin_real[, coef, u, v])]
+    (<= 8); u, v are 2-D history tensors that share row strides."""
+
+    def __init__(self, layers, nrank=0, accumulate="zeroed"):
+        self.n, self.nrank = len(layers), nrank
+        self._keep = layers
+        self._slab = _lib.ptr_array([l["slab"] for l in layers])
+        self._dw = _lib.ptr_array([l["dw"] for l in layers])
+        self._ns, self._co, self._ci, self._cr = (_lib.int_array([l[k] for l in layers])
+                                                  for k in ("nsplit", "cout", "cin", "cin_real"))
+        if nrank:
+            self._coef, self._u, self._v = (_lib.ptr_array([l[k] for l in layers]) for k in ("coef", "u", "v"))
+            self.su, self.sv = layers[0]["u"].stride(0), layers[0]["v"].stride(0)
+            assert all(l["u"].stride(0) == self.su and l["v"].stride(0) == self.sv for l in layers)
+        else:
+            self._coef = self._u = self._v = None
+            self.su = self.sv = 0
+        self.acc = 2 if accumulate == "zeroed" else int(accumulate)
+
+    def run(self):
+        call("gcssl_wgrad_reduce_batch", self.n, self._slab, self._ns, self._dw, self._co, self._ci, self._cr, self._coef,
+             self._u, self._v, self.su, self.sv, self.nrank, self.acc)
+
+
 # ---- critic head
 def c5_fwd(x, wp, out):
     N, Hi, Wi, _ = x.shape
@@ -168,7 +193,7 @@ class SnState:
         self.rows = [w.shape[0] for w in ws]
         self.cols = [w[0].numel() for w in ws]
         self.ws, self.us, self.vs = ws, us, vs
-        tbuf = torch.empty(sum(self.cols), device=device)          # contiguous: zeroed with one memset per iteration
+        tbuf = torch.zeros(sum(self.cols), device=device)          # zero on entry, left zero by every iteration
         self.t, off = [], 0
         for c in self.cols:
             self.t.append(tbuf[off:off + c]); off += c
@@ -202,6 +227,7 @@ def scale_rows(x, coef, y, B):
 
 
 def clip_adam(p, g, m, v, state, lr, b1, b2, eps=1e-8, max_norm=1.0, write_clipped=False):
+    """write_clipped: False/0 leave g, True/1 store the clipped gradient, 2 zero g (fused zero_grad).  state: 8 doubles."""
     call("gcssl_clip_adam", p, g, m, v, p.numel(), state, float(lr), float(b1), float(b2), float(eps),
          float(max_norm), int(write_clipped))
 

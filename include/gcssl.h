@@ -76,6 +76,11 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
 int gcssl_wgrad_reduce(const float* slab, int nsplit, float* dw, int Cout, int Cin, int Cin_real, const float* coef,
                        const float* cscale, const float* u, int ustride, const float* v, int vstride, int nrank,
                        int accumulate, void* stream);
+/* The same reduction for nl <= 8 layers in one launch (all weight gradients of one loss.backward(),
+ * cgan/cgan_train_enhanced.py:330,366); arrays are indexed by layer, nrank/strides/accumulate are shared. */
+int gcssl_wgrad_reduce_batch(int nl, const float* const* slab, const int* nsplit, float* const* dw, const int* Cout,
+                             const int* Cin, const int* Cin_real, const float* const* coef, const float* const* u,
+                             const float* const* v, int ustride, int vstride, int nrank, int accumulate, void* stream);
 
 /* ---- critic head Conv2d(512,1,k4,s1,p1,bias=False): cgan/models.py:252 ------------------------------------------
  * out [N][Hi-1][Wi-1] fp32.  dgrad/wgrad take either a dout tensor or per-group constants g0,g1,g2 (dout==NULL):
@@ -116,7 +121,9 @@ int gcssl_dot_accum(int dtype, const void* x, int ldx, const float* y, int ldy, 
 
 /* ---- spectral norm power iteration (torch.nn.utils.spectral_norm, cgan/models.py:237-238) -----------------------
  * v <- normalize(W^T u), u <- normalize(W v), eps 1e-12; sigma = u.(W v).  nl <= 4 layers per call; iterate=0 only
- * evaluates sigma (eval mode).  History slot `slot` of u_hist/v_hist/sigma/isig receives this iteration's values. */
+ * evaluates sigma (eval mode).  History slot `slot` of u_hist/v_hist/sigma/isig receives this iteration's values.
+ * t[i] (cols[i] floats) must be ZERO on entry and is left zero on exit; s[i] is rows[i] floats of scratch.  One
+ * iteration may be in flight per process at a time (device-side completion counters). */
 int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* const* v, float* const* t, float* const* s,
                         const int* rows, const int* cols, float* sigma, float* isig, float* u_hist, float* v_hist,
                         int hist_stride_u, int hist_stride_v, int slot, int nslots, int iterate, void* stream);
@@ -127,7 +134,10 @@ int gcssl_gp_norm(const float* g, long per_sample, int B, float lambda_gp, float
 int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long per_sample, int B, void* stream);
 
 /* ---- clip_grad_norm_(1.0) + Adam (cgan/cgan_train_enhanced.py:256-257,331-332,368-369) over flat fp32 buffers ---
- * state: 3 doubles {step, sumsq scratch, last total norm}; step is advanced on the device (graph replay safe). */
+ * state: 8 doubles, zeroed once by the caller: {step, sumsq accumulator, last total norm, clip coef, lr/(1-b1^t),
+ * sqrt(1-b2^t), completion counter, spare}; the step is advanced on the device (graph replay safe).
+ * write_clipped: 0 leave g, 1 store g*clip_coef (what clip_grad_norm_ leaves in .grad), 2 zero g (fused zero_grad).
+ * p, g, m, v must be 16-byte aligned. */
 int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* state, double lr, double b1, double b2,
                     double eps, double max_norm, int write_clipped, void* stream);
 

@@ -308,7 +308,7 @@ def test_clip_adam_matches_torch(ops):
     ref = p0.clone().requires_grad_(True)
     opt = torch.optim.Adam([ref], lr=2e-4, betas=(0.5, 0.999))
     p = p0.cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
-    state = torch.zeros(3, device="cuda", dtype=torch.float64)
+    state = torch.zeros(8, device="cuda", dtype=torch.float64)
     for t in range(3):
         g = rnd(n, seed=81 + t, scale=0.05)
         ref.grad = g.clone()
@@ -323,6 +323,16 @@ def test_clip_adam_matches_torch(ops):
         assert float((p.cpu() - ref.detach()).abs().max()) < 2e-7
     assert rel_err(m.cpu(), opt.state[ref]["exp_avg"]) < 1e-6
     assert rel_err(v.cpu(), opt.state[ref]["exp_avg_sq"]) < 1e-6
+    # write_clipped=2: same update, and the bucket comes back zeroed (fused zero_grad); 0 leaves it untouched
+    g = rnd(n, seed=90, scale=0.05)
+    p2, m2, v2, s2 = p.clone(), m.clone(), v.clone(), state.clone()
+    ga, gb = g.cuda(), g.cuda()
+    ops.clip_adam(p, ga, m, v, state, 2e-4, 0.5, 0.999, write_clipped=0)
+    ops.clip_adam(p2, gb, m2, v2, s2, 2e-4, 0.5, 0.999, write_clipped=2)
+    torch.cuda.synchronize()
+    assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2)
+    assert torch.equal(ga.cpu(), g) and float(gb.abs().max()) == 0.0
+    assert float(state[1]) == 0.0 and float(state[6]) == 0.0      # accumulator and counter are reset for the next call
 
 
 def test_generator_head_and_eiou(ops):
@@ -360,3 +370,14 @@ def test_dropout_mask_gen(ops):
     m2 = torch.empty_like(m)
     ops.dropout_mask_gen(m2, 1235)
     assert abs(float((m == m2).float().mean()) - 0.5) < 5e-3
+    # eight bytes come from one hash: neighbouring bytes must still be independent
+    assert abs(float((m[0::2] == m[1::2]).float().mean()) - 0.5) < 5e-3
+    # the device-side counter re-keys the draw (graph replays read it at run time); same key -> same mask
+    ctr = torch.tensor([3.0], device="cuda", dtype=torch.float64)
+    m3 = torch.empty_like(m); m4 = torch.empty_like(m)
+    ops.dropout_mask_gen(m3, 1234, ctr); ops.dropout_mask_gen(m4, 1234, ctr)
+    assert torch.equal(m3, m4) and abs(float((m == m3).float().mean()) - 0.5) < 5e-3
+    # ragged length: the n % 8 tail is filled too
+    t = torch.full((8 * 1000 + 5,), 7, device="cuda", dtype=torch.uint8)
+    ops.dropout_mask_gen(t, 99)
+    assert set(t.unique().tolist()) <= {0, 1}
