@@ -14,6 +14,7 @@
 // (dgrad); weight gradients land in fp32 split-K slabs [split][Cout][16][Cin] that
 // gcssl_wgrad_reduce sums into the PyTorch-layout gradient.
 #include "common.h"
+#include <cstring>
 #include <type_traits>
 #include <cstdlib>
 
@@ -150,6 +151,7 @@ struct ConvParams {
     const float* bias;  // fwd only, nullable
     const float* gscale;  // per-group multiplier, nullable
     int group_n;        // samples per group
+    float inv_group_n;  // 1 / group_n (sample -> group index in the epilogues)
     int ldx, ldw, ldy;  // pixel strides (elements); ldw = lddy for wgrad
     int N, Hi, Wi, Cin, Cout;   // conv geometry: x is [N][Hi][Wi][Cin], y is [N][Hi/2][Wi/2][Cout]
     int lgWo, lgHoWo, lgCin, lgCout;
@@ -532,38 +534,50 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
             slot = slot == 2 ? 0 : slot + 1;
         }
     }
-    // ---- epilogue (identical to the register-staged kernels)
+    // ---- epilogue.  Everything the stores depend on is loaded FIRST: a load that sits between two stores cannot be
+    // hoisted by the compiler (the output may alias it), so the per-row group scale used to serialise the tail into
+    // 16-32 dependent load -> store round trips per wave (measured with s_memtime: a third of the workgroup's life).
     float* y32 = static_cast<float*>(p.y);
     T* yt = static_cast<T*>(p.y);
+    const int ncols = MODE == 0 ? p.Cout : p.Cin;
+    float bcol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + 32 * j + (lane & 31);
+        bcol[j] = (MODE == 0 && p.bias && col < ncols && (p.ksplit <= 1 || ks == 0)) ? p.bias[col] : 0.f;
+    }
+    float sc[TM][16];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm0 + 32 * i + crow(r, lane);
+            sc[i][r] = 1.f;
+            if (p.gscale && m < p.M)          // sample -> group without an integer division (exact below 2^21 samples)
+                sc[i][r] = p.gscale[(int)(((float)(m >> p.lgHoWo) + 0.5f) * p.inv_group_n)];
+        }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm0 + 32 * i + crow(r, lane);
             if (m >= p.M) continue;
-            const int n = m >> p.lgHoWo;
             size_t pix = (size_t)m;
             if (MODE == 1) {
-                const int rem = m & ((1 << p.lgHoWo) - 1);
+                const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
                 const int iy = 2 * (rem >> p.lgWo) + py, ix = 2 * (rem & (Wo - 1)) + px;
                 pix = (size_t)(n * p.Hi + iy) * p.Wi + ix;
             }
-            const float sc = p.gscale ? p.gscale[n / p.group_n] : 1.f;
-            const int ncols = MODE == 0 ? p.Cout : p.Cin;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + wn0 + 32 * j + (lane & 31);
                 if (col >= ncols) continue;
-                float v = acc[i][j][r] * sc;
+                float v = acc[i][j][r] * sc[i][r] + bcol[j];
                 if (p.ksplit > 1) {
-                    if (MODE == 0 && p.bias && ks == 0) v += p.bias[col];
                     atomicAdd(y32 + pix * p.ldy + col, v);
                     continue;
                 }
-                if (MODE == 0) {
-                    if (p.bias) v += p.bias[col];
-                    if (p.act == 1) v = lrelu_f(v);
-                }
+                if (MODE == 0 && p.act == 1) v = lrelu_f(v);
                 if (p.out_f32) y32[pix * p.ldy + col] = v;
                 else Elem<T>::st(yt + pix * p.ldy + col, v);
             }
@@ -800,15 +814,83 @@ void launch_dma(const ConvParams& p, dim3 grid, bool smallk, hipStream_t st) {
 // several layers per launch (blockIdx.y = layer): the critic is re-packed after every optimiser step
 struct PrepLayer { const float* w; void* wf; void* wt; int Cout, Cin, CinP; };
 struct PrepBatch { PrepLayer l[8]; };
+// 16 consecutive fp32 values of an LDS row -> 16 consecutive T in global memory (32 or 64 bytes, vector stores)
+template <typename T> __device__ __forceinline__ void store16(T* dst, const float* src);
+template <> __device__ __forceinline__ void store16<float>(float* dst, const float* src) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        reinterpret_cast<float4*>(dst)[j] = make_float4(src[4 * j], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]);
+}
+template <> __device__ __forceinline__ void store16<bf16_t>(bf16_t* dst, const float* src) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        uint4 w;
+        w.x = f32_to_bf16_bits(src[8 * j + 0]) | (f32_to_bf16_bits(src[8 * j + 1]) << 16);
+        w.y = f32_to_bf16_bits(src[8 * j + 2]) | (f32_to_bf16_bits(src[8 * j + 3]) << 16);
+        w.z = f32_to_bf16_bits(src[8 * j + 4]) | (f32_to_bf16_bits(src[8 * j + 5]) << 16);
+        w.w = f32_to_bf16_bits(src[8 * j + 6]) | (f32_to_bf16_bits(src[8 * j + 7]) << 16);
+        reinterpret_cast<uint4*>(dst)[j] = w;
+    }
+}
+
+// The re-pack is a pair of transposes of w[co][ci][tap]: Wf[co][tap][ci] makes ci the fast axis, Wt[ci][tap][co] makes
+// co the fast axis.  Each goes through an LDS tile shaped so that BOTH the fp32 reads and the packed writes are full
+// 128-byte runs (blockIdx.z = 0: 4 co x 64 ci x 16 taps for Wf; 1: 64 co x 4 ci x 16 taps for Wt); the element-wise
+// form below (2-byte writes 16*Cout elements apart for Wt) ran at <1 TB/s.  Layers whose channel counts are not
+// multiples of 64, or padded (the first layers), keep the element-wise form: they are tiny.
 template <typename T>
-__global__ void prep_weight_batch_kernel(PrepBatch b) {
+__global__ __launch_bounds__(256) void prep_weight_batch_kernel(PrepBatch b) {
     const PrepLayer L = b.l[blockIdx.y];
-    const size_t total = (size_t)L.Cout * 16 * L.CinP;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int ci = idx % L.CinP, tap = (idx / L.CinP) % 16, co = idx / ((size_t)L.CinP * 16);
-        const float val = ci < L.Cin ? L.w[((size_t)co * L.Cin + ci) * 16 + tap] : 0.f;
-        if (L.wf) Elem<T>::st(static_cast<T*>(L.wf) + idx, val);
-        if (L.wt) Elem<T>::st(static_cast<T*>(L.wt) + ((size_t)ci * 16 + tap) * L.Cout + co, val);
+    __shared__ float tile[64 * 65];
+    const bool tiled = L.Cin % 64 == 0 && L.Cout % 64 == 0 && L.CinP == L.Cin;
+    T* wf = static_cast<T*>(L.wf);
+    T* wt = static_cast<T*>(L.wt);
+    const int tid = threadIdx.x;
+    if (!tiled) {
+        if (blockIdx.z) return;
+        const size_t total = (size_t)L.Cout * 16 * L.CinP;
+        for (size_t idx = (size_t)blockIdx.x * blockDim.x + tid; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+            const int ci = idx % L.CinP, tap = (idx / L.CinP) % 16, co = idx / ((size_t)L.CinP * 16);
+            const float val = ci < L.Cin ? L.w[((size_t)co * L.Cin + ci) * 16 + tap] : 0.f;
+            if (wf) Elem<T>::st(wf + idx, val);
+            if (wt) Elem<T>::st(wt + ((size_t)ci * 16 + tap) * L.Cout + co, val);
+        }
+        return;
+    }
+    if (blockIdx.z == 0) {
+        if (!wf) return;
+        const int nci = L.Cin / 64, ntiles = (L.Cout / 4) * nci;
+        for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+            const int co0 = (t / nci) * 4, ci0 = (t % nci) * 64;
+            const int ci = tid >> 2, tp = (tid & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {               // one co: 64 ci x 16 taps = 4 KB contiguous
+                const float4 v = reinterpret_cast<const float4*>(L.w + ((size_t)(co0 + i) * L.Cin + ci0) * 16)[tid];
+                float* row = tile + (i * 16 + tp) * 65 + ci;       // tile[(co, tap)][ci]
+                row[0] = v.x; row[65] = v.y; row[130] = v.z; row[195] = v.w;
+            }
+            __syncthreads();
+            const int r = tid >> 2, c0 = (tid & 3) * 16;            // row r = (co, tap): 64 ci = 128 B (bf16)
+            store16<T>(wf + ((size_t)(co0 + (r >> 4)) * 16 + (r & 15)) * L.CinP + ci0 + c0, tile + r * 65 + c0);
+            __syncthreads();
+        }
+    } else {
+        if (!wt) return;
+        const int nci = L.Cin / 4, ntiles = (L.Cout / 64) * nci;
+        for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+            const int co0 = (t / nci) * 64, ci0 = (t % nci) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {               // per co: 4 ci x 16 taps = 256 B contiguous
+                const int f = tid + 256 * i, co = f >> 4, piece = f & 15;
+                const float4 v = reinterpret_cast<const float4*>(L.w + ((size_t)(co0 + co) * L.Cin + ci0) * 16)[piece];
+                float* col = tile + (piece * 4) * 65 + co;          // tile[k = ci_local*16 + tap][co]
+                col[0] = v.x; col[65] = v.y; col[130] = v.z; col[195] = v.w;
+            }
+            __syncthreads();
+            const int r = tid >> 2, c0 = (tid & 3) * 16;            // row r = (ci_local, tap): 64 co = 128 B (bf16)
+            store16<T>(wt + ((size_t)ci0 * 16 + r) * L.Cout + co0 + c0, tile + r * 65 + c0);
+            __syncthreads();
+        }
     }
 }
 
@@ -860,6 +942,13 @@ long tile_threshold() {
     return v;
 }
 
+// 128x128 (one workgroup per CU: 96 KB of LDS) lost to 128x64 (two per CU) on every layer of the forced-tile matrix
+// (tools/conv_matrix.sh: D.c2.fwd 37.6 -> 29.7 us, D.c3.dgrad 35.2 -> 27.6 us), so it needs many more tiles to be chosen
+long tile128_threshold() {
+    static long v = [] { const char* e = getenv("GCSSL_TILE128_WGS"); return e ? atol(e) : 2048L; }();
+    return v;
+}
+
 int pick_ksplit(long tiles, int nk, bool allowed) {
     if (!allowed || tiles >= 384 || nk < 16) return 1;
     int ks = (int)((512 + tiles - 1) / tiles);
@@ -873,10 +962,33 @@ int zero_output(const ConvParams& p, long rows, int cols, hipStream_t st) {
     return e == hipSuccess ? GCSSL_OK : (int)e;
 }
 
+// 256-row tiles, bf16 LDS-DMA path only: 8 waves as 4 (M) x 2 (N), so a wave owns 64x64 (or 64x32) outputs and issues
+// 16 (8) MFMAs per K step against a fixed per-step cost (barrier skew, DMA issue, fragment reads) of ~750 cycles --
+// measured with s_memtime (tools/trace_conv.py): with 32x32 wave tiles that fixed cost is 5x the MFMA time.
+// 144 KB (120 KB) of LDS: one workgroup per CU, two waves per SIMD.
+const char* forced_tile() {
+    static const char* v = getenv("GCSSL_FORCE_TILE");       // "256x128", "256x64", "128x128", "128x64", "64x64": experiments
+    return v;
+}
+template <int BM, int BN, int MODE>
+int launch_big(const ConvParams& p, hipStream_t st) {
+    const int ncols = MODE == 0 ? p.Cout : p.Cin;
+    dim3 grid((p.M + BM - 1) / BM, (ncols + BN - 1) / BN, (MODE == 1 ? 4 : 1) * (p.ksplit > 1 ? p.ksplit : 1));
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, MODE, 4, 2, false>), grid, dim3(512), 0, st, p);
+    return gcssl_launch_status();
+}
+
 template <typename T>
 int dispatch_fwd(ConvParams p, hipStream_t st) {
+    if (std::is_same<T, bf16_t>::value && use_dma() && p.Cin >= 64) {
+        const char* f = forced_tile();
+        if (f && !strcmp(f, "256x128") && p.Cout >= 128) return launch_big<256, 128, 0>(p, st);
+        if (f && !strcmp(f, "256x64")) return launch_big<256, 64, 0>(p, st);
+        if (f && !strcmp(f, "128x128") && p.Cout >= 128) return launch_fwd<T, 128, 128>(p, st);
+        if (f && !strcmp(f, "128x64")) return launch_fwd<T, 128, 64>(p, st);
+    }
     const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-    if (p.Cout >= 128 && t128 >= tile_threshold()) return launch_fwd<T, 128, 128>(p, st);
+    if (p.Cout >= 128 && t128 >= tile128_threshold()) return launch_fwd<T, 128, 128>(p, st);
     if (p.Cout >= 64 && (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64) >= tile_threshold()) return launch_fwd<T, 128, 64>(p, st);
     const long t64 = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64);
     const int nk = 16 * p.Cin / BKOf<T>::v;
@@ -891,8 +1003,15 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
 }
 template <typename T>
 int dispatch_dgrad(ConvParams p, hipStream_t st) {
+    if (std::is_same<T, bf16_t>::value && use_dma() && p.Cin >= 64) {
+        const char* f = forced_tile();
+        if (f && !strcmp(f, "256x128") && p.Cin >= 128) return launch_big<256, 128, 1>(p, st);
+        if (f && !strcmp(f, "256x64")) return launch_big<256, 64, 1>(p, st);
+        if (f && !strcmp(f, "128x128") && p.Cin >= 128) return launch_dgrad<T, 128, 128>(p, st);
+        if (f && !strcmp(f, "128x64")) return launch_dgrad<T, 128, 64>(p, st);
+    }
     const long t128 = 4L * ((p.M + 127) / 128) * ((p.Cin + 127) / 128);
-    if (p.Cin >= 128 && t128 >= tile_threshold()) return launch_dgrad<T, 128, 128>(p, st);
+    if (p.Cin >= 128 && t128 >= tile128_threshold()) return launch_dgrad<T, 128, 128>(p, st);
     if (p.Cin >= 64 && 4L * ((p.M + 127) / 128) * ((p.Cin + 63) / 64) >= tile_threshold()) return launch_dgrad<T, 128, 64>(p, st);
     const long t64 = 4L * ((p.M + 63) / 64) * ((p.Cin + 63) / 64);
     const int nk = 4 * p.Cout / BKOf<T>::v;
@@ -919,7 +1038,7 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
     if (Cout < 64 || ldx < Cin || ldy < Cout || (gscale && group_n <= 0)) return GCSSL_EBADSHAPE;
     const int kv = dtype == GCSSL_F32 ? 4 : 8;
     if (ldx % kv || !aligned16(x) || !aligned16(wf)) return GCSSL_EALIGN;
-    ConvParams p{}; p.x = x; p.w = wf; p.y = y; p.bias = bias; p.gscale = gscale; p.group_n = group_n;
+    ConvParams p{}; p.x = x; p.w = wf; p.y = y; p.bias = bias; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
     p.ldx = ldx; p.ldy = ldy; p.act = act; p.out_f32 = out_f32;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)Cout * 16 * Cin, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
@@ -938,7 +1057,7 @@ int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, c
     if (Cout < 8 || lddy < Cout || lddx < Cin || (gscale && group_n <= 0)) return GCSSL_EBADSHAPE;
     const int kv = dtype == GCSSL_F32 ? 4 : 8;
     if (lddy % kv || !aligned16(dy) || !aligned16(wt)) return GCSSL_EALIGN;
-    ConvParams p{}; p.x = dy; p.w = wt; p.y = dx; p.gscale = gscale; p.group_n = group_n;
+    ConvParams p{}; p.x = dy; p.w = wt; p.y = dx; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
     p.ldx = lddy; p.ldy = lddx; p.out_f32 = out_f32;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     if (!fill_bytes(p, (size_t)N * (Hi / 2) * (Wi / 2) * lddy, (size_t)Cin * 16 * Cout, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
@@ -1046,8 +1165,8 @@ int gcssl_prep_conv_weights(int dtype, int nl, const float* const* w, void* cons
         const size_t t = (size_t)Cout[i] * 16 * CinP[i];
         if (t > mx) mx = t;
     }
-    unsigned gx = (unsigned)((mx + 255) / 256); if (gx > 1024) gx = 1024;
-    dim3 grid(gx, nl);
+    unsigned gx = (unsigned)((mx + 4095) / 4096); if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;     // one 4096-element tile per pass
+    dim3 grid(gx, nl, 2);
     if (dtype == GCSSL_F32) hipLaunchKernelGGL(prep_weight_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, b);
     else if (dtype == GCSSL_BF16) hipLaunchKernelGGL(prep_weight_batch_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, b);
     else return GCSSL_EBADDTYPE;

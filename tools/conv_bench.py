@@ -1,7 +1,8 @@
 """Standalone launcher of ONE conv configuration (for rocprofv3 --pmc / timing experiments).
 usage: python tools/conv_bench.py {fwd|dgrad|wgrad} N Hi Cin Cout [dtype] [reps]"""
 import importlib, sys, time, torch
-sys.path.insert(0, '.')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 ops = importlib.import_module("gan-calibrated-semi-supervised-learning_amd.ops")
 kind, N, Hi, Cin, Cout = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 dt = torch.bfloat16 if (len(sys.argv) < 7 or sys.argv[6] == "bf16") else torch.float32
