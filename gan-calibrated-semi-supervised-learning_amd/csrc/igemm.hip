@@ -949,10 +949,14 @@ long tile128_threshold() {
     return v;
 }
 
+int ksplit_max() {
+    static int v = [] { const char* e = getenv("GCSSL_KSPLIT_MAX"); return e ? atoi(e) : 8; }();
+    return v;
+}
 int pick_ksplit(long tiles, int nk, bool allowed) {
-    if (!allowed || tiles >= 384 || nk < 16) return 1;
+    if (!allowed || tiles >= 384 || nk < 16 || ksplit_max() <= 1) return 1;
     int ks = (int)((512 + tiles - 1) / tiles);
-    if (ks > 8) ks = 8;
+    if (ks > ksplit_max()) ks = ksplit_max();
     while (ks > 1 && nk / ks < 8) --ks;
     return ks;
 }

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 // generator head  cgan/models.py:118-123,139-141: mean over H*W -> Linear(64,4) -> tanh -> * delta_scale
 // =========================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void pool_fc_tanh_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ pool_sum,
+__global__ __launch_bounds__(256) void pool_fc_tanh_kernel(const T* __restrict__ x, int ldx, float* __restrict__ pool_sum,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias, float scale, float* __restrict__ pooled,
                                                           float* __restrict__ traw, float* __restrict__ delta, int HW) {
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void pool_fc_tanh_kernel(const T* __restrict__
     const int n = blockIdx.x, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     float s = 0.f;
     if (pool_sum) {                                   // sums already accumulated by gcssl_in_act_fwd(pool=...)
-        if (ty == 0) s = pool_sum[(size_t)n * 64 + tx];
+        if (ty == 0) { s = pool_sum[(size_t)n * 64 + tx]; pool_sum[(size_t)n * 64 + tx] = 0.f; }   // consume and clear
     } else {
         const T* xp = x + (size_t)n * HW * ldx + tx;
         for (int p = ty; p < HW; p += 4) s += Elem<T>::ld(xp + (size_t)p * ldx);
@@ -509,6 +509,18 @@ __global__ void mask_gen_kernel(uint8_t* __restrict__ out, size_t n, uint64_t se
     } else {
         out[n8 * 8 + (i - n8)] = (uint8_t)((x >> 40) & 1);
     }
+}
+
+// uniform [0,1) floats from the same counter-based hash: the interpolation weights alpha of cgan/losses.py:199
+__global__ void uniform_gen_kernel(float* __restrict__ out, size_t n, uint64_t seed, const double* counter) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t x = (uint64_t)i + seed * 0x9E3779B97F4A7C15ull + (counter ? (uint64_t)counter[0] * 0xD1B54A32D192ED03ull : 0ull);
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    out[i] = (float)(x >> 40) * (1.0f / 16777216.0f);              // 24 random bits -> [0, 1), exactly representable
 }
 
 // mean of each of `groups` equal chunks of x
@@ -671,7 +683,7 @@ int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* stat
     return gcssl_launch_status();
 }
 
-int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, const float* pool_sum, const float* w, const float* bias,
+int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, float* pool_sum, const float* w, const float* bias,
                            float scale, float* pooled, float* traw, float* delta, int B, int HW, int C, void* stream) {
     if ((!x && !pool_sum) || !w || !bias || !pooled || !traw || !delta) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
@@ -703,6 +715,13 @@ int gcssl_dropout_mask_gen(uint8_t* out, long n, unsigned long long seed, const 
     if (n <= 0) return GCSSL_EBADSHAPE;
     if (((uintptr_t)out) & 7) return GCSSL_EALIGN;
     hipLaunchKernelGGL(mask_gen_kernel, GRID1(n / 8 + (n & 7)), out, (size_t)n, (uint64_t)seed, counter);
+    return gcssl_launch_status();
+}
+
+int gcssl_uniform_gen(float* out, long n, unsigned long long seed, const double* counter, void* stream) {
+    if (!out) return GCSSL_ENULL;
+    if (n <= 0) return GCSSL_EBADSHAPE;
+    hipLaunchKernelGGL(uniform_gen_kernel, GRID1(n), out, (size_t)n, (uint64_t)seed, counter);
     return gcssl_launch_status();
 }
 

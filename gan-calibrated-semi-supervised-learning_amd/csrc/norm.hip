@@ -700,8 +700,12 @@ int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float
         return gcssl_launch_status();
     }
     dim3 grid(C / CW, N, (HW + SMALL_HW - 1) / SMALL_HW);
-    hipMemsetAsync(mean, 0, sizeof(float) * (size_t)N * C, st);
-    hipMemsetAsync(rstd, 0, sizeof(float) * (size_t)N * C, st);
+    if (rstd == mean + (size_t)N * C) {                      // back-to-back buffers (the engine's): one fill
+        hipMemsetAsync(mean, 0, sizeof(float) * 2 * (size_t)N * C, st);
+    } else {
+        hipMemsetAsync(mean, 0, sizeof(float) * (size_t)N * C, st);
+        hipMemsetAsync(rstd, 0, sizeof(float) * (size_t)N * C, st);
+    }
     hipLaunchKernelGGL(in_stats_kernel, grid, dim3(CGN * RGN), 0, st, z, ldz, mean, rstd, HW, C);
     hipLaunchKernelGGL(in_finalize_kernel, dim3((unsigned)(((size_t)N * C + 255) / 256)), dim3(256), 0, st, z, ldz, mean, rstd, N, HW, C);
     if (dtype == GCSSL_F32) hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(CGN * RGN), 0, st, z, ldz, (float*)a, lda, mean, rstd, mask, pool, HW, C, act);

@@ -109,6 +109,7 @@ class StepEngine:
         self._d_dirty = True
         self._g_dirty = True
         self._prep_d_batch = self._prep_g_batch = None
+        self.alpha_buf = torch.empty(batch, **f32)
         self._red_d = self._red_g = None
         # Independent branches of the iteration run on a side HIP stream (hipGraph capture turns them into parallel
         # graph branches): spectral-norm iterations + weight re-pack beside the no-grad generator forward, and every
@@ -241,14 +242,15 @@ class StepEngine:
         self.g_u4 = act(B, S, 64)
         self.g_dmean = [None] + [torch.empty(B, c, **f32) for c in (128, 256, 512)]
         self.g_drstd = [None] + [torch.empty(B, c, **f32) for c in (128, 256, 512)]
-        self.g_umean = [torch.empty(B, c, **f32) for c in (256, 128, 64, 64)]
-        self.g_urstd = [torch.empty(B, c, **f32) for c in (256, 128, 64, 64)]
+        ustats = [torch.empty(2, B, c, **f32) for c in (256, 128, 64, 64)]      # mean | rstd back to back: one fill
+        self.g_umean = [t[0] for t in ustats]
+        self.g_urstd = [t[1] for t in ustats]
         shapes = [(B, S // 16, S // 16, 512), (B, S // 8, S // 8, 256), (B, S // 4, S // 4, 128)]
         sizes = [math.prod(sh) for sh in shapes]
         self.g_maskbuf = torch.empty(sum(sizes), device=dev, dtype=torch.uint8)      # one launch draws all three
         self.g_masks = [self.g_maskbuf[sum(sizes[:j]):sum(sizes[:j + 1])].view(sh) for j, sh in enumerate(shapes)]
         self.g_pooled = torch.empty(B, 64, **f32)
-        self.g_poolsum = torch.zeros(B, 64, **f32)                 # sum over H*W of u4, accumulated by up4's IN apply pass
+        self.g_poolsum = torch.zeros(B, 64, **f32)                 # sum over H*W of u4 (up4's IN apply pass adds, the head consumes and clears)
         self.ws = torch.empty(2 * N3 * 512, **f32)                 # scratch of the large-map InstanceNorm backward
         self.g_traw = torch.empty(B, 4, **f32)
         self.g_delta = torch.empty(B, 4, **f32)
@@ -370,7 +372,6 @@ class StepEngine:
         ops.in_act_fwd(self.g_zd[3], self.g_d4, self.g_dmean[3], self.g_drstd[3], 512, LRELU, mask=mk[0])
         ins = [self.g_d4, self.g_cat1, self.g_cat2, self.g_cat3]
         outs = [self.g_cat1[..., :256], self.g_cat2[..., :128], self.g_cat3[..., :64], self.g_u4]
-        self.g_poolsum.zero_()
         for k, (cint, coutt) in enumerate(G_UP):
             self._conv(f"G.up{k + 1}.fwd", conv_flops(B, S >> (3 - k), coutt, cint), ops.conv_dgrad, ins[k],
                        self.gu_wt[k], self.g_zu[k], coutt, cint)
@@ -425,8 +426,9 @@ class StepEngine:
         self._set_masks(masks)
         delta_det = self._g_forward(self.x0[:B], True)
         refined = refine_fn(delta_det, k)                          # :313-315
-        if alpha is None:
-            alpha = torch.rand(B, device=self.dev)                 # cgan/losses.py:199
+        if alpha is None:                                         # cgan/losses.py:199, keyed like the dropout masks
+            alpha = self.alpha_buf
+            ops.uniform_gen(alpha, self.seed * 131 + 7, self.D.state)
         ops.pack_pair(pred, refined, self.x0[B:2 * B])
         ops.pack_interp(pred, gt, refined, alpha, self.x0[I])
         self._join_side()                                         # sigma, u/v history and packed weights are ready

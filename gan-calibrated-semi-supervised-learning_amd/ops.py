@@ -250,5 +250,9 @@ def dropout_mask_gen(out, seed, counter=None):
     call("gcssl_dropout_mask_gen", out, out.numel(), int(seed), counter)
 
 
+def uniform_gen(out, seed, counter=None):
+    call("gcssl_uniform_gen", out, out.numel(), int(seed), counter)
+
+
 def group_mean(x, groups, out):
     call("gcssl_group_mean", x, groups, x.numel() // groups, out)

@@ -142,8 +142,9 @@ int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* stat
                     double eps, double max_norm, int write_clipped, void* stream);
 
 /* ---- generator head (cgan/models.py:118-123,139-141) and box/EIoU loss (cgan/losses.py:19-73,99-150) ------------- */
-/* pool_sum (nullable): [B][64] sums over H*W already accumulated by gcssl_in_act_fwd(pool=...); then x is not read. */
-int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, const float* pool_sum, const float* w, const float* bias,
+/* pool_sum (nullable): [B][64] sums over H*W already accumulated by gcssl_in_act_fwd(pool=...); then x is not read and
+ * pool_sum is left ZERO for the next accumulation. */
+int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, float* pool_sum, const float* w, const float* bias,
                            float scale, float* pooled, float* traw, float* delta, int B, int HW, int C, void* stream);
 /* dw [4][64] and db [4] are accumulated atomically (caller zeroes them). */
 int gcssl_head_bwd(const float* g_delta, const float* traw, const float* pooled, const float* w, float scale, int B,
@@ -152,7 +153,11 @@ int gcssl_eiou_fwd_bwd(const float* pred_box, const float* delta, const float* d
                        float* g_delta, float* calibrated, float* loss_acc, void* stream);
 
 /* ---- misc ---------------------------------------------------------------------------------------------------------- */
+/* Bernoulli(0.5) keep-masks (nn.Dropout(0.5), cgan/models.py:106,109,110) and uniform [0,1) floats (torch.rand alpha,
+ * cgan/losses.py:199) from a counter-based hash keyed by (seed, counter[0], index); counter lives on the device so a
+ * replayed hipGraph draws fresh values; out of the mask generator must be 8-byte aligned. */
 int gcssl_dropout_mask_gen(uint8_t* out, long n, unsigned long long seed, const double* counter, void* stream);
+int gcssl_uniform_gen(float* out, long n, unsigned long long seed, const double* counter, void* stream);
 int gcssl_group_mean(const float* x, int groups, int per_group, float* out, void* stream);
 int gcssl_cast(int dtype, const float* x, void* y, long n, void* stream);
 int gcssl_uncast(int dtype, const void* x, float* y, long n, void* stream);

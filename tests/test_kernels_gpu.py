@@ -362,6 +362,18 @@ def test_generator_head_and_eiou(ops):
     assert rel_err(g.cpu(), fix["hybrid_grad_delta"]) < 1e-4
 
 
+def test_uniform_gen(ops):
+    u = torch.empty(1 << 18, device="cuda")
+    ops.uniform_gen(u, 77)
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+    assert abs(float(u.mean()) - 0.5) < 5e-3 and abs(float(u.var()) - 1.0 / 12) < 2e-3
+    ctr = torch.tensor([5.0], device="cuda", dtype=torch.float64)
+    u2 = torch.empty_like(u); u3 = torch.empty_like(u)
+    ops.uniform_gen(u2, 77, ctr); ops.uniform_gen(u3, 77, ctr)
+    assert torch.equal(u2, u3) and not torch.equal(u, u2)
+    assert abs(float(torch.corrcoef(torch.stack([u, u2]))[0, 1])) < 1e-2
+
+
 def test_dropout_mask_gen(ops):
     m = torch.empty(1 << 20, device="cuda", dtype=torch.uint8)
     ops.dropout_mask_gen(m, 1234)
