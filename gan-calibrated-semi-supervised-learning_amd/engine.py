@@ -190,9 +190,17 @@ class StepEngine:
             self.gu_wf.append(torch.empty(cint, 16, coutt, device=dev, dtype=T))
             self.gu_wt.append(torch.empty(coutt, 16, cint, device=dev, dtype=T))
         # ---- critic, 3B batch
-        self.x0 = act(N3, S, 8)
+        # The operands of the two weight-gradient contributions of a critic step -- the 3B-sample backward (x = input
+        # activations, dy = dzs) and the reverse of the B-sample GP chain (x = adjoint activations gt_a, dy = gb_zs) --
+        # sit back to back in 4B-sample buffers, so ONE wgrad per layer contracts over both: half the launches, half the
+        # split-K slabs to reduce.
+        N4 = 4 * B
+        x4 = act(N4, S, 8)
+        self.x0, self.gt_x = x4[:N3], x4[N3:]
         sizes = [S // 2, S // 4, S // 8, S // 16]
-        self.d_a = [act(N3, s, c) for s, (_, c) in zip(sizes, D_CH)]
+        self.d_a4 = [act(N4, s, c) for s, (_, c) in zip(sizes, D_CH)]
+        self.d_a = [t[:N3] for t in self.d_a4]
+        self.d_x4 = [x4] + self.d_a4[:3]                                      # wgrad x operand of layer l
         # pre-InstanceNorm tensors are fp32 in both modes (z - mean(z) over 4..64 elements cancels a bf16 mantissa)
         self.d_z = [None] + [act(N3, s, c, torch.float32) for s, (_, c) in zip(sizes[1:], D_CH[1:])]
         self.d_mean = [None] + [torch.empty(N3, c, **f32) for _, c in D_CH[1:]]
@@ -204,17 +212,17 @@ class StepEngine:
         # MFMA (gb_zs, gt_a, dzs) are in the compute dtype
         F32 = torch.float32
         self.gb_a = [act(B, s, c, F32) for s, (_, c) in zip(sizes, D_CH)]     # d out / d a_l
-        self.gb_zs = [act(B, s, c) for s, (_, c) in zip(sizes, D_CH)]         # (d out / d z_l) * isig
+        self.d_dzs4 = [act(N4, s, c) for s, (_, c) in zip(sizes, D_CH)]       # [3B: dzs of the batched backward | B: gb_zs]
+        self.gb_zs = [t[N3:] for t in self.d_dzs4]                            # (d out / d z_l) * isig
         self.gb_x0 = torch.empty(B, S, S, 8, **f32)
         self.gp_nrm = torch.empty(B, **f32)
         self.gp_coef = torch.empty(B, **f32)
-        self.gt_x = act(B, S, 8)
         self.gt_z = [act(B, s, c, F32) for s, (_, c) in zip(sizes, D_CH)]
-        self.gt_a = [act(B, s, c) for s, (_, c) in zip(sizes, D_CH)]
+        self.gt_a = [t[N3:] for t in self.d_a4]
         self.zt = [None] + [act(B, s, c, F32) for s, (_, c) in zip(sizes[1:], D_CH[1:])]
         # backward of the 3B forward
         self.d_da = [act(N3, s, c, F32) for s, (_, c) in zip(sizes, D_CH)]
-        self.d_dzs = [act(N3, s, c) for s, (_, c) in zip(sizes, D_CH)]
+        self.d_dzs = [t[:N3] for t in self.d_dzs4]
         # scalars: [0:12] cdot[layer][group] = <dW_sn_k, W_orig>/sigma_k^2 (spectral-norm quotient rule), [12] gp_sum, [13] eiou acc, [14:17] group means, [17] wgan-G mean
         self.scal = torch.zeros(32, **f32)
         self.cdot = self.scal[0:12].view(4, 3)
@@ -227,8 +235,7 @@ class StepEngine:
         for l, (cin, cout) in enumerate(D_CH):
             hi = S >> l
             cp = _pad8(cin)
-            nc = ops.wgrad_splits(B, hi, hi, cp, cout)
-            nf = ops.wgrad_splits(N3, hi, hi, cp, cout)
+            nc, nf = 0, ops.wgrad_splits(N4, hi, hi, cp, cout)
             self.d_ns.append((nc, nf))
             self.d_slab.append(torch.empty(nc + nf, cout, 16, cp, **f32))
         # ---- generator (B samples)
@@ -453,8 +460,7 @@ class StepEngine:
             fl = conv_flops(B, S >> l, cin, cout)
             self._conv(f"D.c{l + 1}.gp_rev_fwd", fl, ops.conv_fwd, src, self.d_wf[l], self.gt_z[l], cp, cout,
                        gscale=isig[l, 2:3], group_n=B)
-            self._on_side(lambda src=src, l=l, cp=cp, cout=cout, fl=fl: self._conv(
-                f"D.c{l + 1}.gp_rev_wgrad", fl, ops.conv_wgrad, src, self.gb_zs[l], self.d_slab[l], cp, cout))
+            # (the weight gradient of this chain, src x gb_zs[l], is contracted together with the batched backward's below)
             if l == 0:
                 ops.dot_accum(self.gb_zs[0], self.gt_z[0], 64, self.cdot[0, 2:3])
                 ops.act_bwd(self.gt_z[0], self.d_a[0][I], self.gt_a[0], 64)
@@ -481,12 +487,10 @@ class StepEngine:
             else:
                 ops.act_bwd(self.d_da[0], self.d_a[0], self.d_dzs[0], 64, gscale=isig[0], group_n=B, bias=bias,
                             dbias=gbias, cdot=self.cdot[0])
-            nc, nf = self.d_ns[l]
-            xin = self.x0 if l == 0 else self.d_a[l - 1]
             fl = conv_flops(N3, S >> l, cin, cout)
 
-            def wgrad_branch(l=l, cout=cout, cp=cp, nc=nc, xin=xin, fl=fl):
-                self._conv(f"D.c{l + 1}.wgrad", fl, ops.conv_wgrad, xin, self.d_dzs[l], self.d_slab[l][nc:], cp, cout)
+            def wgrad_branch(l=l, cout=cout, cp=cp, fl4=conv_flops(4 * B, S >> l, cin, cout)):
+                self._conv(f"D.c{l + 1}.wgrad", fl4, ops.conv_wgrad, self.d_x4[l], self.d_dzs4[l], self.d_slab[l], cp, cout)
             self._on_side(wgrad_branch)                           # beside the dgrad -> norm-backward chain
             if l > 0:
                 self._conv(f"D.c{l + 1}.dgrad", fl, ops.conv_dgrad, self.d_dzs[l], self.d_wt[l], self.d_da[l - 1], cin, cout)
