@@ -152,6 +152,22 @@ int gcssl_head_bwd(const float* g_delta, const float* traw, const float* pooled,
 int gcssl_eiou_fwd_bwd(const float* pred_box, const float* delta, const float* delta_true, int B, float lambda_iou,
                        float* g_delta, float* calibrated, float* loss_acc, void* stream);
 
+/* ---- re-crop stage (next row f1): get_refined_patch_batch, cgan/cgan_train_enhanced.py:37-137 ---------------------
+ * atlas: device bytes of RGB (HWC, uint8) images; image i starts at img_off[i] and is img_w[i] x img_h[i]; sample n
+ * uses image img_idx[n].  refined_box / pred_box: [B][4] normalised (cx,cy,w,h) fp32 (refined = apply_delta_to_bbox(
+ * pred, delta, training=False), e.g. from gcssl_apply_delta_eval).  out: [B][3][S][S] fp32 in [-1,1].  Per sample:
+ * clamp, crop (fallback to pred_box when the refined crop is invalid, :95-104), grey padding to a square, Pillow 12.2
+ * BICUBIC resize (bit-exact), ToTensor + Normalize(0.5,0.5).  status (nullable) [B]: 0 ok, 1 predicted box used,
+ * 2 failed (the reference's except branch: fallback[n] if given, else zeros).  max_side: upper bound of any crop side
+ * in pixels (sizes the LDS and the coefficient workspace; the largest image side covers every box).  atlas_bytes: size
+ * of the atlas (< 2^31).  ws: gcssl_recrop_ws_ints(B, S, max_side) ints of scratch (per-sample coefficient tables). */
+int gcssl_recrop_ws_ints(int B, int S, int max_side);
+int gcssl_recrop_patches(const uint8_t* atlas, long atlas_bytes, const long* img_off, const int* img_w, const int* img_h,
+                         const int* img_idx, const float* refined_box, const float* pred_box, const float* fallback,
+                         float* out, int* status, int* ws, int B, int S, int max_side, void* stream);
+/* apply_delta_to_bbox(bbox, delta, training=False), cgan/losses.py:108-150, fp32. */
+int gcssl_apply_delta_eval(const float* box, const float* delta, float* out, int B, void* stream);
+
 /* ---- misc ---------------------------------------------------------------------------------------------------------- */
 /* Bernoulli(0.5) keep-masks (nn.Dropout(0.5), cgan/models.py:106,109,110) and uniform [0,1) floats (torch.rand alpha,
  * cgan/losses.py:199) from a counter-based hash keyed by (seed, counter[0], index); counter lives on the device so a
