@@ -161,6 +161,7 @@ struct ConvParams {
     int ktiles_per_split;   // wgrad; fwd/dgrad when ksplit > 1
     int ksplit;             // fwd/dgrad: K is split over ksplit workgroups that atomically add into a zeroed fp32 output
     unsigned x_bytes, w_bytes;   // extents of the two operand buffers (buffer-load bounds; < 2^31)
+    unsigned y_bytes;            // extent of the output (buffer-store bounds of the persistent kernel); 0 = unknown/too large
 };
 
 // ------------------------------------------------------------------------------------------
@@ -677,6 +678,199 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// Persistent form of conv_dma_kernel for layers with more tiles than resident workgroups (G.up4, D.c1/c2: 768-2048
+// tiles of 8-16 K steps).  There a workgroup's life is 1/4 gather setup + first-tile latency, 1/2 K loop, 1/4 store tail
+// (s_memtime stamps), and every round of workgroups pays all three.  Here a workgroup walks tiles
+// t, t+G, t+2G, ... and the DMA ring never drains: the last two K steps of a tile already fetch the first two of the
+// next one (its gather offsets are computed while the current tile's loads are in flight), and the epilogue stores are
+// not waited for.  vmcnt bookkeeping across the tile boundary: loads, stores and LDS-DMA retire in issue order, so
+//   before the epilogue    vmcnt(NL)        -> step 0 of the next tile has landed (its step 1 may be in flight)
+//   next tile, step 1      vmcnt(NL + NST)  -> skips this wave's NST epilogue stores and the step-2 loads behind it
+//   next tile, step >= 2   vmcnt(NL)        -> as inside a tile (the stores are older and therefore complete)
+// which needs a FIXED number of store instructions per tile: the epilogue is branch-free buffer stores whose
+// out-of-range lanes carry an out-of-bounds offset (dropped by the hardware, still counted).  No split-K here.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int MODE, int WM, int WN, bool SMALLK = false>
+__global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvParams p, int tiles_m, int tiles_n, int total_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef bf16_t T;
+    constexpr int NTH = WM * WN * 64;
+    constexpr int BK = 64, ES = 2, KV = 8, CH = 8, RPT = NTH / CH;
+    constexpr int NVA = BM / RPT, NVB = BN / RPT, NL = NVA + NVB;
+    static_assert(NVA >= 1 && NVB >= 1, "tile too small for this many waves");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NST = TM * TN * 16;                                    // epilogue store instructions per wave per tile
+    static_assert(NL + NST <= 63, "vmcnt is a 6-bit counter");
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+    const int Ho = p.Hi >> 1, Wo = p.Wi >> 1;
+    const int K = MODE == 0 ? 16 * p.Cin : 4 * p.Cout;
+    const int nk = K / BK;
+    const int ncols = MODE == 0 ? p.Cout : p.Cin;
+    const int row_t = tid / CH;
+    const int lc = (tid % CH) ^ ((row_t >> 1) & 7);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes), yr = make_rsrc(p.y, p.y_bytes);
+
+    struct Addr { int rowoff[NVA]; unsigned rowmask[NVA]; unsigned wrow[NVB]; int m0, n0, py, px; };
+    auto setup = [&](int tile, Addr& a) {
+        const int mx = tile % tiles_m, rest = tile / tiles_m;
+        const int ny = rest % tiles_n, cls = MODE == 1 ? rest / tiles_n : 0;
+        a.m0 = mx * BM; a.n0 = ny * BN; a.py = cls >> 1; a.px = cls & 1;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int m = a.m0 + row_t + i * RPT;
+            a.rowoff[i] = 0; a.rowmask[i] = 0;
+            if (m < p.M) {
+                const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
+                unsigned mk = 0;
+                if (MODE == 0) {
+                    const int iy0 = 2 * (rem >> p.lgWo) - 1, ix0 = 2 * (rem & (Wo - 1)) - 1;
+                    a.rowoff[i] = ((n * p.Hi + iy0) * p.Wi + ix0) * p.ldx * ES;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        if ((unsigned)(iy0 + (t >> 2)) < (unsigned)p.Hi && (unsigned)(ix0 + (t & 3)) < (unsigned)p.Wi) mk |= 1u << t;
+                } else {
+                    const int yy = (rem >> p.lgWo) + a.py, xx = (rem & (Wo - 1)) + a.px;
+                    a.rowoff[i] = ((n * Ho + yy) * Wo + xx) * p.ldx * ES;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if ((unsigned)(yy - (t >> 1)) < (unsigned)Ho && (unsigned)(xx - (t & 1)) < (unsigned)Wo) mk |= 1u << t;
+                }
+                a.rowmask[i] = mk;
+                if (!SMALLK) a.rowoff[i] += lc * KV * ES;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NVB; ++j) {
+            const int r = a.n0 + row_t + j * RPT;
+            if (MODE == 0) a.wrow[j] = r < p.Cout ? (unsigned)(r * K * ES) : OOB;
+            else a.wrow[j] = r < p.Cin ? (unsigned)(r * 16 * p.Cout * ES) : OOB;
+            if (!SMALLK && a.wrow[j] != OOB) a.wrow[j] += lc * KV * ES;
+        }
+    };
+    int vstride = NTH * 16, a_bytes = A_BYTES, stage = STAGE;
+    auto issue = [&](const Addr& a, int t, int slot) {
+        unsigned char* base = lds + slot * stage + wave * 1024;
+        int tapbit, tapoff; unsigned woff;
+        const int kb = SMALLK ? t * BK + lc * KV : t * BK;             // !SMALLK: wave-uniform -> SALU
+        if (MODE == 0) {
+            const int tap = kb >> p.lgCin, ci = kb & (p.Cin - 1);
+            tapbit = tap; tapoff = (((tap >> 2) * p.Wi + (tap & 3)) * p.ldx + ci) * ES; woff = (unsigned)(kb * ES);
+        } else {
+            const int t4 = kb >> p.lgCout, co = kb & (p.Cout - 1);
+            const int ty = t4 >> 1, tx = t4 & 1;
+            const int tap = (1 - a.py + 2 * ty) * 4 + (1 - a.px + 2 * tx);
+            tapbit = t4; tapoff = (co - (ty * Wo + tx) * p.ldx) * ES; woff = (unsigned)((tap * p.Cout + co) * ES);
+        }
+#pragma unroll
+        for (int i = 0; i < NVA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_p)(base + i * vstride), 16,
+                ((a.rowmask[i] >> tapbit) & 1u) ? (unsigned)(a.rowoff[i] + tapoff) : OOB, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NVB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_p)(base + a_bytes + j * vstride), 16, a.wrow[j] + woff, 0, 0, 0);
+    };
+    auto frag = [&](const unsigned char* tile, int row0, int kstep) -> bf16x8 {
+        const int row = row0 + (lane & 31), c = kstep * 2 + (lane >> 5);
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)));
+    };
+
+    int tile = blockIdx.x;
+    Addr cur, nxt;
+    setup(tile, cur);
+    issue(cur, 0, 0);
+    issue(cur, 1, 1);                                                    // nk >= 2 for every layer that gets here
+    int slot = 0;
+    bool first = true;
+    while (true) {
+        const int next_tile = tile + (int)gridDim.x;
+        const bool has_next = next_tile < total_tiles;
+        if (has_next) setup(next_tile, nxt);                             // VALU work under the loads already in flight
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int t = 0; t < nk; ++t) {
+            const bool younger = (t + 1 < nk) || has_next;               // is the following step's tile in flight?
+            if (t == 0 && !first) { /* waited for before the previous epilogue */ }
+            else if (t == 1 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL + NST) : "memory");
+            else if (younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const int s2 = slot == 0 ? 2 : slot - 1;                      // slot of step t+2 == slot of step t-1
+            if (t + 2 < nk) issue(cur, t + 2, s2);
+            else if (has_next) issue(nxt, t + 2 - nk, s2);
+            const unsigned char* At = lds + slot * STAGE;
+            const unsigned char* Bt = At + A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = frag(At, wm0 + 32 * i, kk);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = frag(Bt, wn0 + 32 * j, kk);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
+            }
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+        // step 0 of the next tile must have landed before this wave's stores enter the queue behind it
+        if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        // ---- epilogue: loads first (bias, 1/sigma of the row's sample group), then exactly NST buffer stores
+        float bcol[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = cur.n0 + wn0 + 32 * j + (lane & 31);
+            bcol[j] = (MODE == 0 && p.bias && col < ncols) ? p.bias[col] : 0.f;
+        }
+        float sc[TM][16];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = cur.m0 + wm0 + 32 * i + crow(r, lane);
+                sc[i][r] = 1.f;
+                if (p.gscale && m < p.M) sc[i][r] = p.gscale[(int)(((float)(m >> p.lgHoWo) + 0.5f) * p.inv_group_n)];
+            }
+        if (p.gscale || (MODE == 0 && p.bias)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // see note below
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = cur.m0 + wm0 + 32 * i + crow(r, lane);
+                unsigned pix = (unsigned)m;
+                if (MODE == 1) {
+                    const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
+                    const int iy = 2 * (rem >> p.lgWo) + cur.py, ix = 2 * (rem & (Wo - 1)) + cur.px;
+                    pix = (unsigned)((n * p.Hi + iy) * p.Wi + ix);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = cur.n0 + wn0 + 32 * j + (lane & 31);
+                    const bool ok = m < p.M && col < ncols;
+                    float v = acc[i][j][r] * sc[i][r] + bcol[j];
+                    if (MODE == 0 && p.act == 1) v = lrelu_f(v);
+                    const unsigned e = pix * (unsigned)p.ldy + (unsigned)col;
+                    if (p.out_f32) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ok ? e * 4u : OOB, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_bf16_bits(v), yr, ok ? e * 2u : OOB, 0, 0);
+                }
+            }
+        if (!has_next) break;
+        cur = nxt; tile = next_tile; first = false;
+    }
+#endif
+}
+
 // sum the split-K slabs, apply the spectral-norm rank-1 corrections, write PyTorch layout
 //   dw[co][ci][tap] (+)= sum_s slab[s][co][tap][ci]  - sum_k coef[k]*cscale[k] u_k[co] v_k[ci*16+tap]
 // One workgroup = one co x 64 ci x 16 taps: slab reads are coalesced along ci, the [tap][ci] -> [ci][tap] transpose
@@ -801,8 +995,50 @@ template <int MODE> struct Dma8<128, 64, MODE> {
         return true;
     }
 };
+// persistent form: only where there are clearly more tiles than resident workgroups (otherwise it IS the plain kernel)
+int persist_mode() {
+    static int v = [] { const char* e = getenv("GCSSL_PERSIST"); return e ? atoi(e) : 3; }();   // bit 0: Cin >= 64 layers, bit 1: 8-channel layers
+    return v;
+}
+int cu_count() {
+    static int v = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+    return v;
+}
+template <int BM, int BN, int MODE> struct Persist {
+    static bool launch(const ConvParams&, int, int, int, int, hipStream_t) { return false; }
+};
+template <int MODE> struct Persist<128, 64, MODE> {
+    static bool launch(const ConvParams& p, int g, int tm, int tn, int total, hipStream_t st) {
+        hipLaunchKernelGGL((conv_dma_persist_kernel<128, 64, MODE, 4, 2>), dim3(g), dim3(512), 0, st, p, tm, tn, total);
+        return true;
+    }
+};
+template <int MODE> struct Persist<64, 64, MODE> {
+    static bool launch(const ConvParams& p, int g, int tm, int tn, int total, hipStream_t st) {
+        hipLaunchKernelGGL((conv_dma_persist_kernel<64, 64, MODE, 2, 2>), dim3(g), dim3(256), 0, st, p, tm, tn, total);
+        return true;
+    }
+};
+template <int BM, int BN, int MODE> struct PersistSmallK {     // 8-channel first layers (K = 128: two K steps per tile)
+    static bool launch(const ConvParams&, int, int, int, int, hipStream_t) { return false; }
+};
+template <> struct PersistSmallK<128, 64, 0> {
+    static bool launch(const ConvParams& p, int g, int tm, int tn, int total, hipStream_t st) {
+        hipLaunchKernelGGL((conv_dma_persist_kernel<128, 64, 0, 2, 2, true>), dim3(g), dim3(256), 0, st, p, tm, tn, total);
+        return true;
+    }
+};
 template <int BM, int BN, int MODE>
 void launch_dma(const ConvParams& p, dim3 grid, bool smallk, hipStream_t st) {
+    if (persist_mode() && p.ksplit <= 1 && p.y_bytes && dma_waves() == 8) {
+        const int nk = (MODE == 0 ? 16 * p.Cin : 4 * p.Cout) / 64;
+        const int resident = (160 * 1024) / (3 * (BM + BN) * 128);
+        const int slots = cu_count() * resident, total = (int)(grid.x * grid.y * grid.z);
+        if (nk >= 2 && total > slots + slots / 4) {
+            if (!smallk && Persist<BM, BN, MODE>::launch(p, slots, (int)grid.x, (int)grid.y, total, st)) return;
+            if (smallk && (persist_mode() & 2) && PersistSmallK<BM, BN, MODE>::launch(p, slots, (int)grid.x, (int)grid.y, total, st)) return;
+        }
+    }
     if (dma_waves() == 8 && !smallk && Dma8<BM, BN, MODE>::launch(p, grid, st)) return;
     if (smallk) {
         hipLaunchKernelGGL((conv_dma_kernel<BM, BN, MODE, 2, 2, true>), grid, dim3(256), 0, st, p);
@@ -949,6 +1185,10 @@ long tile128_threshold() {
     return v;
 }
 
+int split_tile() {
+    static int v = [] { const char* e = getenv("GCSSL_SPLIT_TILE"); return e ? atoi(e) : 64; }();
+    return v;
+}
 int ksplit_max() {
     static int v = [] { const char* e = getenv("GCSSL_KSPLIT_MAX"); return e ? atoi(e) : 8; }();
     return v;
@@ -997,7 +1237,20 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
     const long t64 = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64);
     const int nk = 16 * p.Cin / BKOf<T>::v;
     const bool f32out = p.out_f32 || std::is_same<T, float>::value;
-    p.ksplit = pick_ksplit(t64, nk, f32out && p.act == 0);
+    const bool split_ok = f32out && p.act == 0;
+    // small-M layers: split K.  With the LDS-DMA kernels a K step costs about the same for a 128x64 tile (8 waves) as
+    // for a 64x64 one (4 waves), so prefer half as many, twice as deep... twice as WIDE workgroups with twice the split
+    if (split_tile() == 128 && std::is_same<T, bf16_t>::value && use_dma() && p.Cin >= 64 && p.Cout >= 64 && p.M >= 128) {
+        const long t = (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
+        p.ksplit = pick_ksplit(t, nk, split_ok);
+        if (p.ksplit > 1) {
+            p.ktiles_per_split = (nk + p.ksplit - 1) / p.ksplit;
+            int rc = zero_output(p, p.M, p.Cout, st);
+            if (rc) return rc;
+            return launch_fwd<T, 128, 64>(p, st);
+        }
+    }
+    p.ksplit = pick_ksplit(t64, nk, split_ok);
     if (p.ksplit > 1) {
         p.ktiles_per_split = (nk + p.ksplit - 1) / p.ksplit;
         int rc = zero_output(p, p.M, p.Cout, st);
@@ -1020,6 +1273,16 @@ int dispatch_dgrad(ConvParams p, hipStream_t st) {
     const long t64 = 4L * ((p.M + 63) / 64) * ((p.Cin + 63) / 64);
     const int nk = 4 * p.Cout / BKOf<T>::v;
     const bool f32out = p.out_f32 || std::is_same<T, float>::value;
+    if (split_tile() == 128 && std::is_same<T, bf16_t>::value && use_dma() && p.Cin >= 64 && p.Cout >= 64 && p.M >= 128) {
+        const long t = 4L * ((p.M + 127) / 128) * ((p.Cin + 63) / 64);
+        p.ksplit = pick_ksplit(t, nk, f32out);
+        if (p.ksplit > 1) {
+            p.ktiles_per_split = (nk + p.ksplit - 1) / p.ksplit;
+            int rc = zero_output(p, (long)p.N * p.Hi * p.Wi, p.Cin, st);
+            if (rc) return rc;
+            return launch_dgrad<T, 128, 64>(p, st);
+        }
+    }
     p.ksplit = pick_ksplit(t64, nk, f32out);
     if (p.ksplit > 1) {
         p.ktiles_per_split = (nk + p.ksplit - 1) / p.ksplit;
@@ -1046,6 +1309,10 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
     p.ldx = ldx; p.ldy = ldy; p.act = act; p.out_f32 = out_f32;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)Cout * 16 * Cin, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
+    {   // output extent for buffer stores: the last pixel's Cout channels end it
+        const size_t yb = (((size_t)N * (Hi / 2) * (Wi / 2) - 1) * ldy + Cout) * ((out_f32 || kv == 4) ? 4 : 2);
+        p.y_bytes = yb < 0x7FFFFFFFull ? (unsigned)yb : 0u;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GCSSL_F32) return dispatch_fwd<float>(p, st);
     if (dtype == GCSSL_BF16) return dispatch_fwd<bf16_t>(p, st);
@@ -1065,6 +1332,10 @@ int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, c
     p.ldx = lddy; p.ldy = lddx; p.out_f32 = out_f32;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     if (!fill_bytes(p, (size_t)N * (Hi / 2) * (Wi / 2) * lddy, (size_t)Cin * 16 * Cout, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
+    {
+        const size_t yb = (((size_t)N * Hi * Wi - 1) * lddx + Cin) * ((out_f32 || kv == 4) ? 4 : 2);
+        p.y_bytes = yb < 0x7FFFFFFFull ? (unsigned)yb : 0u;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GCSSL_F32) return dispatch_dgrad<float>(p, st);
     if (dtype == GCSSL_BF16) return dispatch_dgrad<bf16_t>(p, st);

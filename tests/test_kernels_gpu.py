@@ -57,6 +57,9 @@ CONV_CASES = [  # N, Hi, Cin(real), CinP, Cout
     (8, 128, 64, 64, 128),    # large M -> 128x128 tile
     (24, 32, 128, 128, 64),   # 128x64 tile
     (3, 4, 256, 256, 512),    # 4x4 -> 2x2 (D.c4 at 32x32 input)
+    (651, 16, 64, 64, 128),   # 652 fwd tiles / 2604 dgrad tiles of 128x64 (ragged last one): the persistent LDS-DMA kernel
+    (256, 32, 64, 64, 128),   # G.up4 / D.c2 shapes at the bench batch: 2048 dgrad tiles
+    (768, 32, 6, 8, 64),      # D.c1 at the bench batch: 1536 tiles of two K steps (8-channel persistent form)
 ]
 
 
