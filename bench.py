@@ -22,6 +22,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 PKG = "gan-calibrated-semi-supervised-learning_amd"
 
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense, /opt/skills/guides/MI355X_MICROARCH.md:42-43
 F_D = {32: 0.0535e9, 64: 0.2141e9, 128: 0.8564e9}       # forward FLOPs / image
 F_G = {32: 0.2029e9, 64: 0.8116e9, 128: 3.2464e9}
@@ -132,26 +133,33 @@ def main():
         eng.run_iteration(*call)
     prof = eng.probe_summary()
     eng.enable_probe(False)
-    tot = {k: n * t for k, (n, t, _) in prof.items()}
+    tot = {k: n * t for k, (n, t, _, _) in prof.items()}
     if os.environ.get("GCSSL_BENCH_VERBOSE") and rank == 0:
         for k in sorted(tot, key=tot.get, reverse=True):
-            n, t, f = prof[k]
+            n, t, f, nb = prof[k]
             print(f"[probe] {k:24s} {n // args.probe_steps:3d}/iter  {t * 1e3:8.1f} us  {f / (t * 1e-3) / 1e12:8.1f} TF/s  "
-                  f"{f / 1e9:7.2f} GF", file=sys.stderr)
+                  f"{f / 1e9:7.2f} GF  {nb / 1e6:7.1f} MB  {nb / (t * 1e-3) / 1e9:7.0f} GB/s", file=sys.stderr)
     dom = max(tot, key=tot.get)
-    n_dom, ms_dom, fl_dom = prof[dom]
+    n_dom, ms_dom, fl_dom, by_dom = prof[dom]
     conv_ms = sum(tot.values()) / args.probe_steps
-    conv_flops = sum(n * f for (n, _, f) in prof.values()) / args.probe_steps
+    conv_flops = sum(n * f for (n, _, f, _) in prof.values()) / args.probe_steps
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     ach = fl_dom / (ms_dom * 1e-3) / 1e12
+    # which roof binds this kernel: time at the HBM peak for its algorithmic bytes vs time at the MFMA peak for its FLOPs
+    hbm_bound = by_dom / (HBM_PEAK_GBS * 1e9) > fl_dom / (peak * 1e12)
+    ach_gbs = by_dom / (ms_dom * 1e-3) / 1e9
     # HBM bytes per launch of the dominant kernel: from the committed rocprofv3 --pmc passes (FETCH_SIZE x2-corrected +
-    # WRITE_SIZE, profiles/round1_pmc_G_up4_fwd.json) when this run is the configuration they were taken on, else null
+    # WRITE_SIZE, profiles/round1_pmc_G_up4_fwd_persistent.json) when this run is the configuration they were taken on, else null
     traffic = None
-    pmc = ROOT / "profiles" / "round1_pmc_G_up4_fwd.json"
+    pmc = ROOT / "profiles" / "round1_pmc_G_up4_fwd_persistent.json"
     if dom == "G.up4.fwd" and (B, S, args.dtype) == (256, 32, "bf16") and pmc.exists():
         traffic = json.loads(pmc.read_text())["hbm_bytes_per_launch"]
-    roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+    roofline = dict(bound="hbm" if hbm_bound else "mfma", kernel=dom,
+                    achieved=round(ach_gbs if hbm_bound else ach, 2), peak=HBM_PEAK_GBS if hbm_bound else peak,
+                    unit="GB/s" if hbm_bound else "TFLOP/s", frac=round(ach_gbs / HBM_PEAK_GBS if hbm_bound else ach / peak, 4),
                     traffic=traffic, launches=n_dom, avg_us=round(ms_dom * 1e3, 2),
+                    algorithmic=dict(flops=fl_dom, bytes=by_dom, tflops=round(ach, 2), gbs=round(ach_gbs, 1),
+                                     mfma_frac=round(ach / peak, 4), hbm_frac=round(ach_gbs / HBM_PEAK_GBS, 4)),
                     all_convs=dict(tflops=round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), ms_per_iter=round(conv_ms, 3),
                                    frac=round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4)))
     flop_iter = ((12 * c + 1) * F_D[S] + (c + 3) * F_G[S]) * B * world if S in F_D else None

@@ -1218,6 +1218,11 @@ template <int BM, int BN, int MODE>
 int launch_big(const ConvParams& p, hipStream_t st) {
     const int ncols = MODE == 0 ? p.Cout : p.Cin;
     dim3 grid((p.M + BM - 1) / BM, (ncols + BN - 1) / BN, (MODE == 1 ? 4 : 1) * (p.ksplit > 1 ? p.ksplit : 1));
+    const int total = (int)(grid.x * grid.y * grid.z), slots = cu_count();          // 120-144 KB of LDS: one per CU
+    if (persist_mode() && p.ksplit <= 1 && p.y_bytes && total > slots + slots / 4) {
+        hipLaunchKernelGGL((conv_dma_persist_kernel<BM, BN, MODE, 4, 2>), dim3(slots), dim3(512), 0, st, p, (int)grid.x, (int)grid.y, total);
+        return gcssl_launch_status();
+    }
     hipLaunchKernelGGL((conv_dma_kernel<BM, BN, MODE, 4, 2, false>), grid, dim3(512), 0, st, p);
     return gcssl_launch_status();
 }

@@ -36,6 +36,19 @@ def _pad8(c: int) -> int:
     return max(8, c)
 
 
+def _algorithmic_bytes(label: str, args) -> int:
+    """Bytes a conv launch must move at least once: each operand tensor read once, the result written once (for a wgrad
+    ONE fp32 weight-gradient slab, not one per K split).  Tensors are taken from the launch's own arguments."""
+    ts = [a for a in args if isinstance(a, torch.Tensor)]
+    total = 0
+    for i, t in enumerate(ts):
+        n = t.numel() * t.element_size()
+        if label.endswith("wgrad") and t.dim() == 4 and t.dtype == torch.float32 and i == 2:
+            n //= t.shape[0]                                          # slab [nsplit][Cout][16][Cin]
+        total += n
+    return total
+
+
 class FlatParams:
     """Parameters of one network as views into one flat fp32 buffer (+ grad / Adam moments of the same shape)."""
 
@@ -154,16 +167,16 @@ class StepEngine:
         e0.record()
         fn(*args, **kw)
         e1.record()
-        rec = self.probe.setdefault(label, {"events": [], "flops": flops})
+        rec = self.probe.setdefault(label, {"events": [], "flops": flops, "bytes": _algorithmic_bytes(label, args)})
         rec["events"].append((e0, e1))
 
     def probe_summary(self):
-        """-> {label: (n_launches, mean_ms, flops_per_launch)} (synchronises)."""
+        """-> {label: (n_launches, mean_ms, flops_per_launch, algorithmic_bytes_per_launch)} (synchronises)."""
         torch.cuda.synchronize()
         out = {}
         for k, rec in (self.probe or {}).items():
             ts = [a.elapsed_time(b) for a, b in rec["events"]]
-            out[k] = (len(ts), sum(ts) / max(len(ts), 1), rec["flops"])
+            out[k] = (len(ts), sum(ts) / max(len(ts), 1), rec["flops"], rec["bytes"])
         return out
 
     # ------------------------------------------------------------------------------------------ buffers
