@@ -1214,15 +1214,22 @@ const char* forced_tile() {
     static const char* v = getenv("GCSSL_FORCE_TILE");       // "256x128", "256x64", "128x128", "128x64", "64x64": experiments
     return v;
 }
+template <int BM, int BN, int MODE> struct PersistBig {       // 256x128 has 64 epilogue stores per wave: beyond the 6-bit vmcnt
+    static bool launch(const ConvParams&, int, int, int, int, hipStream_t) { return false; }
+};
+template <int MODE> struct PersistBig<256, 64, MODE> {
+    static bool launch(const ConvParams& p, int g, int tm, int tn, int total, hipStream_t st) {
+        hipLaunchKernelGGL((conv_dma_persist_kernel<256, 64, MODE, 4, 2>), dim3(g), dim3(512), 0, st, p, tm, tn, total);
+        return true;
+    }
+};
 template <int BM, int BN, int MODE>
 int launch_big(const ConvParams& p, hipStream_t st) {
     const int ncols = MODE == 0 ? p.Cout : p.Cin;
     dim3 grid((p.M + BM - 1) / BM, (ncols + BN - 1) / BN, (MODE == 1 ? 4 : 1) * (p.ksplit > 1 ? p.ksplit : 1));
     const int total = (int)(grid.x * grid.y * grid.z), slots = cu_count();          // 120-144 KB of LDS: one per CU
-    if (persist_mode() && p.ksplit <= 1 && p.y_bytes && total > slots + slots / 4) {
-        hipLaunchKernelGGL((conv_dma_persist_kernel<BM, BN, MODE, 4, 2>), dim3(slots), dim3(512), 0, st, p, (int)grid.x, (int)grid.y, total);
-        return gcssl_launch_status();
-    }
+    if (persist_mode() && p.ksplit <= 1 && p.y_bytes && total > slots + slots / 4 &&
+        PersistBig<BM, BN, MODE>::launch(p, slots, (int)grid.x, (int)grid.y, total, st)) return gcssl_launch_status();
     hipLaunchKernelGGL((conv_dma_kernel<BM, BN, MODE, 4, 2, false>), grid, dim3(512), 0, st, p);
     return gcssl_launch_status();
 }

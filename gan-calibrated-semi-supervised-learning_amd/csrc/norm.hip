@@ -609,7 +609,8 @@ __global__ __launch_bounds__(CGN * RGN) void act_bwd_kernel(ActBwdParams q, int 
         const float* da2p = q.da2 ? q.da2 + (size_t)n * HW * q.ldda2 + c : nullptr;
         T* op = static_cast<T*>(q.dzs) + (size_t)n * HW * q.lddz + c;
         const float gs = q.gscale ? q.gscale[n / q.group_n] : 1.f;
-        for (int p = p0 + ty; p < p1; p += RGN) {
+#pragma unroll 4
+        for (int p = p0 + ty; p < p1; p += RGN) {           // unrolled: four rows' loads in flight per lane
             float av[VC], d[VC], o[VC];
             ldT4<T>(ap + (size_t)p * q.lda, av);
             ld4(dap + (size_t)p * q.ldda, d);
