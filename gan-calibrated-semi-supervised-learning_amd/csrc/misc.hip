@@ -174,41 +174,46 @@ __device__ unsigned g_sn_done[4];
 
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// s = (W t) / max(|t|, eps): one row per block, its four waves split the columns; one pass of 16-byte loads accumulates
-// both the row's dot product and |t|^2 (every block reads all of t anyway: 16 KB, L2-resident); block 0 also publishes
-// v.  960 blocks for the critic's four layers -- the 240-block form (a wave per row) left most CUs without a wave.
-// The last block of a layer to finish then closes the iteration: u = s / max(|s|, eps), sigma = u . s, and t is zeroed
-// again for the next call (every block of the layer has consumed it by then).
+// s = (W t) / max(|t|, eps): one wave per row (4 rows per block), one pass of 16-byte loads that accumulates both
+// the row's dot product and |t|^2 (every wave reads all of t anyway); block 0 also publishes v.  (One row per block -- 960 blocks -- measured
+// SLOWER, 25 vs 16 us: every block ends with an atomic on the layer's completion counter and same-address atomics
+// serialise at ~12 ns.)  The last block of a
+// layer to finish then closes the iteration: u = s / max(|s|, eps), sigma = u . s, and t is zeroed again for the next
+// call (every block of the layer has consumed it by then).
 __global__ __launch_bounds__(256) void sn_wv_kernel(SnBatch b) {
     const SnLayer L = b.l[blockIdx.y];
     __shared__ float red[4];
-    __shared__ float red2[4];
     __shared__ int last;
-    const int row = blockIdx.x;
-    if (row >= L.rows) return;
+    const int nblk = (L.rows + 3) / 4;
+    if ((int)blockIdx.x >= nblk) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
     const int c4 = (L.cols & 3) ? 0 : L.cols >> 2;          // vector part (all of it for the critic's shapes)
     const float4* t4 = reinterpret_cast<const float4*>(L.t);
-    const float4* w4 = reinterpret_cast<const float4*>(L.w + (size_t)row * L.cols);
     float q = 0.f, s = 0.f;
+    if (row < L.rows) {
+        const float4* w4 = reinterpret_cast<const float4*>(L.w + (size_t)row * L.cols);
 #pragma unroll 4
-    for (int c = threadIdx.x; c < c4; c += 256) {
-        const float4 t = t4[c], w = w4[c];
-        q += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
-        s += w.x * t.x + w.y * t.y + w.z * t.z + w.w * t.w;
+        for (int c = lane; c < c4; c += 64) {
+            const float4 t = t4[c], w = w4[c];
+            q += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+            s += w.x * t.x + w.y * t.y + w.z * t.z + w.w * t.w;
+        }
+        for (int c = c4 * 4 + lane; c < L.cols; c += 64) { const float t = L.t[c]; q += t * t; s += L.w[(size_t)row * L.cols + c] * t; }
+    } else {
+        for (int c = lane; c < L.cols; c += 64) { const float t = L.t[c]; q += t * t; }
     }
-    for (int c = c4 * 4 + threadIdx.x; c < L.cols; c += 256) { const float t = L.t[c]; q += t * t; s += L.w[(size_t)row * L.cols + c] * t; }
-    q = block_sum<4>(q, red);
-    s = block_sum<4>(s, red2);
+    q = wave_sum(q); s = wave_sum(s);
     const float inv = 1.f / fmaxf(sqrtf(q), 1e-12f);
-    if (row == 0) {
+    if (row < L.rows && lane == 0) L.s[row] = s * inv;
+    if (blockIdx.x == 0) {
         float* vh = b.v_hist + ((size_t)blockIdx.y * b.nslots + b.slot) * b.hist_stride_v;
         for (int c = threadIdx.x; c < L.cols; c += 256) { const float vv = L.t[c] * inv; L.v[c] = vv; vh[c] = vv; }
     }
-    __syncthreads();                                         // v (row 0) is written before the block counts as done
+    __syncthreads();                                         // all four rows (and v) of this block are written
     if (threadIdx.x == 0) {
-        L.s[row] = s * inv;
         __threadfence();
-        last = atomicAdd(&g_sn_done[blockIdx.y], 1u) == (unsigned)(L.rows - 1);
+        last = atomicAdd(&g_sn_done[blockIdx.y], 1u) == (unsigned)(nblk - 1);
     }
     __syncthreads();
     if (!last) return;
@@ -639,7 +644,7 @@ int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* c
     if (iterate) {
         // t is zero on entry (caller allocates it zeroed) and sn_wv_kernel leaves it zero again
         hipLaunchKernelGGL(sn_wtu_kernel, dim3((maxc + 63) / 64, nl, (maxr + 63) / 64), dim3(256), 0, st, b);
-        hipLaunchKernelGGL(sn_wv_kernel, dim3(maxr, nl), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(sn_wv_kernel, dim3((maxr + 3) / 4, nl), dim3(256), 0, st, b);
     } else {
         hipLaunchKernelGGL(sn_sigma_kernel, dim3(nl), dim3(256), 0, st, b);
     }
