@@ -51,7 +51,7 @@ __device__ __forceinline__ Rect pixel_rect(const float* box, int W, int H, bool 
 struct RecropParams {
     const uint8_t* atlas; const long* img_off; const int* img_w; const int* img_h; const int* img_idx;
     const float* refined; const float* pred; const float* fallback; float* out; int* status; int* ws;
-    int B, S, ksize_max, row_words, max_side;
+    int B, S, ksize_max, row_words, max_side, mode;
     unsigned atlas_bytes;
 };
 
@@ -61,9 +61,11 @@ __device__ __forceinline__ Crop make_crop(const RecropParams& p, int n) {
     Crop c;
     const int ii = p.img_idx[n];
     c.W = p.img_w[ii]; c.H = p.img_h[ii]; c.img = p.atlas + p.img_off[ii];
-    Rect r = pixel_rect(p.refined + 4 * n, c.W, c.H, true);
+    // mode 0: the training loop's re-crop (clamped box, validity test, fallback to the predicted box);
+    // mode 1: the dataset's _letterbox (cgan/dataset.py:104-124): the box as given, no test, no fallback
+    Rect r = pixel_rect(p.refined + 4 * n, c.W, c.H, p.mode == 0);
     c.status = 0;
-    if (r.x2 <= r.x1 || r.y2 <= r.y1 || (r.x2 - r.x1) < 10.0 || (r.y2 - r.y1) < 10.0) {       // :95
+    if (p.mode == 0 && (r.x2 <= r.x1 || r.y2 <= r.y1 || (r.x2 - r.x1) < 10.0 || (r.y2 - r.y1) < 10.0)) {       // :95
         r = pixel_rect(p.pred + 4 * n, c.W, c.H, false);
         c.status = 1;
     }
@@ -262,9 +264,10 @@ int gcssl_recrop_ws_ints(int B, int S, int max_side) {
 
 int gcssl_recrop_patches(const uint8_t* atlas, long atlas_bytes, const long* img_off, const int* img_w, const int* img_h,
                          const int* img_idx, const float* refined_box, const float* pred_box, const float* fallback,
-                         float* out, int* status, int* ws, int B, int S, int max_side, void* stream) {
-    if (!atlas || !img_off || !img_w || !img_h || !img_idx || !refined_box || !pred_box || !out || !ws) return GCSSL_ENULL;
-    if (B <= 0 || S < 2 || S > 256 || max_side < 1 || atlas_bytes <= 0 || atlas_bytes >= 0x7FFFFFFFL) return GCSSL_EBADSHAPE;
+                         float* out, int* status, int* ws, int B, int S, int max_side, int mode, void* stream) {
+    if (!atlas || !img_off || !img_w || !img_h || !img_idx || !refined_box || (mode == 0 && !pred_box) || !out || !ws) return GCSSL_ENULL;
+    if (B <= 0 || S < 2 || S > 256 || max_side < 1 || atlas_bytes <= 0 || atlas_bytes >= 0x7FFFFFFFL || (mode != 0 && mode != 1))
+        return GCSSL_EBADSHAPE;
     // worst case over the launch: a crop side of max_side pixels
     const double fs = (double)max_side / S > 1.0 ? (double)max_side / S : 1.0;
     const int ksize_max = (int)ceil(2.0 * fs) * 2 + 1;
@@ -278,7 +281,7 @@ int gcssl_recrop_patches(const uint8_t* atlas, long atlas_bytes, const long* img
         lds_set = lds;
     }
     RecropParams p{atlas, img_off, img_w, img_h, img_idx, refined_box, pred_box, fallback, out, status, ws, B, S, ksize_max, row_words,
-                   max_side, (unsigned)atlas_bytes};
+                   max_side, mode, (unsigned)atlas_bytes};
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(recrop_coeff_kernel, dim3(S, B), dim3(64), (size_t)(ksize_max + 2) * 8, st, p);
     hipLaunchKernelGGL(recrop_kernel, dim3((S + CCH - 1) / CCH, B, (S + JCH - 1) / JCH), dim3(256), lds, st, p);

@@ -160,11 +160,13 @@ int gcssl_eiou_fwd_bwd(const float* pred_box, const float* delta, const float* d
  * BICUBIC resize (bit-exact), ToTensor + Normalize(0.5,0.5).  status (nullable) [B]: 0 ok, 1 predicted box used,
  * 2 failed (the reference's except branch: fallback[n] if given, else zeros).  max_side: upper bound of any crop side
  * in pixels (sizes the LDS and the coefficient workspace; the largest image side covers every box).  atlas_bytes: size
- * of the atlas (< 2^31).  ws: gcssl_recrop_ws_ints(B, S, max_side) ints of scratch (per-sample coefficient tables). */
+ * of the atlas (< 2^31).  ws: gcssl_recrop_ws_ints(B, S, max_side) ints of scratch (per-sample coefficient tables).
+ * mode 1 = the dataset's CalibratorDataset._letterbox (cgan/dataset.py:104-124): crop refined_box as given (no clamp, no
+ * validity test, no fallback; pred_box unused), pad, resize, normalise -- the pred/gt training patches themselves. */
 int gcssl_recrop_ws_ints(int B, int S, int max_side);
 int gcssl_recrop_patches(const uint8_t* atlas, long atlas_bytes, const long* img_off, const int* img_w, const int* img_h,
                          const int* img_idx, const float* refined_box, const float* pred_box, const float* fallback,
-                         float* out, int* status, int* ws, int B, int S, int max_side, void* stream);
+                         float* out, int* status, int* ws, int B, int S, int max_side, int mode, void* stream);
 /* apply_delta_to_bbox(bbox, delta, training=False), cgan/losses.py:108-150, fp32. */
 int gcssl_apply_delta_eval(const float* box, const float* delta, float* out, int B, void* stream);
 

@@ -63,6 +63,24 @@ def reference_patch(img_np, refined_box, pred_box, size):
         return np.zeros((3, size, size), np.float32), 2
 
 
+def reference_letterbox(img_np, box, size):
+    """CalibratorDataset._letterbox + transform (cgan/dataset.py:104-124, 50-53) for one box, with Pillow."""
+    img = Image.fromarray(img_np, "RGB")
+    W, H = img.size
+    cx, cy, w, h = box
+    px, py, pw, ph = float(cx) * W, float(cy) * H, float(w) * W, float(h) * H
+    x1, y1 = max(0, px - pw / 2), max(0, py - ph / 2)
+    x2, y2 = min(W, px + pw / 2), min(H, py + ph / 2)
+    crop = img.crop((int(x1), int(y1), int(x2), int(y2)))
+    pad_w = max(crop.height - crop.width, 0)
+    pad_h = max(crop.width - crop.height, 0)
+    padding = (pad_w // 2, pad_h // 2, pad_w - pad_w // 2, pad_h - pad_h // 2)
+    crop_square = ImageOps.expand(crop, padding, fill=(128, 128, 128))
+    crop_resized = crop_square.resize((size, size), Image.BICUBIC)
+    t = torch.from_numpy(np.asarray(crop_resized, np.uint8).copy()).permute(2, 0, 1).float().div(255)
+    return ((t - 0.5) / 0.5).numpy()
+
+
 def main():
     imgs = make_images()
     rng = np.random.default_rng(99)
@@ -88,6 +106,8 @@ def main():
         res = [reference_patch(imgs[idx[i]], torch.from_numpy(refined[i]), torch.from_numpy(pred[i]), size) for i in range(n)]
         out[f"patch{size}"] = np.stack([r[0] for r in res]).astype(np.float32)
         out[f"status{size}"] = np.array([r[1] for r in res], np.int32)
+        out[f"letterbox{size}"] = np.stack([reference_letterbox(imgs[idx[i]], torch.from_numpy(refined[i]), size)
+                                            for i in range(n)]).astype(np.float32)
     np.savez_compressed(ROOT / "tests" / "golden" / "recrop.npz", **out)
     print({k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if not k.startswith("img") or k == "img_idx"})
     print("status32", np.bincount(out["status32"], minlength=3))

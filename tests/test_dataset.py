@@ -1,0 +1,151 @@
+"""Row f2: CalibratorDataset -- on-disk formats, matching, regression targets, letterbox patches
+(cgan/dataset.py:17-236).  The reference module needs torchvision (absent here), so its pure-math helpers are pinned by
+hand-computed known answers and properties, and the letterbox by Pillow-generated fixtures (tests/golden/recrop.npz)."""
+import importlib
+import math
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import recrop_oracle as R  # noqa: E402
+
+PKG = "gan-calibrated-semi-supervised-learning_amd"
+DS = importlib.import_module(PKG + ".dataset")
+
+
+def test_bbox_iou_known_answers():
+    a = torch.tensor([0.5, 0.5, 0.2, 0.2])
+    assert DS.bbox_iou(a, a) == pytest.approx(1.0)
+    assert DS.bbox_iou(a, torch.tensor([0.9, 0.9, 0.1, 0.1])) == 0.0
+    b = torch.tensor([0.6, 0.5, 0.2, 0.2])                      # half overlap in x: inter 0.1*0.2, union 0.06
+    assert DS.bbox_iou(a, b) == pytest.approx(0.02 / 0.06, rel=1e-5)
+    assert DS.bbox_iou(a, b) == pytest.approx(DS.bbox_iou(b, a))
+    assert DS.bbox_iou(torch.tensor([0.5, 0.5, 0.0, 0.0]), torch.tensor([0.5, 0.5, 0.0, 0.0])) == 0.0   # union 0
+
+
+def test_bbox2delta_known_answers():
+    pred = torch.tensor([0.5, 0.5, 0.2, 0.1])
+    d = DS.bbox2delta(pred, pred)
+    assert torch.allclose(d, torch.zeros(4))
+    gt = torch.tensor([0.52, 0.47, 0.3, 0.05])
+    norm = math.sqrt(0.2 * 0.1)
+    want = [0.02 / norm, -0.03 / norm, math.log(1.5), math.log(0.5)]
+    assert torch.allclose(DS.bbox2delta(gt, pred), torch.tensor(want), atol=1e-6)
+    tiny = torch.tensor([0.5, 0.5, 0.01, 0.01])                 # sqrt(area) = 0.01 < 0.05 -> unit 0.05
+    assert DS.bbox2delta(torch.tensor([0.55, 0.5, 0.01, 0.01]), tiny)[0] == pytest.approx(1.0, rel=1e-5)
+    wide = DS.bbox2delta(torch.tensor([0.5, 0.5, 0.9, 1e-9]), torch.tensor([0.5, 0.5, 0.01, 0.5]))
+    assert wide[2] == pytest.approx(math.log(10.0)) and wide[3] == pytest.approx(math.log(0.1))   # ratio clamps
+
+
+def _write_dataset(root: Path, with_images: bool):
+    (root / "images").mkdir(parents=True); (root / "labels_gt").mkdir(); (root / "labels_pred").mkdir()
+    rng = np.random.default_rng(3)
+    for name, (h, w) in (("a", (90, 120)), ("b", (64, 64)), ("c", (50, 70)), ("d", (40, 40))):
+        if with_images:
+            from PIL import Image
+            Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(root / "images" / f"{name}.jpg", quality=95)
+        else:
+            (root / "images" / f"{name}.jpg").write_bytes(b"")
+    (root / "labels_gt" / "a.txt").write_text("0 0.30 0.30 0.20 0.20\n0 0.70 0.70 0.30 0.30\n")
+    (root / "labels_pred" / "a.txt").write_text("0 0.32 0.31 0.22 0.18 0.9\n0 0.68 0.72 0.28 0.33 0.8\n0 0.71 0.69 0.30 0.31 0.7\n"
+                                                "0 0.10 0.90 0.05 0.05 0.6\n0 0.5 0.5 0.1 0.1\n")        # last: no confidence -> skipped
+    (root / "labels_gt" / "b.txt").write_text("1 0.5 0.5 0.5 0.5\n")
+    (root / "labels_pred" / "b.txt").write_text("")                                                       # empty -> skipped
+    (root / "labels_gt" / "c.txt").write_text("0 0.5 0.5 0.4 0.4 extra\nbad line\n")
+    (root / "labels_pred" / "c.txt").write_text("0 0.52 0.5 0.4 0.44 0.5\n")
+    (root / "labels_pred" / "d.txt").write_text("0 0.5 0.5 0.4 0.4 0.5\n")                                 # no labels_gt/d.txt -> skipped
+
+
+def test_index_building(tmp_path):
+    _write_dataset(tmp_path, with_images=False)
+    ds = DS.CalibratorDataset(tmp_path, img_size=32)
+    assert ds.img_size == 32 and ds.iou_thr == 0.25
+    names = [s[0].stem for s in ds.samples]
+    assert names == ["a", "a", "a", "c"]                         # a: 3 of 4 six-field predictions match (two share gt 1)
+    gts = [tuple(round(float(v), 2) for v in s[4]) for s in ds.samples[:3]]
+    assert gts == [(0.3, 0.3, 0.2, 0.2), (0.7, 0.7, 0.3, 0.3), (0.7, 0.7, 0.3, 0.3)]
+    for _, _, pred, delta, gt in ds.samples:
+        assert torch.allclose(delta, DS.bbox2delta(gt, pred))
+    strict = DS.CalibratorDataset(tmp_path, img_size=32, iou_thr=0.8)
+    assert [s[0].stem for s in strict.samples] == ["a", "c"]     # only the near-perfect predictions survive 0.8
+    assert DS.CalibratorDataset(tmp_path).img_size == 128        # cgan/config.yaml defaults
+
+
+def test_host_getitem_matches_letterbox_oracle(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    _write_dataset(tmp_path, with_images=True)
+    ds = DS.CalibratorDataset(tmp_path, img_size=32)
+    for i in range(len(ds)):
+        pred_patch, gt_patch, delta, pred_box, path = ds[i]
+        img = np.asarray(Image.open(path).convert("RGB"))
+        assert np.array_equal(pred_patch.numpy(), R.letterbox_patch(img, pred_box.numpy(), 32))
+        assert np.array_equal(gt_patch.numpy(), R.letterbox_patch(img, ds.samples[i][4].numpy(), 32))
+        assert pred_patch.shape == (3, 32, 32) and path.endswith(".jpg") and delta.shape == (4,)
+
+
+@pytest.mark.parametrize("size", [32, 64])
+def test_letterbox_oracle_matches_pillow_fixture(size):
+    fx = np.load(ROOT / "tests" / "golden" / "recrop.npz")
+    imgs = [fx[f"img{i}"] for i in range(int(fx["n_images"]))]
+    for i in range(len(fx["img_idx"])):
+        got = R.letterbox_patch(imgs[fx["img_idx"][i]], fx["refined"][i], size)
+        assert np.array_equal(got, fx[f"letterbox{size}"][i]), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [32, 64])
+def test_kernel_letterbox_mode_matches_pillow_fixture(size):
+    RF = importlib.import_module(PKG + ".refine")
+    fx = np.load(ROOT / "tests" / "golden" / "recrop.npz")
+    imgs = [fx[f"img{i}"] for i in range(int(fx["n_images"]))]
+    atlas = RF.ImageAtlas(imgs, "cuda")
+    out = RF.recrop(atlas, torch.from_numpy(fx["img_idx"]).cuda(), torch.from_numpy(fx["refined"]).cuda(), None, size,
+                    letterbox=True).cpu().numpy()
+    bad = [i for i in range(len(out)) if not np.array_equal(out[i], fx[f"letterbox{size}"][i])]
+    assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_gpu_batch_equals_host_getitem(tmp_path):
+    pytest.importorskip("PIL.Image")
+    _write_dataset(tmp_path, with_images=True)
+    ds = DS.CalibratorDataset(tmp_path, img_size=32)
+    pred_patch, gt_patch, delta, pred_box, img_idx = ds.gpu_batch(range(len(ds)))
+    torch.cuda.synchronize()
+    for i in range(len(ds)):
+        hp, hg, hd, hb, _ = ds[i]
+        assert torch.equal(pred_patch[i].cpu(), hp) and torch.equal(gt_patch[i].cpu(), hg)
+        assert torch.equal(delta[i].cpu(), hd) and torch.equal(pred_box[i].cpu(), hb.float())
+    assert img_idx.dtype == torch.int32 and int(img_idx.max()) < ds.atlas().n
+
+
+@pytest.mark.gpu
+def test_train_harness_on_a_dataset_directory(tmp_path):
+    """train.py --source dataset: YOLO txt + jpg -> HBM atlas -> GPU patches -> engine iterations with the GPU re-crop
+    stage between G and D -> checkpoint with the reference's keys."""
+    pytest.importorskip("PIL.Image")
+    from PIL import Image
+    root = tmp_path / "data"
+    (root / "images").mkdir(parents=True); (root / "labels_gt").mkdir(); (root / "labels_pred").mkdir()
+    rng = np.random.default_rng(0)
+    for i in range(6):
+        Image.fromarray(rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)).save(root / "images" / f"im{i}.jpg")
+        gt = [(0.3, 0.35, 0.3, 0.3), (0.7, 0.6, 0.25, 0.4)]
+        (root / "labels_gt" / f"im{i}.txt").write_text("".join(f"0 {a} {b} {c} {d}\n" for a, b, c, d in gt))
+        pr = [(a + 0.02, b - 0.01, c * 1.1, d * 0.9) for a, b, c, d in gt]
+        (root / "labels_pred" / f"im{i}.txt").write_text("".join(f"0 {a} {b} {c} {d} 0.9\n" for a, b, c, d in pr))
+    sys.path.insert(0, str(ROOT))
+    import train
+    save = tmp_path / "run"
+    train.main(["--source", "dataset", "--data_dir", str(root), "--img_size", "32", "--batch_size", "4", "--n_epochs", "2",
+                "--n_critic", "2", "--save_dir", str(save), "--compute_dtype", "fp32", "--train_split", "1.0"])
+    hist = __import__("json").loads((save / "training_history.json").read_text())
+    assert len(hist) == 2 and all(np.isfinite(h["loss_G"]) and np.isfinite(h["loss_D"]) for h in hist)
+    ck = torch.load(save / "G_best.pth", weights_only=False) if (save / "G_best.pth").exists() else None
+    if ck is not None:
+        assert set(ck) == {"generator", "discriminator", "epoch", "delta_iou", "config"}

@@ -2,9 +2,10 @@
 """Training harness with the reference's surface (cgan/cgan_train_enhanced.py:139-168,256-261,481-489): same
 argument names and defaults (read from config.yaml), Adam(lr, (beta1, beta2)) for both nets, the same logged scalars
 and the same checkpoint dict keys {'generator','discriminator','epoch','delta_iou','config'} -- driving the MI355X
-step engine.  Data: the reference reads image crops through CalibratorDataset + a PIL re-crop stage (out of scope
-this round); here a synthetic source with the same tensor contract feeds the
-loop, or any iterable yielding (pred_patch, gt_patch, delta_true, pred_box, refine_fn).
+step engine.  Data: `--source synthetic` (default; the tensor contract of SURVEY §8a row I, no files needed) or
+`--source dataset`: CalibratorDataset over --data_dir (YOLO txt + jpg) with the images decoded once into
+an HBM atlas, the pred/gt patches and the per-step re-crop cut on the GPU.  Any iterable yielding
+(pred_patch, gt_patch, delta_true, pred_box, refine_fn) can feed the loop.
 """
 from __future__ import annotations
 
@@ -50,6 +51,7 @@ def build_parser(config: dict) -> argparse.ArgumentParser:
     # MI355X-specific
     p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--iters_per_epoch", type=int, default=20, help="synthetic source: iterations per epoch")
+    p.add_argument("--source", default="synthetic", choices=["synthetic", "dataset"])
     return p
 
 
@@ -65,6 +67,19 @@ def synthetic_source(synth, seed, batch, size, n_critic, device, iters):
         refined = [T(r).to(device) for r in inp["refined"]]
         yield (T(inp["pred"]).to(device), T(inp["gt"]).to(device), T(inp["delta_true"]).to(device),
                T(inp["pred_box"]).to(device), lambda delta, k, r=refined: r[k])
+
+
+def dataset_source(ds, refine_mod, indices, batch, size, device, seed):
+    """CalibratorDataset batches entirely on the device (cgan/cgan_train_enhanced.py:262-303 + the re-crop of :313,358):
+    shuffled, last partial batch dropped (the engine's buffers are sized for one batch size)."""
+    g = torch.Generator().manual_seed(seed)
+    order = [indices[i] for i in torch.randperm(len(indices), generator=g).tolist()]
+    atlas = ds.atlas(device)
+    for b0 in range(0, len(order) - batch + 1, batch):
+        pred_patch, gt_patch, delta_true, pred_box, img_idx = ds.gpu_batch(order[b0:b0 + batch], device)
+        refine = lambda delta, k, ii=img_idx, pb=pred_box, fp=pred_patch: refine_mod.get_refined_patch_batch(
+            atlas, ii, pb, delta, size, fallback_patches=fp)
+        yield pred_patch, gt_patch, delta_true, pred_box, refine
 
 
 def main(argv=None):
@@ -98,6 +113,18 @@ def main(argv=None):
                             allreduce=dist_mod.GradAverager() if world > 1 else None)
     if world > 1:
         dist_mod.broadcast_state([eng.D.p, eng.G.p] + eng.u + eng.v)
+    train_idx = None
+    if args.source == "dataset":
+        dataset_mod = importlib.import_module(PKG + ".dataset")
+        refine_mod = importlib.import_module(PKG + ".refine")
+        ds = dataset_mod.CalibratorDataset(args.data_dir, img_size=args.img_size)
+        g = torch.Generator().manual_seed(args.seed)
+        perm = torch.randperm(len(ds), generator=g).tolist()
+        train_idx = perm[:int(args.train_split * len(ds))][rank::world]              # :219-231 (train part), sharded by rank
+        if rank == 0:
+            print(f"dataset: {len(ds)} (pred, gt) pairs, {len(train_idx)} for training on this rank, {ds.atlas(device).n} images")
+        if len(train_idx) < args.batch_size // world:
+            raise SystemExit("fewer training pairs than one batch")
     out_root = Path(args.save_dir); out_root.mkdir(parents=True, exist_ok=True)
     ckpt_best = out_root / "G_best.pth"
     best, history = -1.0, []
@@ -105,9 +132,12 @@ def main(argv=None):
         stats = dict(loss_G=0.0, loss_D=0.0, loss_iou=0.0, loss_wgan=0.0, loss_gp=0.0, wasserstein_distance=0.0)
         n = 0
         iou_b = iou_a = 0.0
-        for pred, gt, delta_true, pred_box, refine in synthetic_source(synth, args.seed + 1000 * epoch + rank,
-                                                                       args.batch_size // world, args.img_size,
-                                                                       args.n_critic, device, args.iters_per_epoch):
+        if train_idx is not None:
+            source = dataset_source(ds, refine_mod, train_idx, args.batch_size // world, args.img_size, device, args.seed + epoch)
+        else:
+            source = synthetic_source(synth, args.seed + 1000 * epoch + rank, args.batch_size // world, args.img_size,
+                                      args.n_critic, device, args.iters_per_epoch)
+        for pred, gt, delta_true, pred_box, refine in source:
             log = eng.iteration(pred, gt, delta_true, pred_box, refine)
             stats["loss_D"] += sum(log["d_loss"]) / args.n_critic
             stats["loss_gp"] += sum(log["gp"]) / args.n_critic
