@@ -513,6 +513,21 @@ __global__ void mask_gen_kernel(uint8_t* __restrict__ out, size_t n, uint64_t se
     }
 }
 
+// dst[i] (=|+=) sum over replicas of src[i + r * rep_stride]: folds the striped bias / spectral-norm partial sums of the
+// norm-backward kernels (norm.hip, replica_offset) -- up to 8 segments per launch
+struct RepBatch { const float* src[8]; float* dst[8]; int beg[9]; int nseg, nrep, rep_stride, accumulate; };
+__global__ void sum_replicas_kernel(RepBatch b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.beg[b.nseg]) return;
+    int sgi = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) if (k < b.nseg && i >= b.beg[k]) sgi = k;
+    const int j = i - b.beg[sgi];
+    float s = 0.f;
+    for (int r = 0; r < b.nrep; ++r) s += b.src[sgi][j + (size_t)r * b.rep_stride];
+    if ((b.accumulate >> sgi) & 1) b.dst[sgi][j] += s; else b.dst[sgi][j] = s;
+}
+
 // uniform [0,1) floats from the same counter-based hash: the interpolation weights alpha of cgan/losses.py:199
 __global__ void uniform_gen_kernel(float* __restrict__ out, size_t n, uint64_t seed, const double* counter) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -717,6 +732,22 @@ int gcssl_dropout_mask_gen(uint8_t* out, long n, unsigned long long seed, const 
     if (n <= 0) return GCSSL_EBADSHAPE;
     if (((uintptr_t)out) & 7) return GCSSL_EALIGN;
     hipLaunchKernelGGL(mask_gen_kernel, GRID1(n / 8 + (n & 7)), out, (size_t)n, (uint64_t)seed, counter);
+    return gcssl_launch_status();
+}
+
+int gcssl_sum_replicas(int nseg, const float* const* src, float* const* dst, const int* len, int nrep, int rep_stride,
+                       int accumulate, void* stream) {
+    if (!src || !dst || !len) return GCSSL_ENULL;
+    if (nseg < 1 || nseg > 8 || nrep < 1 || rep_stride < 0) return GCSSL_EBADSHAPE;
+    RepBatch b{};
+    int total = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (!src[i] || !dst[i]) return GCSSL_ENULL;
+        if (len[i] <= 0) return GCSSL_EBADSHAPE;
+        b.src[i] = src[i]; b.dst[i] = dst[i]; b.beg[i] = total; total += len[i];
+    }
+    b.beg[nseg] = total; b.nseg = nseg; b.nrep = nrep; b.rep_stride = rep_stride; b.accumulate = accumulate;
+    hipLaunchKernelGGL(sum_replicas_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, b);
     return gcssl_launch_status();
 }
 

@@ -49,6 +49,12 @@ __device__ __forceinline__ float act_grad(float xhat, int act) { return xhat > 0
 constexpr int VC = 4, CGN = 16, RGN = 16, MAXR = 4, SMALL_HW = RGN * MAXR;
 constexpr int BIGR = 16, MID_HW = RGN * BIGR;   // 64 < H*W <= 256: same fused kernels with 16 rows per lane (forward, backward)
 
+__device__ __forceinline__ int replica_offset(int nrep, int rep_stride) {
+    if (nrep <= 1) return 0;
+    const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    return (int)(wg % (unsigned)nrep) * rep_stride;
+}
+
 template <int NV>
 __device__ __forceinline__ void combine16(float (&v)[NV][VC], float (*sm)[RGN][CW], int tx, int ty) {
     __syncthreads();
@@ -260,6 +266,7 @@ struct InBwdParams {
     void* dzs; int lddz;               // output: dz * gscale
     float* dbias;                      // [C] += sum dz (atomic), nullable
     float* cdot;                       // [ngroups] += sum dzs (z - bias) = <G_k, W_orig>/sigma_k^2 (atomic), nullable
+    int nrep, rep_stride;              // dbias/cdot are nrep replicas rep_stride floats apart; a workgroup adds to one
     int HW, C, act;
 };
 
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
             st4<T>(op + (size_t)p * q.lddz, o);
         }
         if (mixed_groups && q.cdot) {          // tiny batches only: a pass may straddle sample groups
-            if (live && sd != 0.f) atomicAdd(q.cdot + n / q.group_n, sd);
+            if (live && sd != 0.f) atomicAdd(q.cdot + replica_offset(q.nrep, q.rep_stride) + n / q.group_n, sd);
             sd = 0.f;
         }
     }
@@ -345,12 +352,12 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
         combine16<1>(sb, reinterpret_cast<float(*)[RGN][CW]>(sm), tx, ty);
         if (ty == 0) {
 #pragma unroll
-            for (int j = 0; j < VC; ++j) atomicAdd(q.dbias + c + j, sb[0][j]);
+            for (int j = 0; j < VC; ++j) atomicAdd(q.dbias + replica_offset(q.nrep, q.rep_stride) + c + j, sb[0][j]);
         }
     }
     if (q.cdot && !mixed_groups) {
         const float tot = block_sum<CGN * RGN / 64>(sd, red);
-        if (threadIdx.x == 0) atomicAdd(q.cdot + nb / q.group_n, tot);     // all samples of a workgroup share a group
+        if (threadIdx.x == 0) atomicAdd(q.cdot + replica_offset(q.nrep, q.rep_stride) + nb / q.group_n, tot);     // all samples of a workgroup share a group
     }
 }
 
@@ -445,12 +452,12 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_kernel(InBwdParams q, float*
         combine16<1>(sb, reinterpret_cast<float(*)[RGN][CW]>(sm), tx, ty);
         if (ty == 0) {
 #pragma unroll
-            for (int j = 0; j < VC; ++j) atomicAdd(q.dbias + c + j, sb[0][j]);
+            for (int j = 0; j < VC; ++j) atomicAdd(q.dbias + replica_offset(q.nrep, q.rep_stride) + c + j, sb[0][j]);
         }
     }
     if (q.cdot) {
         const float tot = block_sum<CGN * RGN / 64>(sd, red);
-        if (threadIdx.x == 0) atomicAdd(q.cdot + n / q.group_n, tot);
+        if (threadIdx.x == 0) atomicAdd(q.cdot + replica_offset(q.nrep, q.rep_stride) + n / q.group_n, tot);
     }
 }
 
@@ -587,6 +594,7 @@ struct ActBwdParams {
     void* dzs; int lddz;
     float* dbias; float* cdot;
     int HW, C;
+    int nrep, rep_stride;
 };
 // grid: (C/64, sample blocks of `spb`, H*W chunks of `rows_per_chunk`); lanes own 4 channels x strided rows, the bias /
 // spectral-norm partial sums stay in registers across the samples of a workgroup (one set of atomics per workgroup)
@@ -630,7 +638,7 @@ __global__ __launch_bounds__(CGN * RGN) void act_bwd_kernel(ActBwdParams q, int 
         }
         if (mixed_groups && q.cdot) {
             const float tot = block_sum<CGN * RGN / 64>(sd, red);
-            if (threadIdx.x == 0) atomicAdd(q.cdot + n / q.group_n, tot);
+            if (threadIdx.x == 0) atomicAdd(q.cdot + replica_offset(q.nrep, q.rep_stride) + n / q.group_n, tot);
             sd = 0.f;
         }
     }
@@ -638,12 +646,12 @@ __global__ __launch_bounds__(CGN * RGN) void act_bwd_kernel(ActBwdParams q, int 
         combine16<1>(sb, sm, tx, ty);
         if (ty == 0) {
 #pragma unroll
-            for (int j = 0; j < VC; ++j) atomicAdd(q.dbias + c + j, sb[0][j]);
+            for (int j = 0; j < VC; ++j) atomicAdd(q.dbias + replica_offset(q.nrep, q.rep_stride) + c + j, sb[0][j]);
         }
     }
     if (q.cdot && !mixed_groups) {
         const float tot = block_sum<CGN * RGN / 64>(sd, red);
-        if (threadIdx.x == 0) atomicAdd(q.cdot + nb / q.group_n, tot);
+        if (threadIdx.x == 0) atomicAdd(q.cdot + replica_offset(q.nrep, q.rep_stride) + nb / q.group_n, tot);
     }
 }
 
@@ -654,6 +662,7 @@ __global__ void dot_accum_kernel(const T* __restrict__ x, int ldx, const float* 
     __shared__ float red[4];
     float s = 0.f;
     const size_t total = pixels * C;
+#pragma unroll 4
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i / C; const int c = i % C;
         s += Elem<T>::ld(x + pix * ldx + c) * y[pix * ldy + c];
@@ -662,6 +671,9 @@ __global__ void dot_accum_kernel(const T* __restrict__ x, int ldx, const float* 
     if (threadIdx.x == 0) atomicAdd(out, tot);
 }
 
+// Same-address float atomics serialise (~12 ns each, and a 256-byte bias vector shares a few memory-side lines): 768
+// workgroups adding 64 bias sums each cost 70 us on a 17-us pass (tools/actbwd_bench.py).  The sums therefore go to one of
+// nrep replicas chosen by workgroup index; gcssl_sum_replicas folds them afterwards.
 bool bad_dtype(int dt) { return dt != GCSSL_F32 && dt != GCSSL_BF16; }
 
 // row-group lanes per sample for a small map, and samples per workgroup (a multiple of the samples per pass that keeps
@@ -717,15 +729,17 @@ int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float
 int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const float* da_bcast,
                      const float* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask,
                      const float* zt, int zt_n0, const float* gscale, int group_n, const float* bias,
-                     void* dzs, int lddz, float* dbias, float* cdot, float* ws, int N, int HW, int C, int act, void* stream) {
+                     void* dzs, int lddz, float* dbias, float* cdot, int nrep, int rep_stride, float* ws, int N, int HW, int C,
+                     int act, void* stream) {
     if ((!da && !da_bcast) || !z || !mean || !rstd || !dzs) return GCSSL_ENULL;
+    if (nrep < 1 || (nrep > 1 && rep_stride < C)) return GCSSL_EBADSHAPE;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lddz < C || ldz % 4 || lddz % 4 || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
     if ((da && ldda % 4) || (da2 && ldda2 % 4)) return GCSSL_EBADSHAPE;
     if ((gscale || cdot) && group_n <= 0) return GCSSL_EBADSHAPE;
     if (HW > MID_HW && !ws) return GCSSL_ENULL;
     InBwdParams q{da, ldda, da2, ldda2, da_bcast, z, ldz, mean, rstd, mask, zt, zt_n0, gscale,
-                  group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, HW, C, act};
+                  group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, nrep, rep_stride, HW, C, act};
     hipStream_t st = (hipStream_t)stream;
     if (HW <= MID_HW) {
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, cdot ? q.group_n : 0);
@@ -779,13 +793,14 @@ int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, in
 
 int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const void* a, int lda,
                   const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias,
-                  float* cdot, int N, int HW, int C, void* stream) {
+                  float* cdot, int nrep, int rep_stride, int N, int HW, int C, void* stream) {
     if (!da || !a || !dzs) return GCSSL_ENULL;
+    if (nrep < 1 || (nrep > 1 && rep_stride < C)) return GCSSL_EBADSHAPE;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || HW <= 0 || C <= 0 || C % CW || lda < C || lddz < C || ldda < C) return GCSSL_EBADSHAPE;
     if (lda % 4 || lddz % 4 || ldda % 4 || (da2 && ldda2 % 4)) return GCSSL_EBADSHAPE;
     if ((gscale || cdot) && group_n <= 0) return GCSSL_EBADSHAPE;
-    ActBwdParams q{da, ldda, da2, ldda2, a, lda, gscale, group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, HW, C};
+    ActBwdParams q{da, ldda, da2, ldda2, a, lda, gscale, group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, HW, C, nrep, rep_stride};
     // 64-row chunks of H*W x blocks of samples; grow the sample block while >= ~512 workgroups remain
     int rows = HW < 64 ? HW : 64;
     const int zc = (HW + rows - 1) / rows;
@@ -805,7 +820,8 @@ int gcssl_dot_accum(int dtype, const void* x, int ldx, const float* y, int ldy, 
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (pixels <= 0 || C <= 0 || ldx < C || ldy < C) return GCSSL_EBADSHAPE;
     const size_t total = (size_t)pixels * C;
-    int blocks = (int)((total + 255) / 256); if (blocks > 1024) blocks = 1024;
+    // one atomic per block on ONE address: 1024 blocks cost 12 us of serialised atomics on a 5-us pass -> 256 blocks
+    int blocks = (int)((total + 255) / 256); if (blocks > 256) blocks = 256;
     if (dtype == GCSSL_F32)
         hipLaunchKernelGGL(dot_accum_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx,
                            y, ldy, (size_t)pixels, C, out);

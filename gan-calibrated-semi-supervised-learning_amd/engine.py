@@ -124,6 +124,7 @@ class StepEngine:
         self._prep_d_batch = self._prep_g_batch = None
         self.alpha_buf = torch.empty(batch, **f32)
         self._red_d = self._red_g = None
+        self._rep_sum = None
         # Independent branches of the iteration run on a side HIP stream (hipGraph capture turns them into parallel
         # graph branches): spectral-norm iterations + weight re-pack beside the no-grad generator forward, and every
         # layer's wgrad + split-K reduce beside the dependent dgrad -> norm-backward chain.  None of these kernels
@@ -237,7 +238,14 @@ class StepEngine:
         self.d_da = [act(N3, s, c, F32) for s, (_, c) in zip(sizes, D_CH)]
         self.d_dzs = [t[:N3] for t in self.d_dzs4]
         # scalars: [0:12] cdot[layer][group] = <dW_sn_k, W_orig>/sigma_k^2 (spectral-norm quotient rule), [12] gp_sum, [13] eiou acc, [14:17] group means, [17] wgan-G mean
-        self.scal = torch.zeros(32, **f32)
+        # ... followed by NREP replicas of the critic backward's striped sums (bias gradients of the four layers + the 12
+        # cdot entries): hundreds of workgroups adding to one 256-byte bias vector serialise (70 us on a 17-us pass), so
+        # each adds to replica (workgroup % NREP) and one gcssl_sum_replicas launch folds them.  One fill zeroes it all.
+        self.NREP, self.REP_STRIDE = 32, 1024
+        self.zero_blk = torch.zeros(32 + self.NREP * self.REP_STRIDE, **f32)
+        self.scal = self.zero_blk[:32]
+        self.rep = self.zero_blk[32:].view(self.NREP, self.REP_STRIDE)
+        self.rep_bias_off = [0, 64, 192, 448]                      # c1..c4 bias (64, 128, 256, 512 floats); cdot at 960
         self.cdot = self.scal[0:12].view(4, 3)
         self.gp_sum = self.scal[12:13]
         self.eiou_acc = self.scal[13:14]
@@ -439,7 +447,7 @@ class StepEngine:
         if not self.D.grads_zero:                                 # optimizer.zero_grad() (:305) unless the last update did it
             self.D.g.zero_()
         self.D.grads_zero = False
-        self.scal.zero_()
+        self.zero_blk.zero_()                                      # scalars + the striped-sum replicas
         self._prep_g()
         # no-grad generator forward in train mode (:311-312) on the real-group input (channels 0-2 = pred)
         ops.pack_pair(pred, gt, self.x0[:B])
@@ -493,13 +501,15 @@ class StepEngine:
             cp = _pad8(cin)
             i = D_IDX[l]
             bias, gbias = self.D.views[f"model.{i}.bias"], self.D.gviews[f"model.{i}.bias"]
+            rb = self.rep[0, self.rep_bias_off[l]:self.rep_bias_off[l] + cout]          # replica 0 of this layer's bias sums
+            rc = self.rep[0, 960 + 3 * l:963 + 3 * l]                                    # ... and of its three cdot entries
             if l > 0:
                 ops.in_act_bwd(self.d_z[l], self.d_mean[l], self.d_rstd[l], self.d_dzs[l], cout, LRELU,
                                da=self.d_da[l], zt=self.zt[l], zt_n0=2 * B, gscale=isig[l], group_n=B, bias=bias,
-                               dbias=gbias, cdot=self.cdot[l], ws=self.ws)
+                               dbias=rb, cdot=rc, ws=self.ws, nrep=self.NREP, rep_stride=self.REP_STRIDE)
             else:
                 ops.act_bwd(self.d_da[0], self.d_a[0], self.d_dzs[0], 64, gscale=isig[0], group_n=B, bias=bias,
-                            dbias=gbias, cdot=self.cdot[0])
+                            dbias=rb, cdot=rc, nrep=self.NREP, rep_stride=self.REP_STRIDE)
             fl = conv_flops(N3, S >> l, cin, cout)
 
             def wgrad_branch(l=l, cout=cout, cp=cp, fl4=conv_flops(4 * B, S >> l, cin, cout)):
@@ -508,6 +518,13 @@ class StepEngine:
             if l > 0:
                 self._conv(f"D.c{l + 1}.dgrad", fl, ops.conv_dgrad, self.d_dzs[l], self.d_wt[l], self.d_da[l - 1], cin, cout)
         self._join_side()                                         # all gradient branches are in before the segment ends
+        # fold the striped sums: bias gradients -> flat gradient, cdot += (the GP-chain part is already there)
+        if self._rep_sum is None:
+            segs = [(self.rep[0, o:o + c], self.D.gviews[f"model.{i}.bias"], c, False)
+                    for o, (_, c), i in zip(self.rep_bias_off, D_CH, D_IDX)]
+            segs.append((self.rep[0, 960:972], self.scal[0:12], 12, True))
+            self._rep_sum = ops.ReplicaSum(segs, self.NREP, self.REP_STRIDE)
+        self._rep_sum.run()
         # dW_orig = sum_k G_k / sigma_k - sum_k c_k u_k v_k^T for the four spectrally-normalised layers, one launch
         self._reduce_batches()[0].run()
 

@@ -100,6 +100,21 @@ def wgrad_reduce(slab, nsplit, dw, cout, cin, cin_real, coef=None, cscale=None, 
          2 if accumulate == "zeroed" else int(accumulate))
 
 
+class ReplicaSum:
+    """Argument block for gcssl_sum_replicas: segments = [(src_replica0, dst, length, accumulate), ...] (<= 8)."""
+
+    def __init__(self, segments, nrep, rep_stride):
+        self._keep = segments
+        self.n, self.nrep, self.rep_stride = len(segments), nrep, rep_stride
+        self.acc = sum(1 << i for i, s in enumerate(segments) if s[3])
+        self._src = _lib.ptr_array([s[0] for s in segments])
+        self._dst = _lib.ptr_array([s[1] for s in segments])
+        self._len = _lib.int_array([s[2] for s in segments])
+
+    def run(self):
+        call("gcssl_sum_replicas", self.n, self._src, self._dst, self._len, self.nrep, self.rep_stride, self.acc)
+
+
 class ReduceBatch:
     """Argument block for gcssl_wgrad_reduce_batch: layers = [dict(slab, nsplit, dw, cout, cin, cin_real[, coef, u, v])]
     (<= 8); u, v are 2-D history tensors that share row strides."""
@@ -153,12 +168,13 @@ def in_act_fwd(z, a, mean, rstd, C, act, mask=None, pool=None):
 
 
 def in_act_bwd(z, mean, rstd, dzs, C, act, da=None, da2=None, da_bcast=None, mask=None, zt=None, zt_n0=0,
-               gscale=None, group_n=0, bias=None, dbias=None, cdot=None, ws=None):
+               gscale=None, group_n=0, bias=None, dbias=None, cdot=None, ws=None, nrep=1, rep_stride=0):
+    """nrep > 1: dbias / cdot point at replica 0 of nrep replicas rep_stride floats apart (fold with ReplicaSum)."""
     N, H, W, _ = z.shape
     assert z.dtype == torch.float32 and all(t is None or t.dtype == torch.float32 for t in (da, da2, zt))
     call("gcssl_in_act_bwd", code(dzs), da, _ld(da) if da is not None else 0, da2, _ld(da2) if da2 is not None else 0,
-         da_bcast, z, _ld(z), mean, rstd, mask, zt, zt_n0, gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot, ws,
-         N, H * W, C, act)
+         da_bcast, z, _ld(z), mean, rstd, mask, zt, zt_n0, gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot, nrep, rep_stride,
+         ws, N, H * W, C, act)
 
 
 def in_dbl_bwd(gb_a, qz, gb_zs, z, mean, rstd, gt_a, zt, C, act, cdot=None):
@@ -169,12 +185,12 @@ def in_dbl_bwd(gb_a, qz, gb_zs, z, mean, rstd, gt_a, zt, C, act, cdot=None):
          z, _ld(z), mean, rstd, gt_a, _ld(gt_a), zt, cdot, N, H * W, C, act)
 
 
-def act_bwd(da, a, dzs, C, da2=None, gscale=None, group_n=0, bias=None, dbias=None, cdot=None):
+def act_bwd(da, a, dzs, C, da2=None, gscale=None, group_n=0, bias=None, dbias=None, cdot=None, nrep=1, rep_stride=0):
     """da/da2: fp32 incoming gradients; a and dzs in the compute dtype."""
     N, H, W, _ = a.shape
     assert da.dtype == torch.float32 and (da2 is None or da2.dtype == torch.float32)
     call("gcssl_act_bwd", code(a), da, _ld(da), da2, _ld(da2) if da2 is not None else 0, a, _ld(a), gscale, group_n,
-         bias, dzs, _ld(dzs), dbias, cdot, N, H * W, C)
+         bias, dzs, _ld(dzs), dbias, cdot, nrep, rep_stride, N, H * W, C)
 
 
 def dot_accum(x, y, C, out):

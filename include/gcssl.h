@@ -106,7 +106,7 @@ int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float
 int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const float* da_bcast,
                      const float* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask, const float* zt,
                      int zt_n0, const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias,
-                     float* cdot, float* ws, int N, int HW, int C, int act, void* stream);
+                     float* cdot, int nrep, int rep_stride, float* ws, int N, int HW, int C, int act, void* stream);
 /* ws: caller-owned scratch of 2*N*C floats, required when H*W > 64 (two-kernel path), else may be NULL. */
 /* second-order backward (create_graph=True, cgan/losses.py:213-220): adjoint of dz=IN_bwd(z, act'*gb_a) for an
  * incoming adjoint qz: gt_a = act'(xhat) * d/d(dn), zt = d/dz; cdot += sum gb_zs*qz. */
@@ -116,7 +116,13 @@ int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, in
 /* LeakyReLU backward for the norm-less layers (D.c1, G.down1; cgan/models.py:103,246), from the activation OUTPUT a. */
 int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const void* a, int lda,
                   const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias, float* cdot,
-                  int N, int HW, int C, void* stream);
+                  int nrep, int rep_stride, int N, int HW, int C, void* stream);
+/* dbias / cdot of the two backward entry points above may be striped: nrep replicas, rep_stride floats apart, each
+ * workgroup adds to one of them (same-address float atomics serialise); nrep = 1 is the plain form.  This folds them:
+ * dst[i][j] (=|+=) sum_r src[i][j + r*rep_stride] for nseg <= 8 segments of len[i] floats; bit i of accumulate
+ * selects += for segment i. */
+int gcssl_sum_replicas(int nseg, const float* const* src, float* const* dst, const int* len, int nrep, int rep_stride,
+                       int accumulate, void* stream);
 int gcssl_dot_accum(int dtype, const void* x, int ldx, const float* y, int ldy, long pixels, int C, float* out, void* stream);
 
 /* ---- spectral norm power iteration (torch.nn.utils.spectral_norm, cgan/models.py:237-238) -----------------------

@@ -396,3 +396,24 @@ def test_dropout_mask_gen(ops):
     t = torch.full((8 * 1000 + 5,), 7, device="cuda", dtype=torch.uint8)
     ops.dropout_mask_gen(t, 99)
     assert set(t.unique().tolist()) <= {0, 1}
+
+
+def test_striped_bias_and_cdot_sums(ops):
+    """dbias / cdot striped over replicas (nrep) + gcssl_sum_replicas == the single-address form."""
+    N, H, C = 24, 16, 64
+    da = rnd(N, H, H, C, seed=70).cuda()
+    a = rnd(N, H, H, C, seed=71).cuda().bfloat16()
+    bias = rnd(C, seed=72, scale=0.1).cuda()
+    gs = torch.tensor([1.5, 0.5, 2.0], device="cuda")
+    dz1 = torch.empty(N, H, H, C, device="cuda", dtype=torch.bfloat16); dz2 = torch.empty_like(dz1)
+    db1 = torch.zeros(C, device="cuda"); cd1 = torch.zeros(3, device="cuda")
+    ops.act_bwd(da, a, dz1, C, gscale=gs, group_n=8, bias=bias, dbias=db1, cdot=cd1)
+    nrep, stride = 8, 128
+    rep = torch.zeros(nrep, stride, device="cuda")
+    ops.act_bwd(da, a, dz2, C, gscale=gs, group_n=8, bias=bias, dbias=rep[0, :C], cdot=rep[0, 100:103], nrep=nrep, rep_stride=stride)
+    db2 = torch.full((C,), 7.0, device="cuda"); cd2 = torch.full((3,), 1.0, device="cuda")
+    ops.ReplicaSum([(rep[0, :C], db2, C, False), (rep[0, 100:103], cd2, 3, True)], nrep, stride).run()
+    torch.cuda.synchronize()
+    assert torch.equal(dz1, dz2)
+    assert int((rep[:, :C].abs().sum(1) > 0).sum()) > 1                     # the sums really are spread over replicas
+    assert rel_err(db2.cpu(), db1.cpu()) < 1e-5 and rel_err((cd2 - 1.0).cpu(), cd1.cpu()) < 1e-4
