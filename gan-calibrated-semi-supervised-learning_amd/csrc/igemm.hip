@@ -918,10 +918,10 @@ __device__ __forceinline__ void wgrad_reduce_body(float (*tile)[65], int co, int
             o[j] = sv;
         }
         float* op = dw + ((size_t)co * Cin_real + ci) * 16 + tp;
-        if (accumulate == 2) {
+        if (accumulate == 2 && zn > 1) {                  // several slab groups add into the zeroed gradient
 #pragma unroll
             for (int j = 0; j < 4; ++j) atomicAdd(op + j, o[j]);
-        } else if (accumulate) {
+        } else if (accumulate == 1) {
             float4 t = *reinterpret_cast<float4*>(op);
             *reinterpret_cast<float4*>(op) = make_float4(t.x + o[0], t.y + o[1], t.z + o[2], t.w + o[3]);
         } else {

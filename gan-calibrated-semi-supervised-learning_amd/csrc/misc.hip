@@ -524,7 +524,9 @@ __global__ void sum_replicas_kernel(RepBatch b) {
     for (int k = 1; k < 8; ++k) if (k < b.nseg && i >= b.beg[k]) sgi = k;
     const int j = i - b.beg[sgi];
     float s = 0.f;
-    for (int r = 0; r < b.nrep; ++r) s += b.src[sgi][j + (size_t)r * b.rep_stride];
+    const float* sp = b.src[sgi] + j;
+#pragma unroll 8
+    for (int r = 0; r < b.nrep; ++r) s += sp[(size_t)r * b.rep_stride];      // independent loads: issued together
     if ((b.accumulate >> sgi) & 1) b.dst[sgi][j] += s; else b.dst[sgi][j] = s;
 }
 
