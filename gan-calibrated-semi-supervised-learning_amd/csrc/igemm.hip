@@ -160,6 +160,9 @@ struct ConvParams {
     int out_f32;        // fwd/dgrad: write fp32 regardless of T
     int ktiles_per_split;   // wgrad; fwd/dgrad when ksplit > 1
     int ksplit;             // fwd/dgrad: K is split over ksplit workgroups that atomically add into a zeroed fp32 output
+    int* plan_out;          // dry run (gcssl_conv4x4s2_*_splits): the dispatcher stores the K split it would use and launches nothing
+    long split_stride;      // ... or, when > 0, store their partial sums plainly into slab ks at y + ks*split_stride (fp32 elements);
+                            // the consumer (gcssl_in_act_fwd nslab) adds the slabs: float atomics run at 1.3 TB/s chip-wide
     unsigned x_bytes, w_bytes;   // extents of the two operand buffers (buffer-load bounds; < 2^31)
     unsigned y_bytes;            // extent of the output (buffer-store bounds of the persistent kernel); 0 = unknown/too large
 };
@@ -268,7 +271,8 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
                 float v = acc[i][j][r] * s;
                 if (p.ksplit > 1) {                       // linear epilogue only: partial sums add up, bias once
                     if (p.bias && ks == 0) v += p.bias[co];
-                    atomicAdd(y32 + (size_t)m * p.ldy + co, v);
+                    if (p.split_stride) y32[(size_t)ks * p.split_stride + (size_t)m * p.ldy + co] = v;
+                    else atomicAdd(y32 + (size_t)m * p.ldy + co, v);
                     continue;
                 }
                 if (p.bias) v += p.bias[co];
@@ -384,7 +388,10 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
                 const int ci = n0 + wn0 + 32 * j + (lane & 31);
                 if (ci >= p.Cin) continue;
                 const float v = acc[i][j][r] * s;
-                if (p.ksplit > 1) atomicAdd(static_cast<float*>(p.y) + pix * p.ldy + ci, v);
+                if (p.ksplit > 1) {
+                    if (p.split_stride) static_cast<float*>(p.y)[(size_t)ks * p.split_stride + pix * p.ldy + ci] = v;
+                    else atomicAdd(static_cast<float*>(p.y) + pix * p.ldy + ci, v);
+                }
                 else if (p.out_f32) static_cast<float*>(p.y)[pix * p.ldy + ci] = v;
                 else Elem<T>::st(static_cast<T*>(p.y) + pix * p.ldy + ci, v);
             }
@@ -575,7 +582,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
                 if (col >= ncols) continue;
                 float v = acc[i][j][r] * sc[i][r] + bcol[j];
                 if (p.ksplit > 1) {
-                    atomicAdd(y32 + pix * p.ldy + col, v);
+                    if (p.split_stride) y32[(size_t)ks * p.split_stride + pix * p.ldy + col] = v;
+                    else atomicAdd(y32 + pix * p.ldy + col, v);
                     continue;
                 }
                 if (MODE == 0 && p.act == 1) v = lrelu_f(v);
@@ -1132,6 +1140,7 @@ __global__ __launch_bounds__(256) void prep_weight_batch_kernel(PrepBatch b) {
 
 template <typename T, int BM, int BN>
 int launch_fwd(const ConvParams& p, hipStream_t st) {
+    if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
     if (std::is_same<T, bf16_t>::value && use_dma()) launch_dma<BM, BN, 0>(p, grid, p.Cin < 64, st);
     else hipLaunchKernelGGL((conv_fwd_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
@@ -1139,6 +1148,7 @@ int launch_fwd(const ConvParams& p, hipStream_t st) {
 }
 template <typename T, int BM, int BN>
 int launch_dgrad(const ConvParams& p, hipStream_t st) {
+    if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cin + BN - 1) / BN, 4 * (p.ksplit > 1 ? p.ksplit : 1));
     if (std::is_same<T, bf16_t>::value && use_dma()) launch_dma<BM, BN, 1>(p, grid, false, st);
     else hipLaunchKernelGGL((conv_dgrad_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
@@ -1202,6 +1212,7 @@ int pick_ksplit(long tiles, int nk, bool allowed) {
 }
 
 int zero_output(const ConvParams& p, long rows, int cols, hipStream_t st) {
+    if (p.split_stride || p.plan_out) return GCSSL_OK;                     // slab mode: every split owns its own slab, nothing to zero
     hipError_t e = hipMemset2DAsync(p.y, (size_t)p.ldy * 4, 0, (size_t)cols * 4, (size_t)rows, st);
     return e == hipSuccess ? GCSSL_OK : (int)e;
 }
@@ -1225,6 +1236,7 @@ template <int MODE> struct PersistBig<256, 64, MODE> {
 };
 template <int BM, int BN, int MODE>
 int launch_big(const ConvParams& p, hipStream_t st) {
+    if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     const int ncols = MODE == 0 ? p.Cout : p.Cin;
     dim3 grid((p.M + BM - 1) / BM, (ncols + BN - 1) / BN, (MODE == 1 ? 4 : 1) * (p.ksplit > 1 ? p.ksplit : 1));
     const int total = (int)(grid.x * grid.y * grid.z), slots = cu_count();          // 120-144 KB of LDS: one per CU
@@ -1308,17 +1320,38 @@ int dispatch_dgrad(ConvParams p, hipStream_t st) {
 
 extern "C" {
 
+// the K split the dispatcher picks for these shapes (1 = none): sizes the slab buffer of the split_stride form
+int gcssl_conv4x4s2_fwd_splits(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int act, int out_f32) {
+    int rc = check_geom(N, Hi, Wi, Cin, Cout);
+    if (rc) return rc;
+    int ks = 1;
+    ConvParams p{}; p.act = act; p.out_f32 = out_f32; p.plan_out = &ks; p.ldx = Cin; p.ldy = Cout; p.y_bytes = 1;
+    fill_geom(p, N, Hi, Wi, Cin, Cout);
+    rc = dtype == GCSSL_F32 ? dispatch_fwd<float>(p, nullptr) : (dtype == GCSSL_BF16 ? dispatch_fwd<bf16_t>(p, nullptr) : GCSSL_EBADDTYPE);
+    return rc ? rc : ks;
+}
+int gcssl_conv4x4s2_dgrad_splits(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int out_f32) {
+    int rc = check_geom(N, Hi, Wi, Cin, Cout);
+    if (rc) return rc;
+    int ks = 1;
+    ConvParams p{}; p.out_f32 = out_f32; p.plan_out = &ks; p.ldx = Cout; p.ldy = Cin; p.y_bytes = 1;
+    fill_geom(p, N, Hi, Wi, Cin, Cout);
+    rc = dtype == GCSSL_F32 ? dispatch_dgrad<float>(p, nullptr) : (dtype == GCSSL_BF16 ? dispatch_dgrad<bf16_t>(p, nullptr) : GCSSL_EBADDTYPE);
+    return rc ? rc : ks;
+}
+
 int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const float* bias,
                         const float* gscale, int group_n, void* y, int ldy, int N, int Hi, int Wi,
-                        int Cin, int Cout, int act, int out_f32, void* stream) {
+                        int Cin, int Cout, int act, int out_f32, long split_stride, void* stream) {
     if (!x || !wf || !y) return GCSSL_ENULL;
+    if (split_stride < 0) return GCSSL_EBADSHAPE;
     int rc = check_geom(N, Hi, Wi, Cin, Cout);
     if (rc) return rc;
     if (Cout < 64 || ldx < Cin || ldy < Cout || (gscale && group_n <= 0)) return GCSSL_EBADSHAPE;
     const int kv = dtype == GCSSL_F32 ? 4 : 8;
     if (ldx % kv || !aligned16(x) || !aligned16(wf)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = x; p.w = wf; p.y = y; p.bias = bias; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
-    p.ldx = ldx; p.ldy = ldy; p.act = act; p.out_f32 = out_f32;
+    p.ldx = ldx; p.ldy = ldy; p.act = act; p.out_f32 = out_f32; p.split_stride = split_stride;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)Cout * 16 * Cin, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
     {   // output extent for buffer stores: the last pixel's Cout channels end it
@@ -1333,15 +1366,16 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
 
 int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, const float* gscale,
                           int group_n, void* dx, int lddx, int N, int Hi, int Wi, int Cin, int Cout,
-                          int out_f32, void* stream) {
+                          int out_f32, long split_stride, void* stream) {
     if (!dy || !wt || !dx) return GCSSL_ENULL;
+    if (split_stride < 0) return GCSSL_EBADSHAPE;
     int rc = check_geom(N, Hi, Wi, Cin, Cout);
     if (rc) return rc;
     if (Cout < 8 || lddy < Cout || lddx < Cin || (gscale && group_n <= 0)) return GCSSL_EBADSHAPE;
     const int kv = dtype == GCSSL_F32 ? 4 : 8;
     if (lddy % kv || !aligned16(dy) || !aligned16(wt)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = dy; p.w = wt; p.y = dx; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
-    p.ldx = lddy; p.ldy = lddx; p.out_f32 = out_f32;
+    p.ldx = lddy; p.ldy = lddx; p.out_f32 = out_f32; p.split_stride = split_stride;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     if (!fill_bytes(p, (size_t)N * (Hi / 2) * (Wi / 2) * lddy, (size_t)Cin * 16 * Cout, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
     {

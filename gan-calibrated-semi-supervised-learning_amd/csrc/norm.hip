@@ -127,10 +127,10 @@ __device__ __forceinline__ void keep4(const uint8_t* mp, float (&k)[VC]) {
 
 // ---- forward, small maps: a = act((z - mean) * rstd) [* keep * 2]; writes mean/rstd [N][C]
 template <typename T, int RG, int MR = MAXR>
-__global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(const float* __restrict__ z, int ldz, T* __restrict__ a, int lda,
+__global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(float* __restrict__ z, int ldz, T* __restrict__ a, int lda,
                                                                 float* __restrict__ mean, float* __restrict__ rstd,
                                                                 const uint8_t* __restrict__ mask, int N, int HW, int C, int act,
-                                                                int spb) {
+                                                                int spb, int nslab, long slab_stride) {
     __shared__ float sm[1][RGN][CW];
     constexpr int SPP = RGN / RG;
     const int tx = threadIdx.x % CGN, ty = threadIdx.x / CGN;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(const float* __
     for (int n0 = blockIdx.y * spb; n0 < min(N, (int)(blockIdx.y + 1) * spb); n0 += SPP) {
         const int n = n0 + slot;
         const bool live = n < N;
-        const float* zp = z + (size_t)n * HW * ldz + c;
+        float* zp = z + (size_t)n * HW * ldz + c;
         float v[MR][VC];
         float s[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -147,6 +147,14 @@ __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(const float* __
             const int p = rg + RG * i;
             if (live && p < HW) {
                 ld4(zp + (size_t)p * ldz, v[i]);
+                if (nslab > 1) {                  // split-K partial sums of the producing conv: add the slabs, keep the total
+                    for (int k = 1; k < nslab; ++k) {
+                        float t[VC]; ld4(zp + (size_t)k * slab_stride + (size_t)p * ldz, t);
+#pragma unroll
+                        for (int j = 0; j < VC; ++j) v[i][j] += t[j];
+                    }
+                    st4<float>(zp + (size_t)p * ldz, v[i]);
+                }
 #pragma unroll
                 for (int j = 0; j < VC; ++j) s[0][j] += v[i][j];
             }
@@ -695,9 +703,10 @@ int small_spb(int N, int C, int rg, int group_n) {
 
 extern "C" {
 
-int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float* mean, float* rstd,
-                     const uint8_t* mask, float* pool, int N, int HW, int C, int act, void* stream) {
+int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean, float* rstd,
+                     const uint8_t* mask, float* pool, int nslab, long slab_stride, int N, int HW, int C, int act, void* stream) {
     if (!z || !a || !mean || !rstd) return GCSSL_ENULL;
+    if (nslab < 1 || (nslab > 1 && (slab_stride <= 0 || slab_stride % 4 || HW > MID_HW || pool))) return GCSSL_EBADSHAPE;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lda < C || ldz % 4 || lda % 4 || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
     if (!aligned16(z) || (((uintptr_t)a) & 7)) return GCSSL_EALIGN;
@@ -705,7 +714,7 @@ int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float
     if (HW <= MID_HW && !pool) {
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, 0);
         dim3 grid(C / CW, (N + spb - 1) / spb);
-#define FWD_SMALL(T, RG, MR) hipLaunchKernelGGL((in_fwd_small_kernel<T, RG, MR>), grid, dim3(CGN * RGN), 0, st, z, ldz, (T*)a, lda, mean, rstd, mask, N, HW, C, act, spb)
+#define FWD_SMALL(T, RG, MR) hipLaunchKernelGGL((in_fwd_small_kernel<T, RG, MR>), grid, dim3(CGN * RGN), 0, st, z, ldz, (T*)a, lda, mean, rstd, mask, N, HW, C, act, spb, nslab, slab_stride)
         if (dtype == GCSSL_F32) {
             if (rg == 1) FWD_SMALL(float, 1, MAXR); else if (rg == 4) FWD_SMALL(float, 4, MAXR);
             else if (HW <= SMALL_HW) FWD_SMALL(float, 16, MAXR); else FWD_SMALL(float, 16, BIGR);

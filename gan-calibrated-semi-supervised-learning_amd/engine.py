@@ -118,6 +118,7 @@ class StepEngine:
         self.u = [sd_d[f"model.{i}.weight_u"].to(dev, torch.float32).clone() for i in D_IDX]
         self.v = [sd_d[f"model.{i}.weight_v"].to(dev, torch.float32).clone() for i in D_IDX]
         self.sn = ops.SnState([self.D.views[f"model.{i}.weight_orig"] for i in D_IDX], self.u, self.v, 3, dev)
+        self._zcap, self._zkeep, self._splits = {}, [], {}
         self._alloc()
         self._d_dirty = True
         self._g_dirty = True
@@ -180,6 +181,35 @@ class StepEngine:
             out[k] = (len(ts), sum(ts) / max(len(ts), 1), rec["flops"], rec["bytes"])
         return out
 
+    # ------------------------------------------------------------------------------------------ split-K slabs
+    def _zbuf(self, kind: str, ns, hi: int, cin: int, cout: int, n_full: int) -> torch.Tensor:
+        """fp32 pre-norm buffer [n_full][H][W][C] of a conv -> InstanceNorm pair, with room behind it for the K-split
+        partial-sum slabs of the producing conv at the batch sizes `ns` the engine launches it with (kind 'fwd': conv of a
+        hi x hi input, output hi/2; 'dgrad': transposed conv to a hi x hi output of `cin` channels).  The view returned is
+        slab 0; _split(...) says how many slabs a launch uses."""
+        ho, c = (hi // 2, cout) if kind == "fwd" else (hi, cin)
+        need = n_full
+        for n in ns:
+            need = max(need, n * ops.conv_splits(kind, self.code, n, hi, cin, cout))
+        buf = torch.empty(need, ho, ho, c, device=self.dev, dtype=torch.float32)
+        z = buf[:n_full]
+        self._zcap[z.data_ptr()] = buf.numel()
+        self._zkeep.append(buf)
+        return z
+
+    def _split(self, kind: str, z: torch.Tensor, n: int, hi: int, cin: int, cout: int):
+        """(nslab, slab_stride) for a launch over the first n samples of z: slab mode when the conv splits K and the slabs
+        fit behind z, else (1, 0) = the atomic form."""
+        key = (kind, z.data_ptr(), n)
+        if key not in self._splits:
+            ks = ops.conv_splits(kind, self.code, n, hi, cin, cout)
+            per = n * z.shape[1] * z.shape[2] * z.shape[3]
+            # (the fused InstanceNorm kernel that adds the slabs handles maps up to 16x16; larger ones keep the atomic form)
+            ok = (ks > 1 and ks * per <= self._zcap.get(z.data_ptr(), 0) and z.is_contiguous()
+                  and z.shape[1] * z.shape[2] <= 256)
+            self._splits[key] = (ks, per) if ok else (1, 0)
+        return self._splits[key]
+
     # ------------------------------------------------------------------------------------------ buffers
     def _alloc(self):
         B, S, T, dev = self.B, self.S, self.T, self.dev
@@ -216,7 +246,8 @@ class StepEngine:
         self.d_a = [t[:N3] for t in self.d_a4]
         self.d_x4 = [x4] + self.d_a4[:3]                                      # wgrad x operand of layer l
         # pre-InstanceNorm tensors are fp32 in both modes (z - mean(z) over 4..64 elements cancels a bf16 mantissa)
-        self.d_z = [None] + [act(N3, s, c, torch.float32) for s, (_, c) in zip(sizes[1:], D_CH[1:])]
+        # (each holds the K-split slabs of its producing conv when that conv splits: _zbuf)
+        self.d_z = [None] + [self._zbuf("fwd", (N3, B), S >> l, D_CH[l][0], D_CH[l][1], N3) for l in (1, 2, 3)]
         self.d_mean = [None] + [torch.empty(N3, c, **f32) for _, c in D_CH[1:]]
         self.d_rstd = [None] + [torch.empty(N3, c, **f32) for _, c in D_CH[1:]]
         self.h5 = sizes[3] - 1
@@ -265,8 +296,8 @@ class StepEngine:
         self.g_cat1 = act(B, S // 8, 512)      # [up1 out (256) | d3 (256)]
         self.g_d4 = act(B, S // 16, 512)
         z32 = torch.float32
-        self.g_zd = [None, act(B, S // 4, 128, z32), act(B, S // 8, 256, z32), act(B, S // 16, 512, z32)]
-        self.g_zu = [act(B, S // 8, 256, z32), act(B, S // 4, 128, z32), act(B, S // 2, 64, z32), act(B, S, 64, z32)]
+        self.g_zd = [None] + [self._zbuf("fwd", (B,), S >> k, G_DOWN[k][0], G_DOWN[k][1], B) for k in (1, 2, 3)]
+        self.g_zu = [self._zbuf("dgrad", (B,), S >> (3 - k), coutt, cint, B) for k, (cint, coutt) in enumerate(G_UP)]
         self.g_u4 = act(B, S, 64)
         self.g_dmean = [None] + [torch.empty(B, c, **f32) for c in (128, 256, 512)]
         self.g_drstd = [None] + [torch.empty(B, c, **f32) for c in (128, 256, 512)]
@@ -358,9 +389,11 @@ class StepEngine:
                 self._conv(f"D.c1.fwd[n={n}]", fl, ops.conv_fwd, x, self.d_wf[0], self.d_a[0][:n], 8, cout, bias=bias,
                            gscale=gscale_of_layer(0), group_n=group_n, act=LRELU)
             else:
+                ns, st = self._split("fwd", self.d_z[l], n, self.S >> l, cin, cout)
                 self._conv(f"D.c{l + 1}.fwd[n={n}]", fl, ops.conv_fwd, self.d_a[l - 1][:n], self.d_wf[l],
-                           self.d_z[l][:n], cin, cout, bias=bias, gscale=gscale_of_layer(l), group_n=group_n)
-                ops.in_act_fwd(self.d_z[l][:n], self.d_a[l][:n], self.d_mean[l][:n], self.d_rstd[l][:n], cout, LRELU)
+                           self.d_z[l][:n], cin, cout, bias=bias, gscale=gscale_of_layer(l), group_n=group_n, split_stride=st)
+                ops.in_act_fwd(self.d_z[l][:n], self.d_a[l][:n], self.d_mean[l][:n], self.d_rstd[l][:n], cout, LRELU,
+                               nslab=ns, slab_stride=st)
         ops.c5_fwd(self.d_a[3][:n], self.d_w5p, self.d_out[:n])
 
     def critic_scores(self, pred: torch.Tensor, other: torch.Tensor, train: bool = True) -> torch.Tensor:
@@ -392,19 +425,23 @@ class StepEngine:
         mk = self.g_masks if train else [None, None, None]
         S = self.S
         self._conv("G.down1.fwd", conv_flops(B, S, 3, 64), ops.conv_fwd, x8, self.gd_wf[0], d1, 8, 64, act=LRELU)
-        self._conv("G.down2.fwd", conv_flops(B, S // 2, 64, 128), ops.conv_fwd, d1, self.gd_wf[1], self.g_zd[1], 64, 128)
-        ops.in_act_fwd(self.g_zd[1], d2, self.g_dmean[1], self.g_drstd[1], 128, LRELU)
-        self._conv("G.down3.fwd", conv_flops(B, S // 4, 128, 256), ops.conv_fwd, d2, self.gd_wf[2], self.g_zd[2], 128, 256)
-        ops.in_act_fwd(self.g_zd[2], d3, self.g_dmean[2], self.g_drstd[2], 256, LRELU)
-        self._conv("G.down4.fwd", conv_flops(B, S // 8, 256, 512), ops.conv_fwd, d3, self.gd_wf[3], self.g_zd[3], 256, 512)
-        ops.in_act_fwd(self.g_zd[3], self.g_d4, self.g_dmean[3], self.g_drstd[3], 512, LRELU, mask=mk[0])
+        dins, douts, dmask = [None, d1, d2, d3], [None, d2, d3, self.g_d4], [None, None, None, mk[0]]
+        for k in (1, 2, 3):
+            cin, cout = G_DOWN[k]
+            ns, st = self._split("fwd", self.g_zd[k], B, S >> k, cin, cout)
+            self._conv(f"G.down{k + 1}.fwd", conv_flops(B, S >> k, cin, cout), ops.conv_fwd, dins[k], self.gd_wf[k],
+                       self.g_zd[k], cin, cout, split_stride=st)
+            ops.in_act_fwd(self.g_zd[k], douts[k], self.g_dmean[k], self.g_drstd[k], cout, LRELU, mask=dmask[k],
+                           nslab=ns, slab_stride=st)
         ins = [self.g_d4, self.g_cat1, self.g_cat2, self.g_cat3]
         outs = [self.g_cat1[..., :256], self.g_cat2[..., :128], self.g_cat3[..., :64], self.g_u4]
         for k, (cint, coutt) in enumerate(G_UP):
+            ns, st = self._split("dgrad", self.g_zu[k], B, S >> (3 - k), coutt, cint) if k < 3 else (1, 0)
             self._conv(f"G.up{k + 1}.fwd", conv_flops(B, S >> (3 - k), coutt, cint), ops.conv_dgrad, ins[k],
-                       self.gu_wt[k], self.g_zu[k], coutt, cint)
+                       self.gu_wt[k], self.g_zu[k], coutt, cint, split_stride=st)
             ops.in_act_fwd(self.g_zu[k], outs[k], self.g_umean[k], self.g_urstd[k], coutt, RELU,
-                           mask=mk[k + 1] if k < 2 else None, pool=self.g_poolsum if k == 3 else None)
+                           mask=mk[k + 1] if k < 2 else None, pool=self.g_poolsum if k == 3 else None,
+                           nslab=ns, slab_stride=st)
         ops.pool_fc_tanh_fwd(self.g_u4, self.G.views["fc_delta.1.weight"], self.G.views["fc_delta.1.bias"],
                              self.delta_scale, self.g_pooled, self.g_traw, self.g_delta, pool_sum=self.g_poolsum)
         return self.g_delta

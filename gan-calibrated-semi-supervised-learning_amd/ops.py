@@ -65,19 +65,32 @@ def prep_c5_weight(w, wp):
 
 
 # ---- conv k4 s2 p1
-def conv_fwd(x, wf, y, cin, cout, bias=None, gscale=None, group_n=0, act=0):
-    """y may be fp32 while x is bf16 (pre-InstanceNorm tensors are kept in fp32)."""
+def conv_fwd(x, wf, y, cin, cout, bias=None, gscale=None, group_n=0, act=0, split_stride=0):
+    """y may be fp32 while x is bf16 (pre-InstanceNorm tensors are kept in fp32).  split_stride > 0: a K-split launch
+    stores its partial sums in fp32 slabs y + k*split_stride instead of adding atomically (see conv_splits)."""
     N, Hi, Wi, _ = x.shape
     out_f32 = 1 if (y.dtype == torch.float32 and x.dtype != torch.float32) else 0
     call("gcssl_conv4x4s2_fwd", code(x), x, _ld(x), wf, bias, gscale, group_n, y, _ld(y), N, Hi, Wi, cin, cout, act,
-         out_f32)
+         out_f32, int(split_stride))
 
 
-def conv_dgrad(dy, wt, dx, cin, cout, gscale=None, group_n=0):
+def conv_splits(kind, dt, N, Hi, cin, cout, act=0, out_f32=1) -> int:
+    """K split the dispatcher uses for a forward ('fwd') or dgrad-form ('dgrad') conv of these shapes."""
+    if kind == "fwd":
+        r = _lib.call_nostream("gcssl_conv4x4s2_fwd_splits", dt, N, Hi, Hi, cin, cout, act, out_f32)
+    else:
+        r = _lib.call_nostream("gcssl_conv4x4s2_dgrad_splits", dt, N, Hi, Hi, cin, cout, out_f32)
+    if r <= 0:
+        raise RuntimeError(f"conv_splits{(kind, N, Hi, cin, cout)} -> {r}")
+    return r
+
+
+def conv_dgrad(dy, wt, dx, cin, cout, gscale=None, group_n=0, split_stride=0):
     """dx: [N][Hi][Wi][>=cin] (fp32 output allowed whatever dy's dtype), dy: [N][Hi/2][Wi/2][>=cout]."""
     N, Hi, Wi, _ = dx.shape
     out_f32 = 1 if (dx.dtype == torch.float32 and dy.dtype != torch.float32) else 0
-    call("gcssl_conv4x4s2_dgrad", code(dy), dy, _ld(dy), wt, gscale, group_n, dx, _ld(dx), N, Hi, Wi, cin, cout, out_f32)
+    call("gcssl_conv4x4s2_dgrad", code(dy), dy, _ld(dy), wt, gscale, group_n, dx, _ld(dx), N, Hi, Wi, cin, cout, out_f32,
+         int(split_stride))
 
 
 def wgrad_splits(N, Hi, Wi, cin, cout) -> int:
@@ -160,11 +173,12 @@ def c5_wgrad(x, dw, C, dout=None, consts=(0.0, 0.0, 0.0), group_n=1):
 
 
 # ---- norm / activation
-def in_act_fwd(z, a, mean, rstd, C, act, mask=None, pool=None):
-    """z: fp32 pre-norm tensor; a: activation output in the compute dtype."""
+def in_act_fwd(z, a, mean, rstd, C, act, mask=None, pool=None, nslab=1, slab_stride=0):
+    """z: fp32 pre-norm tensor; a: activation output in the compute dtype.  nslab > 1: z is the first of nslab split-K
+    slabs slab_stride floats apart; they are summed on load and the total is written back to z."""
     N, H, W, _ = z.shape
     assert z.dtype == torch.float32
-    call("gcssl_in_act_fwd", code(a), z, _ld(z), a, _ld(a), mean, rstd, mask, pool, N, H * W, C, act)
+    call("gcssl_in_act_fwd", code(a), z, _ld(z), a, _ld(a), mean, rstd, mask, pool, nslab, int(slab_stride), N, H * W, C, act)
 
 
 def in_act_bwd(z, mean, rstd, dzs, C, act, da=None, da2=None, da_bcast=None, mask=None, zt=None, zt_n0=0,

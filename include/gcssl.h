@@ -58,11 +58,17 @@ int gcssl_prep_c5_weight(const float* w, float* wp, int C, void* stream);
  * out_f32: write y as fp32 whatever dtype (pre-InstanceNorm tensors are always fp32, see gcssl_in_act_fwd). */
 int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const float* bias, const float* gscale,
                         int group_n, void* y, int ldy, int N, int Hi, int Wi, int Cin, int Cout, int act, int out_f32,
-                        void* stream);
+                        long split_stride, void* stream);
+/* K split the dispatcher uses for these shapes (>= 1).  With split_stride > 0 the ks partial sums are stored plainly in
+ * fp32 slabs y + k*split_stride (no memset, no atomics: float atomics run at 1.3 TB/s chip-wide) and the consumer
+ * adds them (gcssl_in_act_fwd nslab); with split_stride = 0 they are added atomically into y, which the call zeroes. */
+int gcssl_conv4x4s2_fwd_splits(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int act, int out_f32);
 /* data gradient of the conv == ConvTranspose2d(k4,s2,p1) forward (cgan/models.py:72,113):
  * dx[N][Hi][Wi][lddx>=Cin] = gscale * convT(dy[N][Hi/2][Wi/2][lddy>=Cout], W).  out_f32: write fp32 whatever dtype. */
 int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, const float* gscale, int group_n,
-                          void* dx, int lddx, int N, int Hi, int Wi, int Cin, int Cout, int out_f32, void* stream);
+                          void* dx, int lddx, int N, int Hi, int Wi, int Cin, int Cout, int out_f32,
+                          long split_stride, void* stream);
+int gcssl_conv4x4s2_dgrad_splits(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int out_f32);
 /* weight gradient: slab[s][Cout][16][Cin] (fp32, s < gcssl_conv4x4s2_wgrad_splits(...)) partial sums over the
  * s-th K range of sum_{n,oy,ox} dy[n,oy,ox,co] x[n,2oy-1+ky,2ox-1+kx,ci].  Cin is 8 (padded first layer) or >= 64. */
 int gcssl_conv4x4s2_wgrad_splits(int N, int Hi, int Wi, int Cin, int Cout);
@@ -95,8 +101,8 @@ int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dou
  * act: 1 LeakyReLU(0.2), 2 ReLU.  mask: dropout keep mask [N][HW][C] (uint8) or NULL; kept values are scaled by 2.
  * The pre-norm tensor z and every incoming gradient (da, da2, gb_a, qz, zt) are ALWAYS fp32 (z - mean(z) and
  * dn - mean(dn) over 4..64 elements cancel a bf16 mantissa); tensors that feed an MFMA (a, dzs, gt_a, gb_zs) are `dtype`. */
-int gcssl_in_act_fwd(int dtype, const float* z, int ldz, void* a, int lda, float* mean, float* rstd, const uint8_t* mask,
-                     float* pool, int N, int HW, int C, int act, void* stream);
+int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean, float* rstd, const uint8_t* mask,
+                     float* pool, int nslab, long slab_stride, int N, int HW, int C, int act, void* stream);
 /* pool (nullable): [N][C] fp32, += sum over H*W of the activation output (AdaptiveAvgPool2d(1) of cgan/models.py:118,
  * fused; caller zeroes it and divides by H*W). */
 /* first-order backward: dn = act'(xhat) (da + da2 + da_bcast) [*2 keep]; dz = rstd (dn - mean dn - xhat mean(dn xhat))

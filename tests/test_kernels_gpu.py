@@ -417,3 +417,36 @@ def test_striped_bias_and_cdot_sums(ops):
     assert torch.equal(dz1, dz2)
     assert int((rep[:, :C].abs().sum(1) > 0).sum()) > 1                     # the sums really are spread over replicas
     assert rel_err(db2.cpu(), db1.cpu()) < 1e-5 and rel_err((cd2 - 1.0).cpu(), cd1.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("kind", ["fwd", "dgrad"])
+def test_split_k_slab_mode_matches_atomic_mode(ops, kind):
+    """A K-split conv that stores per-split slabs + in_act_fwd(nslab) == the atomic form + plain in_act_fwd."""
+    dt = torch.bfloat16
+    N, Hi, Cin, Cout = 64, 8, 256, 512                      # G.down4-like: small M, long K -> the dispatcher splits
+    w = rnd(Cout, Cin, 4, 4, seed=91, scale=0.05)
+    wf, wt = packed_weights(ops, w, dt)
+    if kind == "fwd":
+        x = nhwc(q(rnd(N, Cin, Hi, Hi, seed=92), dt), dt)
+        ks = ops.conv_splits("fwd", ops.code(x), N, Hi, Cin, Cout)
+        shape, C = (N, Hi // 2, Hi // 2, Cout), Cout
+        run = lambda y, st: ops.conv_fwd(x, wf, y, Cin, Cout, split_stride=st)
+    else:
+        dy = nhwc(q(rnd(N, Cout, Hi // 2, Hi // 2, seed=93), dt), dt)
+        ks = ops.conv_splits("dgrad", ops.code(dy), N, Hi, Cin, Cout)
+        shape, C = (N, Hi, Hi, Cin), Cin
+        run = lambda y, st: ops.conv_dgrad(dy, wt, y, Cin, Cout, split_stride=st)
+    assert ks > 1
+    z_atomic = torch.empty(shape, device="cuda")
+    run(z_atomic, 0)
+    slabs = torch.full((ks,) + shape, float("nan"), device="cuda")
+    run(slabs[0], slabs.stride(0))
+    torch.cuda.synchronize()
+    assert rel_err(slabs.sum(0).cpu(), z_atomic.cpu()) < 1e-5
+    a1 = torch.empty(shape, device="cuda", dtype=dt); a2 = torch.empty_like(a1)
+    m1 = torch.empty(N, C, device="cuda"); r1 = torch.empty(N, C, device="cuda"); m2 = torch.empty_like(m1); r2 = torch.empty_like(r1)
+    ops.in_act_fwd(z_atomic, a1, m1, r1, C, 1)
+    ops.in_act_fwd(slabs[0], a2, m2, r2, C, 1, nslab=ks, slab_stride=slabs.stride(0))
+    torch.cuda.synchronize()
+    assert rel_err(slabs[0].cpu(), z_atomic.cpu()) < 1e-5                  # the total was written back to slab 0
+    assert rel_err(a2.float().cpu(), a1.float().cpu()) < 1e-2 and rel_err(r2.cpu(), r1.cpu()) < 1e-4
