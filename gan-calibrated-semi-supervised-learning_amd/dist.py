@@ -50,6 +50,19 @@ class GradAverager:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.mul_(1.0 / self.world)
 
+    # split form: the collective runs on the backend's own stream (RCCL) / thread (gloo) while the caller keeps launching
+    # work that does not need the result; finish() orders the caller's stream behind it.
+    def start(self, flat: torch.Tensor):
+        if self.world == 1:
+            return None
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self, handle, flat: torch.Tensor) -> None:
+        if handle is None:
+            return
+        handle.wait()
+        flat.mul_(1.0 / self.world)
+
 
 def shard(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     """Equal split along the batch dim (dim 0); the batch must divide evenly so mean-of-means == global mean."""

@@ -410,10 +410,11 @@ class StepEngine:
     # ------------------------------------------------------------------------------------------ generator forward
     def _set_masks(self, masks: Optional[Sequence[torch.Tensor]], phase: int = 0):
         """masks given as NCHW keep-masks (fixture/parity mode) or None -> drawn on the device.  The draw is keyed by
-        (seed, phase, critic step count): the step count lives on the device (Adam state), so graph replays draw fresh
-        masks; phase 0 = the forwards of the critic steps, 1 = the generator step, 2 = generator_delta()."""
+        (seed, phase, generator step count): the count lives on the device (Adam state), so graph replays draw fresh
+        masks, and it is constant within an iteration, so the draw does not depend on where d_pre runs relative to the
+        critic updates; phase 10+k = critic step k, 1 = the generator step, 2 = generator_delta()."""
         if masks is None:
-            ops.dropout_mask_gen(self.g_maskbuf, self.seed * 131 + phase, self.D.state)
+            ops.dropout_mask_gen(self.g_maskbuf, self.seed * 131 + phase, self.G.state)
         else:
             for m, src in zip(self.g_masks, masks):
                 m.copy_(src.permute(0, 2, 3, 1))
@@ -460,10 +461,26 @@ class StepEngine:
         self.d_compute(pred, gt, refine_fn, k, alpha, masks)
         self.d_update()
 
-    def d_update(self) -> None:
-        """all-reduce (data parallel) -> clip_grad_norm_(1.0) -> Adam  (:331-332)."""
+    def allreduce_start(self, flat: torch.Tensor):
+        """Begin averaging a flat gradient over the ranks without blocking this stream (dist.GradAverager.start);
+        hooks that are plain callables run synchronously here."""
+        start = getattr(self.allreduce, "start", None)
+        if start is None:
+            self.allreduce(flat)
+            return None
+        return start(flat)
+
+    def _allreduce_finish(self, handle, flat: torch.Tensor) -> None:
+        if handle is not None:
+            self.allreduce.finish(handle, flat)
+
+    def d_update(self, handle="sync") -> None:
+        """all-reduce (data parallel) -> clip_grad_norm_(1.0) -> Adam  (:331-332).  handle: what allreduce_start
+        returned when the exchange was started earlier; "sync" = do it here."""
         self._join_side()
-        if self.allreduce is not None:
+        if handle != "sync":
+            self._allreduce_finish(handle, self.D.g)
+        elif self.allreduce is not None:
             self.allreduce(self.D.g)
         ops.clip_adam(self.D.p, self.D.g, self.D.m, self.D.v, self.D.state, self.lr, self.betas[0], self.betas[1],
                       write_clipped=1 if self.keep_clipped_grads else 2)     # 2: the update also re-zeroes the bucket
@@ -472,7 +489,29 @@ class StepEngine:
 
     def d_compute(self, pred, gt, refine_fn, k: int, alpha: Optional[torch.Tensor], masks) -> None:
         """Forward passes, gradient penalty and all critic gradients of one critic step (:305-330); pure kernel
-        launches on the current stream (hipGraph capturable)."""
+        launches on the current stream (hipGraph capturable).  Two parts: d_pre does not depend on the critic's weights
+        (with data parallelism it runs under the previous critic step's all-reduce), d_main does."""
+        self.d_pre(pred, gt, refine_fn, k, alpha, masks)
+        self.d_main()
+
+    def d_pre(self, pred, gt, refine_fn, k: int, alpha: Optional[torch.Tensor], masks) -> None:
+        """The generator side of a critic step: no-grad train-mode forward (:311-312), the re-crop (:313-315), alpha
+        (cgan/losses.py:199) and the packed fake / interpolated groups."""
+        B = self.B
+        I = slice(2 * B, 3 * B)
+        self._prep_g()
+        ops.pack_pair(pred, gt, self.x0[:B])                       # real group; channels 0-2 = pred are G's input too
+        self._set_masks(masks, 10 + k)                             # keyed by (seed, step index, critic step count)
+        delta_det = self._g_forward(self.x0[:B], True)
+        refined = refine_fn(delta_det, k)                          # :313-315
+        if alpha is None:
+            alpha = self.alpha_buf
+            ops.uniform_gen(alpha, self.seed * 131 + 7 + 16 * k, self.G.state)
+        ops.pack_pair(pred, refined, self.x0[B:2 * B])
+        ops.pack_interp(pred, gt, refined, alpha, self.x0[I])
+
+    def d_main(self) -> None:
+        """The critic side: spectral-norm iterations, the 3B-sample forward, gradient penalty, all gradients."""
         B, S, N3 = self.B, self.S, 3 * self.B
         I = slice(2 * B, 3 * B)
         isig = self.sn.isig
@@ -480,22 +519,11 @@ class StepEngine:
             for slot in range(3):                                 # real, fake, interp forwards each iterate once
                 self.sn.iterate(slot, True)
             self._prep_d()
-        self._on_side(sn_and_prep, 0, 1)                                # overlaps the generator forward below
+        self._on_side(sn_and_prep, 0, 1)
         if not self.D.grads_zero:                                 # optimizer.zero_grad() (:305) unless the last update did it
             self.D.g.zero_()
         self.D.grads_zero = False
         self.zero_blk.zero_()                                      # scalars + the striped-sum replicas
-        self._prep_g()
-        # no-grad generator forward in train mode (:311-312) on the real-group input (channels 0-2 = pred)
-        ops.pack_pair(pred, gt, self.x0[:B])
-        self._set_masks(masks)
-        delta_det = self._g_forward(self.x0[:B], True)
-        refined = refine_fn(delta_det, k)                          # :313-315
-        if alpha is None:                                         # cgan/losses.py:199, keyed like the dropout masks
-            alpha = self.alpha_buf
-            ops.uniform_gen(alpha, self.seed * 131 + 7, self.D.state)
-        ops.pack_pair(pred, refined, self.x0[B:2 * B])
-        ops.pack_interp(pred, gt, refined, alpha, self.x0[I])
         self._join_side()                                         # sigma, u/v history and packed weights are ready
         self._d_forward(N3, lambda l: isig[l], B)
         ops.group_mean(self.d_out, 3, self.means)
@@ -571,9 +599,11 @@ class StepEngine:
         self.g_compute(pred, delta_true, pred_box, refine_fn, masks)
         self.g_update()
 
-    def g_update(self) -> None:
+    def g_update(self, handle="sync") -> None:
         self._join_side()
-        if self.allreduce is not None:
+        if handle != "sync":
+            self._allreduce_finish(handle, self.G.g)
+        elif self.allreduce is not None:
             self.allreduce(self.G.g)
         ops.clip_adam(self.G.p, self.G.g, self.G.m, self.G.v, self.G.state, self.lr, self.betas[0], self.betas[1],
                       write_clipped=1 if self.keep_clipped_grads else 2)                # :368-369
@@ -581,6 +611,22 @@ class StepEngine:
         self._g_dirty = True
 
     def g_compute(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
+        """The generator step's launches (:345-366).  g_main (forward, EIoU, backward: the gradient) and g_critic (the
+        value-only critic forward of :361-362) are independent of each other; with data parallelism g_critic runs under
+        the generator gradient's all-reduce."""
+        self.g_main(pred, delta_true, pred_box, refine_fn, masks)
+        self.g_critic(pred)
+
+    def g_critic(self, pred) -> None:
+        """D forward on (pred, refined_G): value only (zero gradient to G) but it advances u,v (:361)."""
+        B = self.B
+        self.sn.iterate(0, True)
+        self._prep_d()
+        ops.pack_pair(pred, self._refined_g, self.x0[B:2 * B])     # x0[:B] stays G's input (down1's wgrad operand)
+        self._d_forward(B, lambda l: self.sn.isig[l, 0:1], B, x=self.x0[B:2 * B])
+        ops.group_mean(self.d_out[:B], 1, self.wgan_mean)                              # loss_WGAN_G = -mean (:362)
+
+    def g_main(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
         B, S = self.B, self.S
         self.scal[13:].zero_()
         self._prep_g()
@@ -590,16 +636,7 @@ class StepEngine:
         ops.eiou_fwd_bwd(pred_box, self.g_delta, delta_true, self.lambda_iou, self.g_gdelta, self.g_cal,
                          self.eiou_acc)                                                # :351-355
         self.delta_pred = self.g_delta.clone()
-        # D forward on (pred, refined_G): value only (zero gradient to G) but it advances u,v (:361)
-        refined_g = refine_fn(self.delta_pred, self.c)                                 # :358-360
-
-        def critic_branch():            # independent of G's backward: own input buffer, the critic's activations
-            self.sn.iterate(0, True)
-            self._prep_d()
-            ops.pack_pair(pred, refined_g, self.x0[B:2 * B])       # x0[:B] stays G's input for the down1 wgrad
-            self._d_forward(B, lambda l: self.sn.isig[l, 0:1], B, x=self.x0[B:2 * B])
-            ops.group_mean(self.d_out[:B], 1, self.wgan_mean)                          # loss_WGAN_G = -mean (:362)
-        self._on_side(critic_branch, 1, 1)
+        self._refined_g = refine_fn(self.delta_pred, self.c)                           # :358-360
         # ---- backward of lambda_iou * EIoU through G (:365-366)
         if not self.G.grads_zero:
             self.G.g.zero_()
@@ -703,29 +740,50 @@ class GraphedIteration:
         self.fused_update = eng.allreduce is None
         self.d_graphs, self.g_graph = [], None
         pool = None
-        for k in range(eng.c):
-            eng._d_dirty, eng._g_dirty = True, (k == 0)       # weights change between replays: keep the prep kernels
+
+        def capture(fn):
+            nonlocal pool
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
-                eng.d_compute(pred, gt, refine_fn, k, None, None)
-                if self.fused_update:
-                    eng.d_update()
+                fn()
             pool = g.pool()
-            self.d_graphs.append(g)
-        eng._d_dirty, eng._g_dirty = True, False
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=pool):
-            eng.g_compute(pred, delta_true, pred_box, refine_fn, None)
-            if self.fused_update:
-                eng.g_update()
-        self.g_graph = g
+            return g
+
+        if self.fused_update:
+            for k in range(eng.c):
+                eng._d_dirty, eng._g_dirty = True, (k == 0)   # weights change between replays: keep the prep kernels
+                self.d_graphs.append(capture(lambda k=k: (eng.d_compute(pred, gt, refine_fn, k, None, None), eng.d_update())))
+            eng._d_dirty, eng._g_dirty = True, False
+            self.g_graph = capture(lambda: (eng.g_compute(pred, delta_true, pred_box, refine_fn, None), eng.g_update()))
+            return
+        # data parallel: every all-reduce runs beside launches that do not need its result --
+        #   critic step k's gradient  ||  d_pre of step k+1 (G's no-grad forward, re-crop, packing) or, after the last
+        #                                 critic step, g_main (G's forward + backward)
+        #   the generator's gradient  ||  g_critic (the value-only critic forward of the generator step)
+        self.pre, self.main = [], []
+        for k in range(eng.c):
+            eng._g_dirty = (k == 0)
+            self.pre.append(capture(lambda k=k: eng.d_pre(pred, gt, refine_fn, k, None, None)))
+            eng._d_dirty = True
+            self.main.append(capture(eng.d_main))
+        eng._g_dirty = False
+        self.g_main = capture(lambda: eng.g_main(pred, delta_true, pred_box, refine_fn, None))
+        eng._d_dirty = True
+        self.g_crit = capture(lambda: eng.g_critic(pred))
 
     def replay(self):
         eng = self.eng
-        for g in self.d_graphs:
-            g.replay()
-            if not self.fused_update:
-                eng.d_update()
-        self.g_graph.replay()
-        if not self.fused_update:
-            eng.g_update()
+        if self.fused_update:
+            for g in self.d_graphs:
+                g.replay()
+            self.g_graph.replay()
+            return
+        self.pre[0].replay()
+        for k in range(eng.c):
+            self.main[k].replay()
+            h = eng.allreduce_start(eng.D.g)
+            (self.pre[k + 1] if k + 1 < eng.c else self.g_main).replay()
+            eng.d_update(h)
+        h = eng.allreduce_start(eng.G.g)
+        self.g_crit.replay()
+        eng.g_update(h)

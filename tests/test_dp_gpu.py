@@ -70,3 +70,45 @@ def test_two_rank_iteration_matches_single_process(tmp_path):
         assert (diff > 0.05 * lr * steps).mean() < 0.01, k
         assert diff.max() <= 2.2 * lr * steps, k
     assert np.abs(a["u"] - b["u"]).max() < 1e-5
+
+
+def _run_graphed(rank, world, port, out_dir):
+    """The graphed data-parallel path (all-reduces started early and finished behind independent launches) against the
+    eager one on the same ranks: same device-side mask / alpha draws, same collectives, so the weights must agree."""
+    import importlib
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), GCSSL_DIST_BACKEND="gloo", GCSSL_SINGLE_DEVICE="1")
+    dist_mod = importlib.import_module(PKG + ".dist")
+    synth = importlib.import_module(PKG + ".synth")
+    engine = importlib.import_module(PKG + ".engine")
+    dist_mod.init_from_env()
+    T = torch.from_numpy
+    seed, B, S, c = 23, 8, 32, 2
+    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+    d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+    inp = synth.step_inputs(seed, B, S, c, tag="dpgraph")
+    sh = lambda a: dist_mod.shard(T(a), rank, world).contiguous().cuda()
+    refined = [sh(x) for x in inp["refined"]]
+    call = (sh(inp["pred"]), sh(inp["gt"]), sh(inp["delta_true"]), sh(inp["pred_box"]), lambda delta, k: refined[k])
+    mk = lambda: engine.StepEngine(g, d, batch=B // world, size=S, n_critic=c, dtype="fp32", device="cuda:0",
+                                   seed=77 + rank, allreduce=dist_mod.GradAverager(), keep_clipped_grads=False)
+    eager, graphed = mk(), mk()
+    for _ in range(2):
+        eager.run_iteration(*call)
+    gi = engine.GraphedIteration(graphed, *call)
+    for _ in range(2):
+        gi.replay()
+    torch.cuda.synchronize()
+    lr = 2e-4
+    for name, a, b, steps in (("D", eager.D.p, graphed.D.p, 4), ("G", eager.G.p, graphed.G.p, 2)):
+        diff = (a - b).abs()
+        assert float((diff > 0.05 * lr * steps).float().mean()) < 0.02, (name, float((diff > 0.05 * lr * steps).float().mean()))
+        assert float(diff.max()) <= 2.2 * lr * steps, name
+    assert float(graphed.D.state[0]) == 4.0 and float(graphed.G.state[0]) == 2.0
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_graphed_overlapped_allreduce_matches_eager():
+    mp.spawn(_run_graphed, args=(2, _free_port(), ""), nprocs=2, join=True)
