@@ -43,7 +43,12 @@ def test_every_declared_symbol_is_exported(lib_mod):
 def test_argument_validation_without_gpu(lib_mod):
     """Pure host-side checks return negative codes before any launch (safe on a CPU-only box)."""
     h = lib_mod.lib()
-    assert h.gcssl_conv4x4s2_fwd(0, None, 8, None, None, None, 0, None, 64, 1, 8, 8, 8, 64, 0, 0, None) == -4
+    assert h.gcssl_conv4x4s2_fwd(0, None, 8, None, None, None, 0, None, 64, 1, 8, 8, 8, 64, 0, 0, 0, None) == -4
+    assert h.gcssl_conv4x4s2_fwd_splits(1, 256, 4, 4, 256, 512, 0, 1) >= 1     # dry run of the dispatcher: host only
+    assert h.gcssl_conv4x4s2_dgrad_splits(1, 256, 4, 4, 256, 512, 1) >= 1
+    assert h.gcssl_conv4x4s2_fwd_splits(1, 256, 12, 12, 256, 512, 0, 1) == -1  # non power-of-two spatial size
+    assert h.gcssl_recrop_ws_ints(256, 32, 1280) > 0 and h.gcssl_recrop_ws_ints(0, 32, 1280) == -1
+    assert h.gcssl_sum_replicas(1, None, None, None, 4, 64, 0, None) == -4
     assert h.gcssl_conv4x4s2_wgrad_splits(4, 12, 12, 64, 64) == -1          # non power-of-two spatial size
     assert h.gcssl_conv4x4s2_wgrad_splits(256, 16, 16, 64, 128) > 0
     assert h.gcssl_gp_norm(None, 10, 2, ctypes.c_float(1.0), None, None, None, None) == -4
