@@ -636,7 +636,8 @@ int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dou
     if (!x || !dw) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || ldx < C || (!dout && group_n <= 0)) return GCSSL_EBADSHAPE;
-    int zs = N / 48; if (zs < 1) zs = 1; if (zs > 16) zs = 16;
+    static const int zcap = [] { const char* e = getenv("GCSSL_C5_ZS"); return e ? atoi(e) : 16; }();
+    int zs = N * zcap / 768; if (zs < 1) zs = 1; if (zs > zcap) zs = zcap;
     const int per = (N + zs - 1) / zs;
     dim3 grid((C + 63) / 64, 16, zs);
     if (dtype == GCSSL_F32) hipLaunchKernelGGL(c5_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C, per);
