@@ -491,8 +491,13 @@ class StepEngine:
         """Forward passes, gradient penalty and all critic gradients of one critic step (:305-330); pure kernel
         launches on the current stream (hipGraph capturable).  Two parts: d_pre does not depend on the critic's weights
         (with data parallelism it runs under the previous critic step's all-reduce), d_main does."""
-        self.d_pre(pred, gt, refine_fn, k, alpha, masks)
-        self.d_main()
+        if self.overlap >= 1 and self.probe is None:              # SN + re-pack on the side stream, under the generator forward
+            self._on_side(self._sn_and_prep, 0, 1)
+            self.d_pre(pred, gt, refine_fn, k, alpha, masks)
+            self.d_main(sn_done=True)
+        else:
+            self.d_pre(pred, gt, refine_fn, k, alpha, masks)
+            self.d_main()
 
     def d_pre(self, pred, gt, refine_fn, k: int, alpha: Optional[torch.Tensor], masks) -> None:
         """The generator side of a critic step: no-grad train-mode forward (:311-312), the re-crop (:313-315), alpha
@@ -510,16 +515,18 @@ class StepEngine:
         ops.pack_pair(pred, refined, self.x0[B:2 * B])
         ops.pack_interp(pred, gt, refined, alpha, self.x0[I])
 
-    def d_main(self) -> None:
+    def _sn_and_prep(self) -> None:
+        for slot in range(3):                                     # real, fake, interp forwards each iterate once
+            self.sn.iterate(slot, True)
+        self._prep_d()
+
+    def d_main(self, sn_done: bool = False) -> None:
         """The critic side: spectral-norm iterations, the 3B-sample forward, gradient penalty, all gradients."""
         B, S, N3 = self.B, self.S, 3 * self.B
         I = slice(2 * B, 3 * B)
         isig = self.sn.isig
-        def sn_and_prep():
-            for slot in range(3):                                 # real, fake, interp forwards each iterate once
-                self.sn.iterate(slot, True)
-            self._prep_d()
-        self._on_side(sn_and_prep, 0, 1)
+        if not sn_done:
+            self._sn_and_prep()
         if not self.D.grads_zero:                                 # optimizer.zero_grad() (:305) unless the last update did it
             self.D.g.zero_()
         self.D.grads_zero = False
