@@ -751,7 +751,9 @@ class GraphedIteration:
         def capture(fn):
             nonlocal pool
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            # thread_local: with data parallelism RCCL's watchdog thread polls events while we capture; only THIS thread's
+            # calls belong to the capture
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 fn()
             pool = g.pool()
             return g
