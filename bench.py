@@ -143,6 +143,8 @@ def main():
     n_dom, ms_dom, fl_dom, by_dom = prof[dom]
     conv_ms = sum(tot.values()) / args.probe_steps
     conv_flops = sum(n * f for (n, _, f, _) in prof.values()) / args.probe_steps
+    d_ms = sum(v for k, v in tot.items() if k.startswith("D.")) / args.probe_steps
+    d_flops = sum(n * f for k, (n, _, f, _) in prof.items() if k.startswith("D.")) / args.probe_steps
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     ach = fl_dom / (ms_dom * 1e-3) / 1e12
     # which roof binds this kernel: time at the HBM peak for its algorithmic bytes vs time at the MFMA peak for its FLOPs
@@ -161,7 +163,10 @@ def main():
                     algorithmic=dict(flops=fl_dom, bytes=by_dom, tflops=round(ach, 2), gbs=round(ach_gbs, 1),
                                      mfma_frac=round(ach / peak, 4), hbm_frac=round(ach_gbs / HBM_PEAK_GBS, 4)),
                     all_convs=dict(tflops=round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), ms_per_iter=round(conv_ms, 3),
-                                   frac=round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4)))
+                                   frac=round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4)),
+                    # MFMA utilisation of the critic's conv stack (every D.* conv launch of an iteration)
+                    d_convs=dict(tflops=round(d_flops / (d_ms * 1e-3) / 1e12, 2), ms_per_iter=round(d_ms, 3),
+                                 frac=round(d_flops / (d_ms * 1e-3) / 1e12 / peak, 4)))
     flop_iter = ((12 * c + 1) * F_D[S] + (c + 3) * F_G[S]) * B * world if S in F_D else None
 
     out = dict(metric="images/sec (G+D step)", value=round(value, 1), unit="images/s", n_gpus=world, steps=args.steps,
