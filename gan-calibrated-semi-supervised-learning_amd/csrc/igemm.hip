@@ -1400,7 +1400,11 @@ int gcssl_conv4x4s2_wgrad_splits(int N, int Hi, int Wi, int Cin, int Cout) {
     if (want > 128) want = 128;                            // padded first layers have a single tile: bound the slab count
     if (want < 1) want = 1;
     if (want > nkt) want = nkt;
-    const int per = (nkt + (int)want - 1) / (int)want;
+    // ... but never fewer than `mink` K granules (64 pixels each) per split: below that a workgroup writes its fp32 slab
+    // tile (64 KB) for a handful of MFMAs and the slabs, not the contraction, set the time
+    static const int mink = [] { const char* e = getenv("GCSSL_WGRAD_MINK"); return e ? atoi(e) : 8; }();   // 1/8/16/32: 78.0/78.4/78.0/76.7k img/s
+    int per = (nkt + (int)want - 1) / (int)want;
+    if (per < mink) per = mink < nkt ? mink : nkt;
     return (nkt + per - 1) / per;
 }
 
