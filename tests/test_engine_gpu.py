@@ -190,13 +190,15 @@ def test_eval_mode_forward_matches_golden(synth):
         assert rel_err(dl, fix["train.g_delta"]) < 2e-4
 
 
-def test_full_size_iteration_matches_oracle(synth):
-    """BASELINE's bench configuration itself (B=256, 32x32, n_critic=2), fp32-MFMA mode, against the pinned CPU oracle on
-    the same seeded inputs: one whole iteration (two critic updates + the generator update) -- scalars, scores, delta,
-    the oracle's un-clipped gradients of the first critic step and of the generator step, and the updated weights."""
+@pytest.mark.parametrize("B,S", [(256, 32), (128, 64)])
+def test_full_size_iteration_matches_oracle(synth, B, S):
+    """BASELINE's configurations at full size -- the bench line (B=256, 32x32) and the STL shape (B=128, 64x64), n_critic=2 --
+    in fp32-MFMA mode against the pinned CPU oracle on the same seeded inputs: one whole iteration (two critic updates +
+    the generator update) -- scalars, scores, delta, the oracle's un-clipped gradients of the first critic step and of the
+    generator step, and the updated weights."""
     from oracle import cgan_oracle as O
     engine = load_pkg("engine")
-    seed, B, S, c = 42, 256, 32, 2
+    seed, c = 42, 2
     g = {k: T(v) for k, v in synth.generator_state(seed).items()}
     d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
     inp = synth.step_inputs(seed, B, S, c, tag="fullsize")
@@ -222,7 +224,15 @@ def test_full_size_iteration_matches_oracle(synth):
         if k in ("model.2.bias", "model.5.bias", "model.8.bias"):
             continue                                      # true gradient is exactly zero (cancelled by InstanceNorm)
         got, want = eng0.D.gviews[k].cpu() / coef, taps[f"d.grad.{k}"]
-        assert rel_err(got, want) < 1e-3, (k, rel_err(got, want))
+        if S == 32:
+            assert rel_err(got, want) < 1e-3, (k, rel_err(got, want))          # measured <= 4e-4
+        else:
+            # 64x64: 4x more pre-activations per sample; the few with |xhat| ~ 1e-7 take the other LeakyReLU branch than
+            # the CPU run and move single entries by ~1e-2 of the tensor's scale (as for G below): bulk, outliers, norm
+            err = (got - want).abs() / want.abs().max()
+            assert float((err < 5e-3).float().mean()) >= 0.995, (k, float((err < 5e-3).float().mean()))
+            assert float(err.max()) < 0.1, (k, float(err.max()))
+            assert abs(float(got.norm()) - float(want.norm())) < 5e-3 * float(want.norm()), k
     eng0.g_step(pred, T(inp["delta_true"]).cuda(), T(inp["pred_box"]).cuda(), lambda dl, k: refined[k],
                 [T(m).cuda() for m in inp["masks"][c]])
     torch.cuda.synchronize()
