@@ -757,9 +757,12 @@ bool bad_dtype(int dt) { return dt != GCSSL_F32 && dt != GCSSL_BF16; }
 // >= ~256 workgroups and, when per-group sums are accumulated, never straddles a sample group)
 int small_rg(int HW) { return HW <= 4 ? 1 : (HW <= 16 ? 4 : 16); }
 int small_spb(int N, int C, int rg, int group_n) {
+    // streaming passes want several workgroups per CU in flight (256 -> 1024: +2 % on the whole iteration); the sums they
+    // add atomically are striped over replicas, so more workgroups no longer means more contention
+    static const long min_wgs = [] { const char* e = getenv("GCSSL_IN_WGS"); return e ? atol(e) : 1024L; }();
     const int spp = RGN / rg;
     int spb = spp;
-    while (spb * 2 <= 64 && (long)(C / CW) * ((N + spb * 2 - 1) / (spb * 2)) >= 256 &&
+    while (spb * 2 <= 64 && (long)(C / CW) * ((N + spb * 2 - 1) / (spb * 2)) >= min_wgs &&
            (group_n <= 0 || group_n % (spb * 2) == 0)) spb *= 2;
     return spb;
 }
@@ -897,7 +900,8 @@ int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ld
     int rows = HW < 64 ? HW : 64;
     const int zc = (HW + rows - 1) / rows;
     int spb = 1;
-    while (spb * 2 <= 32 && (long)(C / CW) * zc * ((N + spb * 2 - 1) / (spb * 2)) >= 512 &&
+    static const long act_wgs = [] { const char* e = getenv("GCSSL_ACT_WGS"); return e ? atol(e) : 512L; }();
+    while (spb * 2 <= 32 && (long)(C / CW) * zc * ((N + spb * 2 - 1) / (spb * 2)) >= act_wgs &&
            (!cdot || q.group_n % (spb * 2) == 0)) spb *= 2;
     const int mixed = (cdot && q.group_n % spb) ? 1 : 0;
     dim3 grid(C / CW, (N + spb - 1) / spb, zc);
