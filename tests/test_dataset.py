@@ -143,7 +143,7 @@ def test_train_harness_on_a_dataset_directory(tmp_path):
     import train
     save = tmp_path / "run"
     train.main(["--source", "dataset", "--data_dir", str(root), "--img_size", "32", "--batch_size", "4", "--n_epochs", "2",
-                "--n_critic", "2", "--save_dir", str(save), "--compute_dtype", "fp32", "--train_split", "1.0"])
+                "--n_critic", "2", "--save_dir", str(save), "--compute_dtype", "fp32", "--train_split", "0.67"])   # 8 train / 4 val pairs
     hist = __import__("json").loads((save / "training_history.json").read_text())
     assert len(hist) == 2 and all(np.isfinite(h["loss_G"]) and np.isfinite(h["loss_D"]) for h in hist)
     ck = torch.load(save / "G_best.pth", weights_only=False) if (save / "G_best.pth").exists() else None

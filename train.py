@@ -113,14 +113,16 @@ def main(argv=None):
                             allreduce=dist_mod.GradAverager() if world > 1 else None)
     if world > 1:
         dist_mod.broadcast_state([eng.D.p, eng.G.p] + eng.u + eng.v)
-    train_idx = None
+    train_idx, val_idx = None, []
     if args.source == "dataset":
         dataset_mod = importlib.import_module(PKG + ".dataset")
         refine_mod = importlib.import_module(PKG + ".refine")
         ds = dataset_mod.CalibratorDataset(args.data_dir, img_size=args.img_size)
         g = torch.Generator().manual_seed(args.seed)
         perm = torch.randperm(len(ds), generator=g).tolist()
-        train_idx = perm[:int(args.train_split * len(ds))][rank::world]              # :219-231 (train part), sharded by rank
+        n_train = int(args.train_split * len(ds))
+        train_idx = perm[:n_train][rank::world]                                      # :219-231 (train part), sharded by rank
+        val_idx = perm[n_train:]                                                     # the validation part (rank 0 evaluates it)
         if rank == 0:
             print(f"dataset: {len(ds)} (pred, gt) pairs, {len(train_idx)} for training on this rank, {ds.atlas(device).n} images")
         if len(train_idx) < args.batch_size // world:
@@ -151,6 +153,18 @@ def main(argv=None):
         for k in stats:
             stats[k] /= max(n, 1)
         delta_iou = (iou_a - iou_b) / max(n, 1)
+        Bv = args.batch_size // world
+        if train_idx is not None and len(val_idx) >= Bv:
+            # validation of :395-420 on the held-out pairs: eval-mode G (dropout off), eval-mode box transform, plain IoU
+            sb = sa = 0.0
+            nv = 0
+            for b0 in range(0, len(val_idx) - Bv + 1, Bv):
+                pv, _, dtv, pbv, _ = ds.gpu_batch(val_idx[b0:b0 + Bv], device)
+                dv = eng.generator_delta(pv, train=False)
+                gtb = losses.apply_delta_to_bbox(pbv, dtv, training=False)
+                cal = losses.apply_delta_to_bbox(pbv, dv, training=False)
+                sb += float(losses.iou_metric(pbv, gtb).sum()); sa += float(losses.iou_metric(cal, gtb).sum()); nv += Bv
+            delta_iou = sa / nv - sb / nv
         history.append(dict(epoch=epoch, delta_iou=delta_iou, **stats))
         if rank == 0:
             print(f"[Epoch {epoch}/{args.n_epochs}] G: {stats['loss_G']:.3f} D: {stats['loss_D']:.3f} EIoU: {stats['loss_iou']:.3f} "
