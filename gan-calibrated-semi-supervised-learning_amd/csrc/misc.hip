@@ -118,30 +118,41 @@ __global__ void c5_dgrad_kernel(const float* __restrict__ dout, float g0, float 
 template <typename T>
 __global__ __launch_bounds__(256) void c5_wgrad_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ dout, float g0, float g1,
                                 float g2, int group_n, float* __restrict__ dw, int N, int Hi, int Wi, int C, int per) {
-    __shared__ float sm[4][64];
+    // block = 64 channels x a chunk of `per` samples; every input pixel is read ONCE and feeds the (<= 16) taps whose
+    // output position it touches: dw[c][ky][kx] += d(n, iy+1-ky, ix+1-kx) * x[n, iy, ix, c]
+    __shared__ float sm[4][16][64];
     const int Ho = Hi - 1, Wo = Wi - 1;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx, tap = blockIdx.y;
-    const int ky = tap >> 2, kx = tap & 3;
-    const int nb = blockIdx.z * per, ne = min(N, nb + per);
-    // valid output window for this tap: iy = oy-1+ky in [0,Hi)
-    const int oy0 = max(0, 1 - ky), oy1 = min(Ho, Hi + 1 - ky), ox0 = max(0, 1 - kx), ox1 = min(Wo, Wi + 1 - kx);
-    float s = 0.f;
+    const int c = blockIdx.x * 64 + tx;
+    const int nb = blockIdx.y * per, ne = min(N, nb + per);
+    float acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
     if (c < C) {
-#pragma unroll 4
         for (int n = nb + ty; n < ne; n += 4) {
             float gconst = 0.f;
             if (!dout) { const int g = n / group_n; gconst = g == 0 ? g0 : (g == 1 ? g1 : g2); }
-            for (int oy = oy0; oy < oy1; ++oy)
-                for (int ox = ox0; ox < ox1; ++ox) {
-                    const float d = dout ? dout[((size_t)n * Ho + oy) * Wo + ox] : gconst;
-                    s += d * Elem<T>::ld(x + ((size_t)(n * Hi + oy - 1 + ky) * Wi + ox - 1 + kx) * ldx + c);
+            for (int iy = 0; iy < Hi; ++iy)
+                for (int ix = 0; ix < Wi; ++ix) {
+                    const float xv = Elem<T>::ld(x + ((size_t)(n * Hi + iy) * Wi + ix) * ldx + c);
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int oy = iy + 1 - (t >> 2), ox = ix + 1 - (t & 3);
+                        if ((unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo)
+                            acc[t] += (dout ? dout[((size_t)n * Ho + oy) * Wo + ox] : gconst) * xv;
+                    }
                 }
         }
     }
-    sm[ty][tx] = s;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sm[ty][t][tx] = acc[t];
     __syncthreads();
-    if (ty == 0 && c < C) atomicAdd(dw + (size_t)c * 16 + tap, sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx]);
+    // 1024 sums (16 taps x 64 channels) over the 4 row groups; dw[c][tap]: a channel's 16 taps are contiguous
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+        const int cc = e >> 4, t = e & 15;
+        const int ch = blockIdx.x * 64 + cc;
+        if (ch < C) atomicAdd(dw + (size_t)ch * 16 + t, sm[0][t][cc] + sm[1][t][cc] + sm[2][t][cc] + sm[3][t][cc]);
+    }
 }
 
 // =========================================================================================
@@ -252,9 +263,12 @@ __global__ __launch_bounds__(256) void sn_sigma_kernel(SnBatch b) {
 // gradient penalty norm  cgan/losses.py:223-231:  nrm_b = sqrt(sum g^2 + 1e-12); gp = mean((nrm-1)^2)
 // also emits coef_b = lambda_gp * 2/B * (nrm_b-1)/nrm_b, the adjoint seed of the reverse pass.
 // =========================================================================================
+template <typename T>
 __global__ __launch_bounds__(256) void gp_norm_kernel(const float* __restrict__ g, size_t per_sample, int B, float lambda_gp,
-                                                     float* __restrict__ nrm, float* __restrict__ coef, float* gp_sum) {
+                                                     float* __restrict__ nrm, float* __restrict__ coef, float* gp_sum,
+                                                     T* __restrict__ scaled) {
     __shared__ float red[4];
+    __shared__ float cf;
     const int n = blockIdx.x;
     const float* p = g + (size_t)n * per_sample;
     float s = 0.f;
@@ -269,9 +283,16 @@ __global__ __launch_bounds__(256) void gp_norm_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) {
         const float nr = sqrtf(tot + 1e-12f);
         nrm[n] = nr;
-        coef[n] = lambda_gp * (2.0f / B) * (nr - 1.f) / nr;
+        const float c = lambda_gp * (2.0f / B) * (nr - 1.f) / nr;
+        coef[n] = c; cf = c;
         atomicAdd(gp_sum, (nr - 1.f) * (nr - 1.f) / B);
     }
+    if (!scaled) return;
+    // the adjoint seed of the reverse pass, g * coef[n], in the same launch (the sample's 32 KB are still in cache)
+    __syncthreads();
+    const float c = cf;
+    T* q = scaled + (size_t)n * per_sample;
+    for (size_t i = threadIdx.x; i < per_sample; i += 256) Elem<T>::st(q + i, p[i] * c);
 }
 
 template <typename T>
@@ -636,10 +657,10 @@ int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dou
     if (!x || !dw) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || ldx < C || (!dout && group_n <= 0)) return GCSSL_EBADSHAPE;
-    static const int zcap = [] { const char* e = getenv("GCSSL_C5_ZS"); return e ? atoi(e) : 16; }();
+    static const int zcap = [] { const char* e = getenv("GCSSL_C5_ZS"); return e ? atoi(e) : 64; }();   // 8/16/32/64: 77.1/80.7/82.1/82.4k img/s
     int zs = N * zcap / 768; if (zs < 1) zs = 1; if (zs > zcap) zs = zcap;
     const int per = (N + zs - 1) / zs;
-    dim3 grid((C + 63) / 64, 16, zs);
+    dim3 grid((C + 63) / 64, zs);
     if (dtype == GCSSL_F32) hipLaunchKernelGGL(c5_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C, per);
     else hipLaunchKernelGGL(c5_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C, per);
     return gcssl_launch_status();
@@ -676,10 +697,14 @@ int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* c
 }
 
 int gcssl_gp_norm(const float* g, long per_sample, int B, float lambda_gp, float* nrm, float* coef, float* gp_sum,
-                  void* stream) {
+                  int dtype, void* scaled, void* stream) {
     if (!g || !nrm || !coef || !gp_sum) return GCSSL_ENULL;
     if (per_sample <= 0 || B <= 0) return GCSSL_EBADSHAPE;
-    hipLaunchKernelGGL(gp_norm_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, g, (size_t)per_sample, B, lambda_gp, nrm, coef, gp_sum);
+    if (scaled && bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (scaled && dtype == GCSSL_BF16)
+        hipLaunchKernelGGL(gp_norm_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, g, (size_t)per_sample, B, lambda_gp, nrm, coef, gp_sum, (bf16_t*)scaled);
+    else
+        hipLaunchKernelGGL(gp_norm_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, g, (size_t)per_sample, B, lambda_gp, nrm, coef, gp_sum, (float*)scaled);
     return gcssl_launch_status();
 }
 

@@ -544,9 +544,8 @@ class StepEngine:
                        self.d_wt[l], self.gb_a[l - 1], cin, cout)
         ops.act_bwd(self.gb_a[0], self.d_a[0][I], self.gb_zs[0], 64, gscale=isig[0, 2:3], group_n=B)
         self._conv("D.c1.gp_dgrad", conv_flops(B, S, 6, 64), ops.conv_dgrad, self.gb_zs[0], self.d_wt[0], self.gb_x0, 8, 64)
-        ops.gp_norm(self.gb_x0, B, self.lambda_gp, self.gp_nrm, self.gp_coef, self.gp_sum)     # :223-231
-        # ---- reverse of the chain (the create_graph=True part of d_loss.backward(), :330)
-        ops.scale_rows(self.gb_x0, self.gp_coef, self.gt_x, B)
+        # :223-231, and the seed of the reverse pass (gb_x0 * coef, the create_graph=True part of d_loss.backward(), :330)
+        ops.gp_norm(self.gb_x0, B, self.lambda_gp, self.gp_nrm, self.gp_coef, self.gp_sum, scaled=self.gt_x)
         src = self.gt_x
         for l, (cin, cout) in enumerate(D_CH):
             cp = _pad8(cin)

@@ -248,8 +248,10 @@ class SnState:
 
 
 # ---- GP, optimiser, heads
-def gp_norm(g, B, lambda_gp, nrm, coef, gp_sum):
-    call("gcssl_gp_norm", g, g.numel() // B, B, float(lambda_gp), nrm, coef, gp_sum)
+def gp_norm(g, B, lambda_gp, nrm, coef, gp_sum, scaled=None):
+    """scaled (optional, compute dtype): receives g * coef[n] in the same launch (== scale_rows afterwards)."""
+    call("gcssl_gp_norm", g, g.numel() // B, B, float(lambda_gp), nrm, coef, gp_sum,
+         code(scaled) if scaled is not None else 0, scaled)
 
 
 def scale_rows(x, coef, y, B):

@@ -142,7 +142,8 @@ int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* c
 
 /* ---- gradient penalty (cgan/losses.py:223-231) -------------------------------------------------------------------
  * nrm[b] = sqrt(sum g_b^2 + 1e-12); gp_sum += mean((nrm-1)^2); coef[b] = lambda_gp*2/B*(nrm-1)/nrm. */
-int gcssl_gp_norm(const float* g, long per_sample, int B, float lambda_gp, float* nrm, float* coef, float* gp_sum, void* stream);
+int gcssl_gp_norm(const float* g, long per_sample, int B, float lambda_gp, float* nrm, float* coef, float* gp_sum,
+                  int dtype, void* scaled, void* stream);   /* scaled (nullable, `dtype`): g * coef[n], the reverse pass's seed */
 int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long per_sample, int B, void* stream);
 
 /* ---- clip_grad_norm_(1.0) + Adam (cgan/cgan_train_enhanced.py:256-257,331-332,368-369) over flat fp32 buffers ---

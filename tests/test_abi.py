@@ -51,7 +51,7 @@ def test_argument_validation_without_gpu(lib_mod):
     assert h.gcssl_sum_replicas(1, None, None, None, 4, 64, 0, None) == -4
     assert h.gcssl_conv4x4s2_wgrad_splits(4, 12, 12, 64, 64) == -1          # non power-of-two spatial size
     assert h.gcssl_conv4x4s2_wgrad_splits(256, 16, 16, 64, 128) > 0
-    assert h.gcssl_gp_norm(None, 10, 2, ctypes.c_float(1.0), None, None, None, None) == -4
+    assert h.gcssl_gp_norm(None, 10, 2, ctypes.c_float(1.0), None, None, None, 0, None, None) == -4
 
 
 def test_code_object_is_gfx950(lib_mod):
