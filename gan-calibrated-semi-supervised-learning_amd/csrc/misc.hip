@@ -155,6 +155,41 @@ __global__ __launch_bounds__(256) void c5_wgrad_kernel(const T* __restrict__ x, 
     }
 }
 
+// fake group (pred, refined) and interpolated group (alpha-mix of the real and fake pairs, cgan/losses.py:203-204) of a
+// critic step in one pass over pred / gt / refined; alpha given per sample or drawn from the counter-based hash
+template <typename T>
+__global__ void pack_fake_interp_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                        const float* __restrict__ refined, const float* __restrict__ alpha, uint64_t seed,
+                                        const double* counter, T* __restrict__ out_fake, T* __restrict__ out_interp, int B, int HW) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * HW) return;
+    const int n = idx / HW, p = idx % HW;
+    float al;
+    if (alpha) al = alpha[n];
+    else {
+        uint64_t x = (uint64_t)n + seed * 0x9E3779B97F4A7C15ull + (counter ? (uint64_t)counter[0] * 0xD1B54A32D192ED03ull : 0ull);
+        x += 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        al = (float)(x >> 40) * (1.0f / 16777216.0f);
+    }
+    const float om = __fsub_rn(1.0f, al);
+    float f[8], v[8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float pv = pred[((size_t)n * 3 + c) * HW + p], gv = gt[((size_t)n * 3 + c) * HW + p];
+        const float rv = refined[((size_t)n * 3 + c) * HW + p];
+        f[c] = pv; f[3 + c] = rv;
+        v[c] = __fadd_rn(__fmul_rn(al, pv), __fmul_rn(om, pv));          // rounded op by op like the eager reference
+        v[3 + c] = __fadd_rn(__fmul_rn(al, gv), __fmul_rn(om, rv));
+    }
+    f[6] = f[7] = v[6] = v[7] = 0.f;
+    T* of = out_fake + idx * 8; T* oi = out_interp + idx * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { Elem<T>::st(of + c, f[c]); Elem<T>::st(oi + c, v[c]); }
+}
+
 // =========================================================================================
 // spectral norm power iteration (legacy torch.nn.utils.spectral_norm as used at cgan/models.py:237-238):
 //   v <- normalize(W^T u), u <- normalize(W v)  (eps 1e-12), sigma = u . (W v).   Up to 4 layers per launch.
@@ -613,6 +648,18 @@ int gcssl_pack_interp(int dtype, const float* pred, const float* gt, const float
     const size_t n = (size_t)B * S * S;
     if (dtype == GCSSL_F32) hipLaunchKernelGGL(pack_pair_kernel<float>, GRID1(n), pred, gt, refined, alpha, (float*)out, B, S * S);
     else hipLaunchKernelGGL(pack_pair_kernel<bf16_t>, GRID1(n), pred, gt, refined, alpha, (bf16_t*)out, B, S * S);
+    return gcssl_launch_status();
+}
+
+int gcssl_pack_fake_interp(int dtype, const float* pred, const float* gt, const float* refined, const float* alpha,
+                           unsigned long long seed, const double* counter, void* out_fake, void* out_interp, int B, int S,
+                           void* stream) {
+    if (!pred || !gt || !refined || !out_fake || !out_interp) return GCSSL_ENULL;
+    if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (B <= 0 || S <= 0) return GCSSL_EBADSHAPE;
+    const size_t n = (size_t)B * S * S;
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(pack_fake_interp_kernel<float>, GRID1(n), pred, gt, refined, alpha, (uint64_t)seed, counter, (float*)out_fake, (float*)out_interp, B, S * S);
+    else hipLaunchKernelGGL(pack_fake_interp_kernel<bf16_t>, GRID1(n), pred, gt, refined, alpha, (uint64_t)seed, counter, (bf16_t*)out_fake, (bf16_t*)out_interp, B, S * S);
     return gcssl_launch_status();
 }
 

@@ -509,11 +509,9 @@ class StepEngine:
         self._set_masks(masks, 10 + k)                             # keyed by (seed, step index, critic step count)
         delta_det = self._g_forward(self.x0[:B], True)
         refined = refine_fn(delta_det, k)                          # :313-315
-        if alpha is None:
-            alpha = self.alpha_buf
-            ops.uniform_gen(alpha, self.seed * 131 + 7 + 16 * k, self.G.state)
-        ops.pack_pair(pred, refined, self.x0[B:2 * B])
-        ops.pack_interp(pred, gt, refined, alpha, self.x0[I])
+        # fake (pred, refined) and interpolated groups in one pass; alpha given (parity runs) or drawn in the kernel
+        ops.pack_fake_interp(pred, gt, refined, alpha, self.x0[B:2 * B], self.x0[I], seed=self.seed * 131 + 7 + 16 * k,
+                             counter=self.G.state)
 
     def _sn_and_prep(self) -> None:
         for slot in range(3):                                     # real, fake, interp forwards each iterate once
@@ -641,7 +639,7 @@ class StepEngine:
         self._g_forward(self.x0[:B], True)                                             # :348
         ops.eiou_fwd_bwd(pred_box, self.g_delta, delta_true, self.lambda_iou, self.g_gdelta, self.g_cal,
                          self.eiou_acc)                                                # :351-355
-        self.delta_pred = self.g_delta.clone()
+        self.delta_pred = self.g_delta                  # (alias: valid until the next generator forward; iteration() clones it)
         self._refined_g = refine_fn(self.delta_pred, self.c)                           # :358-360
         # ---- backward of lambda_iou * EIoU through G (:365-366)
         if not self.G.grads_zero:

@@ -248,6 +248,12 @@ class SnState:
 
 
 # ---- GP, optimiser, heads
+def pack_fake_interp(pred, gt, refined, alpha, out_fake, out_interp, seed=0, counter=None):
+    """alpha None: drawn on the device from (seed, counter[0], sample)."""
+    B, _, S, _ = pred.shape
+    call("gcssl_pack_fake_interp", code(out_fake), pred, gt, refined, alpha, int(seed), counter, out_fake, out_interp, B, S)
+
+
 def gp_norm(g, B, lambda_gp, nrm, coef, gp_sum, scaled=None):
     """scaled (optional, compute dtype): receives g * coef[n] in the same launch (== scale_rows afterwards)."""
     call("gcssl_gp_norm", g, g.numel() // B, B, float(lambda_gp), nrm, coef, gp_sum,

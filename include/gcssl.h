@@ -37,6 +37,11 @@ int gcssl_pack_pair(int dtype, const float* a, const float* b, void* out, int B,
 /* interpolation alpha*real + (1-alpha)*fake of both halves (cgan/losses.py:203-204), alpha: [B]. */
 int gcssl_pack_interp(int dtype, const float* pred, const float* gt, const float* refined, const float* alpha,
                       void* out, int B, int S, void* stream);
+/* both non-real groups of a critic step in one pass: out_fake = (pred, refined), out_interp as gcssl_pack_interp;
+ * alpha NULL: drawn per sample from the counter-based hash keyed by (seed, counter[0], n) like gcssl_uniform_gen. */
+int gcssl_pack_fake_interp(int dtype, const float* pred, const float* gt, const float* refined, const float* alpha,
+                           unsigned long long seed, const double* counter, void* out_fake, void* out_interp, int B, int S,
+                           void* stream);
 /* NHWC8 fp32 input-gradient -> the two NCHW (B,3,S,S) gradients torch.autograd.grad returns (cgan/losses.py:213). */
 int gcssl_unpack_grad(const float* g, float* ga, float* gb, int B, int S, void* stream);
 

@@ -451,3 +451,28 @@ def test_split_k_slab_mode_matches_atomic_mode(ops, kind):
     torch.cuda.synchronize()
     assert rel_err(slabs[0].cpu(), z_atomic.cpu()) < 1e-5                  # the total was written back to slab 0
     assert rel_err(a2.float().cpu(), a1.float().cpu()) < 1e-2 and rel_err(r2.cpu(), r1.cpu()) < 1e-4
+
+
+def test_pack_fake_interp_equals_the_two_separate_packs(ops):
+    B, S = 5, 32
+    pred, gt, ref = rnd(B, 3, S, S, seed=60).cuda(), rnd(B, 3, S, S, seed=61).cuda(), rnd(B, 3, S, S, seed=62).cuda()
+    alpha = torch.rand(B, device="cuda")
+    for dt in (torch.float32, torch.bfloat16):
+        f1 = torch.empty(B, S, S, 8, device="cuda", dtype=dt); i1 = torch.empty_like(f1)
+        f2 = torch.empty_like(f1); i2 = torch.empty_like(f1)
+        ops.pack_pair(pred, ref, f1); ops.pack_interp(pred, gt, ref, alpha, i1)
+        ops.pack_fake_interp(pred, gt, ref, alpha, f2, i2)
+        torch.cuda.synchronize()
+        # (the mix may differ in the last bit between the two kernels: the compiler fuses a*b+c differently)
+        assert torch.equal(f1, f2) and float((i1.float() - i2.float()).abs().max()) <= (1e-6 if dt == torch.float32 else 8e-3)
+    # device-drawn alpha: a convex combination per sample with the same alpha for all pixels, re-keyed by the counter
+    ctr = torch.tensor([2.0], device="cuda", dtype=torch.float64)
+    f3 = torch.empty(B, S, S, 8, device="cuda"); i3 = torch.empty_like(f3); i4 = torch.empty_like(f3)
+    ops.pack_fake_interp(pred, gt, ref, None, f3, i3, seed=11, counter=ctr)
+    ops.pack_fake_interp(pred, gt, ref, None, f3, i4, seed=11, counter=ctr)
+    torch.cuda.synchronize()
+    assert torch.equal(i3, i4)
+    g, r, m = gt.permute(0, 2, 3, 1), ref.permute(0, 2, 3, 1), i3[..., 3:6]
+    al = ((m - r) / (g - r)).reshape(B, -1)
+    assert float(al.min()) >= -1e-3 and float(al.max()) <= 1 + 1e-3
+    assert float((al - al.median(1, keepdim=True).values).abs().median()) < 1e-3
