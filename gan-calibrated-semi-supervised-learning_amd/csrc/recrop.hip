@@ -62,14 +62,17 @@ __device__ __forceinline__ Crop make_crop(const RecropParams& p, int n) {
     const int ii = p.img_idx[n];
     c.W = p.img_w[ii]; c.H = p.img_h[ii]; c.img = p.atlas + p.img_off[ii];
     // mode 0: the training loop's re-crop (clamped box, validity test, fallback to the predicted box);
-    // mode 1: the dataset's _letterbox (cgan/dataset.py:104-124): the box as given, no test, no fallback
+    // mode 1: the dataset's _letterbox (cgan/dataset.py:104-124): the box as given, no test, no fallback;
+    // mode 2: inference.py's crop_patch + letterbox (cgan/inference.py:51-68): as mode 1, but Image.crop gets FLOAT
+    //         coordinates there and rounds them to nearest-even instead of truncating
     Rect r = pixel_rect(p.refined + 4 * n, c.W, c.H, p.mode == 0);
     c.status = 0;
     if (p.mode == 0 && (r.x2 <= r.x1 || r.y2 <= r.y1 || (r.x2 - r.x1) < 10.0 || (r.y2 - r.y1) < 10.0)) {       // :95
         r = pixel_rect(p.pred + 4 * n, c.W, c.H, false);
         c.status = 1;
     }
-    c.l = (int)r.x1; c.t = (int)r.y1; c.cw = (int)r.x2 - c.l; c.ch = (int)r.y2 - c.t;
+    if (p.mode == 2) { c.l = (int)rint(r.x1); c.t = (int)rint(r.y1); c.cw = (int)rint(r.x2) - c.l; c.ch = (int)rint(r.y2) - c.t; }
+    else { c.l = (int)r.x1; c.t = (int)r.y1; c.cw = (int)r.x2 - c.l; c.ch = (int)r.y2 - c.t; }
     if (c.cw < 0 || c.ch < 0) c.status = 2;                 // Image.crop raises -> the reference's except branch
     c.q = max(c.cw, c.ch);
     if (c.q > p.max_side) c.status = 2;                     // larger than the caller's bound: LDS and tables were sized for it
@@ -266,7 +269,7 @@ int gcssl_recrop_patches(const uint8_t* atlas, long atlas_bytes, const long* img
                          const int* img_idx, const float* refined_box, const float* pred_box, const float* fallback,
                          float* out, int* status, int* ws, int B, int S, int max_side, int mode, void* stream) {
     if (!atlas || !img_off || !img_w || !img_h || !img_idx || !refined_box || (mode == 0 && !pred_box) || !out || !ws) return GCSSL_ENULL;
-    if (B <= 0 || S < 2 || S > 256 || max_side < 1 || atlas_bytes <= 0 || atlas_bytes >= 0x7FFFFFFFL || (mode != 0 && mode != 1))
+    if (B <= 0 || S < 2 || S > 256 || max_side < 1 || atlas_bytes <= 0 || atlas_bytes >= 0x7FFFFFFFL || mode < 0 || mode > 2)
         return GCSSL_EBADSHAPE;
     // worst case over the launch: a crop side of max_side pixels
     const double fs = (double)max_side / S > 1.0 ? (double)max_side / S : 1.0;

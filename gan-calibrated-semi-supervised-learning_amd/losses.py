@@ -75,6 +75,19 @@ def apply_delta_to_bbox(bbox, delta, training: bool = True):
     return torch.stack([cx, cy, w, h], dim=-1)
 
 
+def apply_delta_to_bbox_inference(bbox, delta):
+    """The box transform of the reference's inference script, cgan/inference.py:69-89.  It is NOT apply_delta_to_bbox(
+    training=False) although its docstring says so: the deltas are clamped to [-2, 2] (not 1.5), exp() is
+    not clamped to [-1, 1], and w, h end in [0.01, 0.9] (not [0.02, 0.8]).  Kept as it is so that infer.py reproduces the
+    reference's output files; validation during training (cgan/cgan_train_enhanced.py:395-420) uses the other one."""
+    d = torch.clamp(delta, -2.0, 2.0)
+    cx = torch.clamp(bbox[:, 0] + d[:, 0] * bbox[:, 2], 0.05, 0.95)
+    cy = torch.clamp(bbox[:, 1] + d[:, 1] * bbox[:, 3], 0.05, 0.95)
+    w = torch.clamp(bbox[:, 2] * torch.exp(d[:, 2]), 0.01, 0.9)
+    h = torch.clamp(bbox[:, 3] * torch.exp(d[:, 3]), 0.01, 0.9)
+    return torch.stack([cx, cy, w, h], dim=-1)
+
+
 def iou_metric(pred_boxes, target_boxes, eps: float = 1e-6):
     """cgan/losses.py:152-183."""
     px1, py1 = pred_boxes[:, 0] - pred_boxes[:, 2] / 2, pred_boxes[:, 1] - pred_boxes[:, 3] / 2

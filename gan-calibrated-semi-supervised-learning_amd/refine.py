@@ -62,9 +62,10 @@ def apply_delta_eval(pred_bboxes: torch.Tensor, deltas: torch.Tensor) -> torch.T
 
 def recrop(atlas: ImageAtlas, img_idx: torch.Tensor, refined_boxes: torch.Tensor, pred_bboxes: torch.Tensor,
            img_size: int, fallback_patches: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None, max_side: Optional[int] = None, letterbox: bool = False) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, max_side: Optional[int] = None, letterbox=False) -> torch.Tensor:
     """letterbox=True: CalibratorDataset._letterbox semantics (cgan/dataset.py:104-124) -- refined_boxes are cropped as
-    given (no clamp, validity test or fallback) -- i.e. the dataset's pred/gt patches."""
+    given (no clamp, validity test or fallback) -- i.e. the dataset's pred/gt patches.  letterbox="round": the same with
+    the crop edges rounded to nearest, which is what cgan/inference.py:59-68 does (Image.crop on float coordinates)."""
     B = refined_boxes.shape[0]
     if out is None:
         out = torch.empty(B, 3, img_size, img_size, device=refined_boxes.device, dtype=torch.float32)
@@ -73,7 +74,7 @@ def recrop(atlas: ImageAtlas, img_idx: torch.Tensor, refined_boxes: torch.Tensor
     ms = int(max_side if max_side is not None else atlas.max_side)
     call("gcssl_recrop_patches", atlas.data, atlas.data.numel(), atlas.off, atlas.w, atlas.h, img_idx,
          refined_boxes.contiguous(), pred_bboxes.contiguous() if pred_bboxes is not None else None, fallback_patches, out,
-         status, atlas.workspace(B, img_size, ms), B, img_size, ms, 1 if letterbox else 0)
+         status, atlas.workspace(B, img_size, ms), B, img_size, ms, 2 if letterbox == "round" else (1 if letterbox else 0))
     return out
 
 

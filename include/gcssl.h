@@ -180,7 +180,9 @@ int gcssl_eiou_fwd_bwd(const float* pred_box, const float* delta, const float* d
  * in pixels (sizes the LDS and the coefficient workspace; the largest image side covers every box).  atlas_bytes: size
  * of the atlas (< 2^31).  ws: gcssl_recrop_ws_ints(B, S, max_side) ints of scratch (per-sample coefficient tables).
  * mode 1 = the dataset's CalibratorDataset._letterbox (cgan/dataset.py:104-124): crop refined_box as given (no clamp, no
- * validity test, no fallback; pred_box unused), pad, resize, normalise -- the pred/gt training patches themselves. */
+ * validity test, no fallback; pred_box unused), pad, resize, normalise -- the pred/gt training patches themselves.
+ * mode 2 = inference.py's crop_patch + letterbox (cgan/inference.py:51-68): as mode 1 with the crop edges rounded to
+ * nearest (Image.crop on float coordinates) instead of truncated. */
 int gcssl_recrop_ws_ints(int B, int S, int max_side);
 int gcssl_recrop_patches(const uint8_t* atlas, long atlas_bytes, const long* img_off, const int* img_w, const int* img_h,
                          const int* img_idx, const float* refined_box, const float* pred_box, const float* fallback,

@@ -81,6 +81,23 @@ def reference_letterbox(img_np, box, size):
     return ((t - 0.5) / 0.5).numpy()
 
 
+def reference_inference_patch(img_np, box, size):
+    """crop_patch + letterbox + transform of cgan/inference.py:51-68,147-166 for one box, with Pillow."""
+    img = Image.fromarray(img_np, "RGB")
+    W, H = img.size
+    cx, cy, w, h = (float(v) for v in box)
+    px, py, pw, ph = cx * W, cy * H, w * W, h * H
+    x1, y1 = max(0, px - pw / 2), max(0, py - ph / 2)
+    x2, y2 = min(W, px + pw / 2), min(H, py + ph / 2)
+    crop = img.crop((x1, y1, x2, y2))                       # float box: Pillow rounds
+    pad_w = max(crop.height - crop.width, 0)
+    pad_h = max(crop.width - crop.height, 0)
+    sq = ImageOps.expand(crop, (pad_w // 2, pad_h // 2, pad_w - pad_w // 2, pad_h - pad_h // 2), fill=(128, 128, 128))
+    res = sq.resize((size, size), Image.BICUBIC)
+    t = torch.from_numpy(np.asarray(res, np.uint8).copy()).permute(2, 0, 1).float().div(255)
+    return ((t - 0.5) / 0.5).numpy()
+
+
 def main():
     imgs = make_images()
     rng = np.random.default_rng(99)
@@ -106,6 +123,8 @@ def main():
         res = [reference_patch(imgs[idx[i]], torch.from_numpy(refined[i]), torch.from_numpy(pred[i]), size) for i in range(n)]
         out[f"patch{size}"] = np.stack([r[0] for r in res]).astype(np.float32)
         out[f"status{size}"] = np.array([r[1] for r in res], np.int32)
+        if size == 32:
+            out["infer32"] = np.stack([reference_inference_patch(imgs[idx[i]], refined[i], size) for i in range(n)]).astype(np.float32)
         out[f"letterbox{size}"] = np.stack([reference_letterbox(imgs[idx[i]], torch.from_numpy(refined[i]), size)
                                             for i in range(n)]).astype(np.float32)
     np.savez_compressed(ROOT / "tests" / "golden" / "recrop.npz", **out)

@@ -149,3 +149,58 @@ def test_train_harness_on_a_dataset_directory(tmp_path):
     ck = torch.load(save / "G_best.pth", weights_only=False) if (save / "G_best.pth").exists() else None
     if ck is not None:
         assert set(ck) == {"generator", "discriminator", "epoch", "delta_iou", "config"}
+
+
+def test_inference_box_transform_known_answers():
+    """cgan/inference.py:69-89 (which differs from apply_delta_to_bbox(training=False): clamp 2, free exp, w/h in [.01,.9])."""
+    L = importlib.import_module(PKG + ".losses")
+    bbox = torch.tensor([[0.5, 0.5, 0.2, 0.4], [0.9, 0.1, 0.5, 0.5], [0.5, 0.5, 0.5, 0.001]])
+    delta = torch.tensor([[0.1, -0.2, 0.3, -0.3], [3.0, -3.0, 2.5, -9.0], [0.0, 0.0, 1.9, 0.0]])
+    got = L.apply_delta_to_bbox_inference(bbox, delta)
+    want = torch.tensor([[0.52, 0.42, 0.2 * math.exp(0.3), 0.4 * math.exp(-0.3)],
+                         [0.95, 0.05, 0.9, 0.5 * math.exp(-2.0)],
+                         [0.5, 0.5, 0.9, 0.01]])
+    assert torch.allclose(got, want, atol=1e-6)
+    ev = L.apply_delta_to_bbox(bbox, delta, training=False)
+    assert not torch.allclose(got, ev)                          # the reference's two transforms are not the same function
+
+
+def test_inference_patch_oracle_matches_pillow_fixture():
+    fx = np.load(ROOT / "tests" / "golden" / "recrop.npz")
+    imgs = [fx[f"img{i}"] for i in range(int(fx["n_images"]))]
+    for i in range(len(fx["img_idx"])):
+        got = R.letterbox_patch(imgs[fx["img_idx"][i]], fx["refined"][i], 32, rounded=True)
+        assert np.array_equal(got, fx["infer32"][i]), i
+
+
+@pytest.mark.gpu
+def test_infer_script_end_to_end(tmp_path):
+    """infer.py: checkpoint with the reference's keys -> one image + YOLO txt -> calibrated txt; the patches it feeds G are
+    the Pillow ones bit for bit, the rows keep class and confidence."""
+    pytest.importorskip("PIL.Image")
+    from PIL import Image
+    sys.path.insert(0, str(ROOT))
+    import infer
+    RF = importlib.import_module(PKG + ".refine")
+    models = importlib.import_module(PKG + ".models")
+    fx = np.load(ROOT / "tests" / "golden" / "recrop.npz")
+    imgs = [fx[f"img{i}"] for i in range(int(fx["n_images"]))]
+    atlas = RF.ImageAtlas(imgs, "cuda")
+    out = RF.recrop(atlas, torch.from_numpy(fx["img_idx"]).cuda(), torch.from_numpy(fx["refined"]).cuda(), None, 32,
+                    letterbox="round").cpu().numpy()
+    assert all(np.array_equal(out[i], fx["infer32"][i]) for i in range(len(out)))
+    # the script
+    rng = np.random.default_rng(1)
+    Image.fromarray(rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)).save(tmp_path / "demo.png")
+    (tmp_path / "pred.txt").write_text("0 0.30 0.35 0.30 0.30 0.91\n\n2 0.70 0.60 0.25 0.40 0.55\n1 0.5 0.5 0.2 0.2\n")
+    G = models.GeneratorUNet(delta_scale=0.3)
+    G.apply(models.weights_init_normal)
+    torch.save({"generator": G.state_dict(), "discriminator": {}, "epoch": 3, "delta_iou": 0.0,
+                "config": {"delta_scale": 0.3, "generator_type": "unet"}}, tmp_path / "G_best.pth")
+    infer.main(["--weights", str(tmp_path / "G_best.pth"), "--image", str(tmp_path / "demo.png"),
+                "--pred_txt", str(tmp_path / "pred.txt"), "--out_txt", str(tmp_path / "out.txt"), "--img_size", "32"])
+    rows = [l.split() for l in (tmp_path / "out.txt").read_text().splitlines()]
+    assert [r[0] for r in rows] == ["0", "2", "1"] and rows[0][5] == "0.91" and len(rows[2]) == 5
+    vals = np.array([[float(v) for v in r[1:5]] for r in rows])
+    assert np.all(vals[:, :2] >= 0.05) and np.all(vals[:, :2] <= 0.95) and np.all(vals[:, 2:] >= 0.01) and np.all(vals[:, 2:] <= 0.9)
+    assert np.abs(vals - np.array([[0.30, 0.35, 0.30, 0.30], [0.70, 0.60, 0.25, 0.40], [0.5, 0.5, 0.2, 0.2]])).max() < 0.2
