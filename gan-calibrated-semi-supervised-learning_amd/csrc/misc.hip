@@ -832,6 +832,16 @@ int gcssl_sum_replicas(int nseg, const float* const* src, float* const* dst, con
     return gcssl_launch_status();
 }
 
+extern "C" int gcssl_init_norm();
+extern "C" int gcssl_init_recrop();
+/* One-time device-side set-up (dynamic-LDS opt-ins).  Call once per process with a GPU present and BEFORE capturing any
+ * of the entry points into a hipGraph; the entry points also do it lazily on first use. */
+int gcssl_init() {
+    int rc = gcssl_init_norm();
+    if (rc) return rc;
+    return gcssl_init_recrop();
+}
+
 int gcssl_uniform_gen(float* out, long n, unsigned long long seed, const double* counter, void* stream) {
     if (!out) return GCSSL_ENULL;
     if (n <= 0) return GCSSL_EBADSHAPE;

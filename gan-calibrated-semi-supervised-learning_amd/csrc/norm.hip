@@ -771,6 +771,14 @@ int small_spb(int N, int C, int rg, int group_n) {
 
 extern "C" {
 
+// the LDS-resident forward needs the 128-KB dynamic-LDS opt-in; done once, outside any stream capture (gcssl_init)
+int gcssl_init_norm() {
+    const int bytes = (int)(LDS_HW_MAX * LDS_CH * sizeof(float));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return e == hipSuccess ? GCSSL_OK : (int)e;
+}
+
 int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean, float* rstd,
                      const uint8_t* mask, float* pool, int nslab, long slab_stride, int N, int HW, int C, int act, void* stream) {
     if (!z || !a || !mean || !rstd) return GCSSL_ENULL;

@@ -258,6 +258,11 @@ __global__ void apply_delta_eval_kernel(const float* __restrict__ box, const flo
 
 extern "C" {
 
+int gcssl_init_recrop() {         // dynamic-LDS opt-in up to the 160 KB of a CU, once, outside any stream capture
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(recrop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e == hipSuccess ? GCSSL_OK : (int)e;
+}
+
 int gcssl_recrop_ws_ints(int B, int S, int max_side) {
     if (B <= 0 || S < 2 || S > 256 || max_side < 1) return GCSSL_EBADSHAPE;
     const double fs = (double)max_side / S > 1.0 ? (double)max_side / S : 1.0;

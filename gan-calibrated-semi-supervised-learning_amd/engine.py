@@ -111,6 +111,7 @@ class StepEngine:
         self.allreduce = allreduce
         self.keep_clipped_grads = keep_clipped_grads     # write g*clip_coef back like clip_grad_norm_ does (not needed to step)
         _lib.lib()                                                  # fail loudly now if the HIP library is missing
+        _lib.call_nostream("gcssl_init")                            # dynamic-LDS opt-ins, before any graph capture
         dev = self.dev
         f32 = dict(device=dev, dtype=torch.float32)
         self.D = FlatParams({k: sd_d[k].to(dev, torch.float32) for k in D_PARAM_KEYS}, D_PARAM_KEYS, dev)

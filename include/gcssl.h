@@ -29,6 +29,12 @@ extern "C" {
 #define GCSSL_BF16 1
 
 const char* gcssl_version(void);
+/* One-time device-side set-up (dynamic-LDS opt-ins of the kernels that use > 64 KB).  Call once per process with a GPU
+ * present and before capturing entry points into a hipGraph (they also do it lazily on first use, which a capture in
+ * progress may refuse). */
+int gcssl_init(void);
+int gcssl_init_norm(void);
+int gcssl_init_recrop(void);
 
 /* ---- boundary packing ------------------------------------------------------------------------------------
  * torch.cat([pred_patch, other_patch], 1) (cgan/models.py:257): two NCHW fp32 (B,3,S,S) tensors -> NHWC
