@@ -757,11 +757,19 @@ class GraphedIteration:
             return g
 
         if self.fused_update:
+            # single GPU: the whole iteration (critic steps, generator step, all three updates) is ONE graph
+            # (GCSSL_ONE_GRAPH=0: one graph per step, for A/B runs)
+            import os
+            steps = []
             for k in range(eng.c):
-                eng._d_dirty, eng._g_dirty = True, (k == 0)   # weights change between replays: keep the prep kernels
-                self.d_graphs.append(capture(lambda k=k: (eng.d_compute(pred, gt, refine_fn, k, None, None), eng.d_update())))
-            eng._d_dirty, eng._g_dirty = True, False
-            self.g_graph = capture(lambda: (eng.g_compute(pred, delta_true, pred_box, refine_fn, None), eng.g_update()))
+                steps.append(lambda k=k: (setattr(eng, "_d_dirty", True), setattr(eng, "_g_dirty", k == 0),
+                                          eng.d_compute(pred, gt, refine_fn, k, None, None), eng.d_update()))
+            steps.append(lambda: (setattr(eng, "_d_dirty", True), setattr(eng, "_g_dirty", False),
+                                  eng.g_compute(pred, delta_true, pred_box, refine_fn, None), eng.g_update()))
+            if os.environ.get("GCSSL_ONE_GRAPH", "1") != "0":
+                self.graphs = [capture(lambda: [f() for f in steps])]
+            else:
+                self.graphs = [capture(f) for f in steps]
             return
         # data parallel: every all-reduce runs beside launches that do not need its result --
         #   critic step k's gradient  ||  d_pre of step k+1 (G's no-grad forward, re-crop, packing) or, after the last
@@ -781,9 +789,8 @@ class GraphedIteration:
     def replay(self):
         eng = self.eng
         if self.fused_update:
-            for g in self.d_graphs:
+            for g in self.graphs:
                 g.replay()
-            self.g_graph.replay()
             return
         self.pre[0].replay()
         for k in range(eng.c):
