@@ -343,7 +343,9 @@ __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __re
 // (torch.nn.utils.clip_grad_norm_ + torch.optim.Adam at cgan/cgan_train_enhanced.py:256-257,331-332,368-369)
 // =========================================================================================
 // state (8 doubles): [0] step count, [1] sum of squares accumulator (zero between calls), [2] last total norm,
-// [3] clip coefficient, [4] lr / (1 - b1^t), [5] sqrt(1 - b2^t), [6] blocks-finished counter (as u64), [7] spare.
+// [3] clip coefficient, [4] lr / (1 - b1^t), [5] sqrt(1 - b2^t), [6] blocks-finished counter (as u64),
+// [7] learning-rate override (> 0: used instead of the launch argument -- an LR scheduler writes it between iterations
+//     without re-capturing the graph).
 // Few blocks (same-address fp64 atomics serialise at ~12 ns each); the last block to finish advances the step and
 // derives the scalars of this update, following torch's single-tensor Adam (python doubles, cast to float where
 // they meet the tensor).
@@ -381,7 +383,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
             state[0] = t;
             state[2] = sqrt(ss);
             state[3] = (double)fminf(1.0f, (float)max_norm / (total + 1e-6f));
-            state[4] = (double)(float)(lr / (1.0 - pow(b1, t)));
+            const double lr_eff = state[7] > 0.0 ? state[7] : lr;       // per-epoch scheduler override (graph-replay safe)
+            state[4] = (double)(float)(lr_eff / (1.0 - pow(b1, t)));
             state[5] = (double)(float)sqrt(1.0 - pow(b2, t));
             state[1] = 0.0;
             *cnt = 0ull;

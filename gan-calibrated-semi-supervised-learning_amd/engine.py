@@ -722,6 +722,14 @@ class StepEngine:
                    calibrated=self.g_cal.clone(), fake_for_g=self.d_out[:self.B].clone())
         return log
 
+    def set_lr(self, lr_g: Optional[float] = None, lr_d: Optional[float] = None) -> None:
+        """Learning rates for the following updates (an LR scheduler's step): written into the optimisers' device-side
+        state blocks, so captured graphs pick them up without re-capture."""
+        if lr_g is not None:
+            self.G.state[7] = float(lr_g)
+        if lr_d is not None:
+            self.D.state[7] = float(lr_d)
+
     # ------------------------------------------------------------------------------------------ state access
     def state_dicts(self):
         """(generator_state_dict, discriminator_state_dict) keyed like the reference."""

@@ -337,6 +337,16 @@ def test_clip_adam_matches_torch(ops):
     assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2)
     assert torch.equal(ga.cpu(), g) and float(gb.abs().max()) == 0.0
     assert float(state[1]) == 0.0 and float(state[6]) == 0.0      # accumulator and counter are reset for the next call
+    # state[7] > 0 overrides the launch argument's learning rate (LR scheduler without re-capturing a graph)
+    pa, pb = p.clone(), p.clone()
+    ma, va, sa = m.clone(), v.clone(), state.clone()
+    mb, vb, sb = m.clone(), v.clone(), state.clone()
+    sb[7] = 1e-4
+    g2 = rnd(n, seed=91, scale=0.05).cuda()
+    ops.clip_adam(pa, g2.clone(), ma, va, sa, 1e-4, 0.5, 0.999)
+    ops.clip_adam(pb, g2.clone(), mb, vb, sb, 2e-4, 0.5, 0.999)
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb)
 
 
 def test_generator_head_and_eiou(ops):

@@ -127,6 +127,10 @@ def main(argv=None):
             print(f"dataset: {len(ds)} (pred, gt) pairs, {len(train_idx)} for training on this rank, {ds.atlas(device).n} images")
         if len(train_idx) < args.batch_size // world:
             raise SystemExit("fewer training pairs than one batch")
+    # ReduceLROnPlateau(mode='max', factor=0.5, patience=5) on delta_iou for both optimisers (:260-261,427-428): torch's own
+    # scheduler logic on placeholder optimisers; the resulting rates go to the engine's device-side optimiser state
+    sched = [torch.optim.lr_scheduler.ReduceLROnPlateau(torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=args.lr),
+                                                        mode="max", factor=0.5, patience=5) for _ in range(2)]
     out_root = Path(args.save_dir); out_root.mkdir(parents=True, exist_ok=True)
     ckpt_best = out_root / "G_best.pth"
     best, history = -1.0, []
@@ -165,6 +169,9 @@ def main(argv=None):
                 cal = losses.apply_delta_to_bbox(pbv, dv, training=False)
                 sb += float(losses.iou_metric(pbv, gtb).sum()); sa += float(losses.iou_metric(cal, gtb).sum()); nv += Bv
             delta_iou = sa / nv - sb / nv
+        for sc in sched:
+            sc.step(delta_iou)
+        eng.set_lr(lr_g=sched[0].optimizer.param_groups[0]["lr"], lr_d=sched[1].optimizer.param_groups[0]["lr"])
         history.append(dict(epoch=epoch, delta_iou=delta_iou, **stats))
         if rank == 0:
             print(f"[Epoch {epoch}/{args.n_epochs}] G: {stats['loss_G']:.3f} D: {stats['loss_D']:.3f} EIoU: {stats['loss_iou']:.3f} "
