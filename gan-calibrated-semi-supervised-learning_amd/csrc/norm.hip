@@ -193,22 +193,23 @@ __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(float* __restri
 // ---- forward, maps of 257..1024 pixels: one workgroup owns (sample, 32 channels) and keeps its slab of z in LDS
 // (<= 128 KB), so z is read from HBM ONCE, the statistics are the exact two-pass ones, and mean/rstd/pool have a single
 // writer (no atomics, no fills, no finalize launch).  Replaces stats + finalize + apply (+2 fills) for G.up4 at 32x32.
-constexpr int LDS_CH = 32, LDS_HW_MAX = 1024;
-template <typename T>
+constexpr int LDS_HW_MAX = 1024;
+template <typename T, int LDS_CH>
 __global__ __launch_bounds__(256) void in_fwd_lds_kernel(const float* __restrict__ z, int ldz, T* __restrict__ a, int lda,
                                                          float* __restrict__ mean, float* __restrict__ rstd,
                                                          const uint8_t* __restrict__ mask, float* __restrict__ pool,
                                                          int HW, int C, int act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* slab = reinterpret_cast<float*>(lds_raw);                    // [HW][32]
-    __shared__ float part[32][LDS_CH + 1];
+    constexpr int LPR = LDS_CH / VC, RGS = 256 / LPR;                    // lanes per pixel row, row groups
+    __shared__ float part[RGS][LDS_CH + 1];
     __shared__ float stat[2][LDS_CH];
-    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;              // 8 lanes x 4 channels, 32 row groups
+    const int tx = threadIdx.x % LPR, ty = threadIdx.x / LPR;            // LPR lanes x 4 channels, RGS row groups
     const int c = blockIdx.x * LDS_CH + tx * VC, n = blockIdx.y;
     const float* zp = z + (size_t)n * HW * ldz + c;
     float s[VC] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int p = ty; p < HW; p += 32) {
+    for (int p = ty; p < HW; p += RGS) {
         float v[VC]; ld4(zp + (size_t)p * ldz, v);
         *reinterpret_cast<float4*>(slab + p * LDS_CH + tx * VC) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void in_fwd_lds_kernel(const float* __restrict
         if (threadIdx.x < LDS_CH) {
             float t = 0.f;
 #pragma unroll
-            for (int g = 0; g < 32; ++g) t += part[g][threadIdx.x];
+            for (int g = 0; g < RGS; ++g) t += part[g][threadIdx.x];
             stat[which][threadIdx.x] = t;
         }
         __syncthreads();
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void in_fwd_lds_kernel(const float* __restrict
     float mu[VC], r[VC];
 #pragma unroll
     for (int j = 0; j < VC; ++j) { mu[j] = stat[0][tx * VC + j] / HW; s[j] = 0.f; }
-    for (int p = ty; p < HW; p += 32) {
+    for (int p = ty; p < HW; p += RGS) {
         const float4 v = *reinterpret_cast<const float4*>(slab + p * LDS_CH + tx * VC);
         const float d0 = v.x - mu[0], d1 = v.y - mu[1], d2 = v.z - mu[2], d3 = v.w - mu[3];
         s[0] += d0 * d0; s[1] += d1 * d1; s[2] += d2 * d2; s[3] += d3 * d3;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void in_fwd_lds_kernel(const float* __restrict
     for (int j = 0; j < VC; ++j) { r[j] = 1.0f / sqrtf(stat[1][tx * VC + j] / HW + IN_EPS); s[j] = 0.f; }
     if (ty == 0) { st4<float>(mean + (size_t)n * C + c, mu); st4<float>(rstd + (size_t)n * C + c, r); }
     T* ap = a + (size_t)n * HW * lda + c;
-    for (int p = ty; p < HW; p += 32) {
+    for (int p = ty; p < HW; p += RGS) {
         const float4 v4 = *reinterpret_cast<const float4*>(slab + p * LDS_CH + tx * VC);
         const float v[VC] = {v4.x, v4.y, v4.z, v4.w};
         float o[VC], k[VC] = {1.f, 1.f, 1.f, 1.f};
@@ -773,9 +774,11 @@ extern "C" {
 
 // the LDS-resident forward needs the 128-KB dynamic-LDS opt-in; done once, outside any stream capture (gcssl_init)
 int gcssl_init_norm() {
-    const int bytes = (int)(LDS_HW_MAX * LDS_CH * sizeof(float));
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    const int bytes = (int)(LDS_HW_MAX * 32 * sizeof(float));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<bf16_t, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<float, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<bf16_t, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes / 2);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<float, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes / 2);
     return e == hipSuccess ? GCSSL_OK : (int)e;
 }
 
@@ -801,18 +804,16 @@ int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean
 #undef FWD_SMALL
         return gcssl_launch_status();
     }
-    if (HW <= LDS_HW_MAX && C % LDS_CH == 0 && nslab == 1) {
-        const size_t lds = (size_t)HW * LDS_CH * sizeof(float);
-        static size_t lds_set = 0;
-        if (lds > lds_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_HW_MAX * LDS_CH * sizeof(float)));
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_HW_MAX * LDS_CH * sizeof(float)));
-            if (e != hipSuccess) return (int)e;
-            lds_set = LDS_HW_MAX * LDS_CH * sizeof(float);
-        }
-        dim3 g2(C / LDS_CH, N);
-        if (dtype == GCSSL_F32) hipLaunchKernelGGL(in_fwd_lds_kernel<float>, g2, dim3(256), lds, st, z, ldz, (float*)a, lda, mean, rstd, mask, pool, HW, C, act);
-        else hipLaunchKernelGGL(in_fwd_lds_kernel<bf16_t>, g2, dim3(256), lds, st, z, ldz, (bf16_t*)a, lda, mean, rstd, mask, pool, HW, C, act);
+    static const int lds_ch = [] { const char* e = getenv("GCSSL_IN_LDS_CH"); return (e && atoi(e) == 16) ? 16 : 32; }();
+    if (HW <= LDS_HW_MAX && C % lds_ch == 0 && nslab == 1) {
+        const size_t lds = (size_t)HW * lds_ch * sizeof(float);
+        static bool inited = false;
+        if (!inited) { int rc = gcssl_init_norm(); if (rc) return rc; inited = true; }
+        dim3 g2(C / lds_ch, N);
+#define LDS_FWD(T, CHN) hipLaunchKernelGGL((in_fwd_lds_kernel<T, CHN>), g2, dim3(256), lds, st, z, ldz, (T*)a, lda, mean, rstd, mask, pool, HW, C, act)
+        if (dtype == GCSSL_F32) { if (lds_ch == 16) LDS_FWD(float, 16); else LDS_FWD(float, 32); }
+        else { if (lds_ch == 16) LDS_FWD(bf16_t, 16); else LDS_FWD(bf16_t, 32); }
+#undef LDS_FWD
         return gcssl_launch_status();
     }
     dim3 grid(C / CW, N, (HW + SMALL_HW - 1) / SMALL_HW);
