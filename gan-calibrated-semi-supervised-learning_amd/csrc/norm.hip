@@ -341,6 +341,7 @@ struct InBwdParams {
     float* dbias;                      // [C] += sum dz (atomic), nullable
     float* cdot;                       // [ngroups] += sum dzs (z - bias) = <G_k, W_orig>/sigma_k^2 (atomic), nullable
     int nrep, rep_stride;              // dbias/cdot are nrep replicas rep_stride floats apart; a workgroup adds to one
+    int da_nslab; long da_slab_stride; // da is the first of da_nslab split-K partial-sum slabs of the producing conv (floats apart)
     int HW, C, act;
 };
 
@@ -381,6 +382,14 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
             float d[VC] = {dab[0], dab[1], dab[2], dab[3]};
             if (dap) {
                 float t[VC]; ld4(dap + (size_t)p * q.ldda, t);
+                if (q.da_nslab > 1) {                                  // split-K slabs of the producing conv: add them and
+                    for (int k = 1; k < q.da_nslab; ++k) {             // leave the total in slab 0 for later readers of da
+                        float u[VC]; ld4(dap + (size_t)k * q.da_slab_stride + (size_t)p * q.ldda, u);
+#pragma unroll
+                        for (int j = 0; j < VC; ++j) t[j] += u[j];
+                    }
+                    st4<float>(const_cast<float*>(dap) + (size_t)p * q.ldda, t);
+                }
 #pragma unroll
                 for (int j = 0; j < VC; ++j) d[j] += t[j];
             }
@@ -545,6 +554,7 @@ struct InDblParams {
     float* zt;                         // out: adjoint wrt z, dense fp32 [N][HW][C]
     float* cdot;                       // scalar += sum gb_zs * q (atomic), nullable
     int HW, C, act;
+    int q_nslab; long q_slab_stride;   // qz is the first of q_nslab split-K slabs of the producing conv
 };
 
 // adjoint of dz = in_bwd(xhat(z), rstd(z), dn) for incoming adjoint q (see oracle/manual_step.py:in_bwd_bwd)
@@ -622,6 +632,11 @@ __global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, 
             if (!live || p >= HW) continue;
             float zv[VC], g[VC];
             ld4(zp + (size_t)p * q.ldz, zv); ld4(gp + (size_t)p * q.ldgb, g); ld4(qp + (size_t)p * q.ldq, qq[i]);
+            for (int k = 1; k < q.q_nslab; ++k) {
+                float t[VC]; ld4(qp + (size_t)k * q.q_slab_stride + (size_t)p * q.ldq, t);
+#pragma unroll
+                for (int j = 0; j < VC; ++j) qq[i][j] += t[j];
+            }
             float gz[VC] = {0.f, 0.f, 0.f, 0.f};
             if (gzp) ldT4<T>(gzp + (size_t)p * q.ldgz, gz);
 #pragma unroll
@@ -833,17 +848,18 @@ int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean
 int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const float* da_bcast,
                      const float* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask,
                      const float* zt, int zt_n0, const float* gscale, int group_n, const float* bias,
-                     void* dzs, int lddz, float* dbias, float* cdot, int nrep, int rep_stride, float* ws, int N, int HW, int C,
-                     int act, void* stream) {
+                     void* dzs, int lddz, float* dbias, float* cdot, int nrep, int rep_stride, int da_nslab, long da_slab_stride,
+                     float* ws, int N, int HW, int C, int act, void* stream) {
     if ((!da && !da_bcast) || !z || !mean || !rstd || !dzs) return GCSSL_ENULL;
     if (nrep < 1 || (nrep > 1 && rep_stride < C)) return GCSSL_EBADSHAPE;
+    if (da_nslab < 1 || (da_nslab > 1 && (!da || da_slab_stride <= 0 || da_slab_stride % 4 || HW > MID_HW))) return GCSSL_EBADSHAPE;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lddz < C || ldz % 4 || lddz % 4 || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
     if ((da && ldda % 4) || (da2 && ldda2 % 4)) return GCSSL_EBADSHAPE;
     if ((gscale || cdot) && group_n <= 0) return GCSSL_EBADSHAPE;
     if (HW > MID_HW && !ws) return GCSSL_ENULL;
     InBwdParams q{da, ldda, da2, ldda2, da_bcast, z, ldz, mean, rstd, mask, zt, zt_n0, gscale,
-                  group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, nrep, rep_stride, HW, C, act};
+                  group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, nrep, rep_stride, da_nslab, da_slab_stride, HW, C, act};
     hipStream_t st = (hipStream_t)stream;
     if (HW <= MID_HW) {
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, cdot ? q.group_n : 0);
@@ -874,12 +890,15 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
 
 int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, int ldq, const void* gb_zs, int ldgz,
                      const float* z, int ldz, const float* mean, const float* rstd, void* gt_a, int ldga,
-                     float* zt, float* cdot, int N, int HW, int C, int act, void* stream) {
+                     float* zt, float* cdot, int q_nslab, long q_slab_stride, int N, int HW, int C, int act, void* stream) {
     if (!gb_a || !qz || !z || !mean || !rstd || !gt_a || !zt) return GCSSL_ENULL;
+    if (q_nslab < 1 || (q_nslab > 1 && (q_slab_stride <= 0 || q_slab_stride % 4 || HW > SMALL_HW))) return GCSSL_EBADSHAPE;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || ldgb < C || ldq < C || ldga < C) return GCSSL_EBADSHAPE;
-    InDblParams q{gb_a, ldgb, qz, ldq, gb_zs, ldgz, z, ldz, mean, rstd, gt_a, ldga, zt, cdot, HW, C, act};
-    if (HW <= SMALL_HW && !(ldgb % 4) && !(ldq % 4) && !(ldz % 4) && !(ldga % 4) && (!gb_zs || !(ldgz % 4))) {
+    InDblParams q{gb_a, ldgb, qz, ldq, gb_zs, ldgz, z, ldz, mean, rstd, gt_a, ldga, zt, cdot, HW, C, act, q_nslab, q_slab_stride};
+    const bool small = HW <= SMALL_HW && !(ldgb % 4) && !(ldq % 4) && !(ldz % 4) && !(ldga % 4) && (!gb_zs || !(ldgz % 4));
+    if (q_nslab > 1 && !small) return GCSSL_EBADSHAPE;      // slabs are summed by the fused small-map kernel only
+    if (small) {
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, 0);
         dim3 sgrid(C / CW, (N + spb - 1) / spb);
         hipStream_t st = (hipStream_t)stream;

@@ -15,6 +15,7 @@ MI355X-first choices:
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -120,6 +121,7 @@ class StepEngine:
         self.v = [sd_d[f"model.{i}.weight_v"].to(dev, torch.float32).clone() for i in D_IDX]
         self.sn = ops.SnState([self.D.views[f"model.{i}.weight_orig"] for i in D_IDX], self.u, self.v, 3, dev)
         self._zcap, self._zkeep, self._splits = {}, [], {}
+        self.grad_slabs = os.environ.get("GCSSL_GRAD_SLABS", "1") != "0"
         self._alloc()
         self._d_dirty = True
         self._g_dirty = True
@@ -198,16 +200,19 @@ class StepEngine:
         self._zkeep.append(buf)
         return z
 
-    def _split(self, kind: str, z: torch.Tensor, n: int, hi: int, cin: int, cout: int):
+    def _split(self, kind: str, z: torch.Tensor, n: int, hi: int, cin: int, cout: int, max_hw: int = 256, grad: bool = False):
         """(nslab, slab_stride) for a launch over the first n samples of z: slab mode when the conv splits K and the slabs
         fit behind z, else (1, 0) = the atomic form."""
         key = (kind, z.data_ptr(), n)
+        if grad and not self.grad_slabs:                           # (A/B knob GCSSL_GRAD_SLABS=0: gradient chains keep atomics)
+            return 1, 0
         if key not in self._splits:
             ks = ops.conv_splits(kind, self.code, n, hi, cin, cout)
             per = n * z.shape[1] * z.shape[2] * z.shape[3]
-            # (the fused InstanceNorm kernel that adds the slabs handles maps up to 16x16; larger ones keep the atomic form)
+            # (the fused InstanceNorm kernels that add the slabs handle maps up to 16x16 -- 8x8 for the double backward;
+            # larger ones keep the atomic form)
             ok = (ks > 1 and ks * per <= self._zcap.get(z.data_ptr(), 0) and z.is_contiguous()
-                  and z.shape[1] * z.shape[2] <= 256)
+                  and z.shape[1] * z.shape[2] <= max_hw)
             self._splits[key] = (ks, per) if ok else (1, 0)
         return self._splits[key]
 
@@ -257,13 +262,16 @@ class StepEngine:
         # gradient tensors that feed a norm/activation backward kernel are fp32 (norm.hip header); those that feed an
         # MFMA (gb_zs, gt_a, dzs) are in the compute dtype
         F32 = torch.float32
+        # (those written by a K-split conv and read by a fused norm-backward kernel carry slab room: _zbuf)
         self.gb_a = [act(B, s, c, F32) for s, (_, c) in zip(sizes, D_CH)]     # d out / d a_l
+        for l in (1, 2):
+            self.gb_a[l] = self._zbuf("dgrad", (B,), S >> (l + 1), D_CH[l + 1][0], D_CH[l + 1][1], B)
         self.d_dzs4 = [act(N4, s, c) for s, (_, c) in zip(sizes, D_CH)]       # [3B: dzs of the batched backward | B: gb_zs]
         self.gb_zs = [t[N3:] for t in self.d_dzs4]                            # (d out / d z_l) * isig
         self.gb_x0 = torch.empty(B, S, S, 8, **f32)
         self.gp_nrm = torch.empty(B, **f32)
         self.gp_coef = torch.empty(B, **f32)
-        self.gt_z = [act(B, s, c, F32) for s, (_, c) in zip(sizes, D_CH)]
+        self.gt_z = [act(B, sizes[0], 64, F32)] + [self._zbuf("fwd", (B,), S >> l, D_CH[l][0], D_CH[l][1], B) for l in (1, 2, 3)]
         self.gt_a = [t[N3:] for t in self.d_a4]
         self.zt = [None] + [act(B, s, c, F32) for s, (_, c) in zip(sizes[1:], D_CH[1:])]
         # backward of the 3B forward
@@ -322,9 +330,9 @@ class StepEngine:
         self.g_dcat3 = act(B, S // 2, 128, z32)
         self.g_dcat2 = act(B, S // 4, 256, z32)
         self.g_dcat1 = act(B, S // 8, 512, z32)
-        self.g_dd4 = act(B, S // 16, 512, z32)
+        self.g_dd4 = self._zbuf("fwd", (B,), S // 8, 256, 512, B)
         self.g_dzd = [act(B, S // 2, 64), act(B, S // 4, 128), act(B, S // 8, 256), act(B, S // 16, 512)]
-        self.g_dd = [None, act(B, S // 2, 64, z32), act(B, S // 4, 128, z32), act(B, S // 8, 256, z32)]   # grad wrt d1..d3 via the down path
+        self.g_dd = [None] + [self._zbuf("dgrad", (B,), S >> k, G_DOWN[k][0], G_DOWN[k][1], B) for k in (1, 2, 3)]   # grad wrt d1..d3 via the down path
         self.g_slab_d, self.g_ns_d, self.g_slab_u, self.g_ns_u = [], [], [], []
         for k, (cin, cout) in enumerate(G_DOWN):
             hi = S >> k
@@ -535,12 +543,14 @@ class StepEngine:
         ops.group_mean(self.d_out, 3, self.means)
         # ---- GP first-order chain on the interpolated group (cgan/losses.py:213-220)
         ops.c5_dgrad(self.gb_a[3], self.d_w5p, consts=(1.0, 1.0, 1.0), group_n=B)
+        ns, st = 1, 0                                             # K-split slabs of the conv that produced gb_a[l]
         for l in (3, 2, 1):
             cin, cout = D_CH[l]
             ops.in_act_bwd(self.d_z[l][I], self.d_mean[l][I], self.d_rstd[l][I], self.gb_zs[l], cout, LRELU,
-                           da=self.gb_a[l], gscale=isig[l, 2:3], group_n=B, ws=self.ws)
+                           da=self.gb_a[l], gscale=isig[l, 2:3], group_n=B, ws=self.ws, da_nslab=ns, da_slab_stride=st)
+            ns, st = self._split("dgrad", self.gb_a[l - 1], B, S >> l, cin, cout, grad=True) if l > 1 else (1, 0)
             self._conv(f"D.c{l + 1}.gp_dgrad", conv_flops(B, S >> l, cin, cout), ops.conv_dgrad, self.gb_zs[l],
-                       self.d_wt[l], self.gb_a[l - 1], cin, cout)
+                       self.d_wt[l], self.gb_a[l - 1], cin, cout, split_stride=st)
         ops.act_bwd(self.gb_a[0], self.d_a[0][I], self.gb_zs[0], 64, gscale=isig[0, 2:3], group_n=B)
         self._conv("D.c1.gp_dgrad", conv_flops(B, S, 6, 64), ops.conv_dgrad, self.gb_zs[0], self.d_wt[0], self.gb_x0, 8, 64)
         # :223-231, and the seed of the reverse pass (gb_x0 * coef, the create_graph=True part of d_loss.backward(), :330)
@@ -549,15 +559,17 @@ class StepEngine:
         for l, (cin, cout) in enumerate(D_CH):
             cp = _pad8(cin)
             fl = conv_flops(B, S >> l, cin, cout)
+            ns, st = self._split("fwd", self.gt_z[l], B, S >> l, cin, cout, max_hw=64, grad=True) if l > 0 else (1, 0)
             self._conv(f"D.c{l + 1}.gp_rev_fwd", fl, ops.conv_fwd, src, self.d_wf[l], self.gt_z[l], cp, cout,
-                       gscale=isig[l, 2:3], group_n=B)
+                       gscale=isig[l, 2:3], group_n=B, split_stride=st)
             # (the weight gradient of this chain, src x gb_zs[l], is contracted together with the batched backward's below)
             if l == 0:
                 ops.dot_accum(self.gb_zs[0], self.gt_z[0], 64, self.cdot[0, 2:3])
                 ops.act_bwd(self.gt_z[0], self.d_a[0][I], self.gt_a[0], 64)
             else:
                 ops.in_dbl_bwd(self.gb_a[l], self.gt_z[l], self.gb_zs[l], self.d_z[l][I], self.d_mean[l][I],
-                               self.d_rstd[l][I], self.gt_a[l], self.zt[l], cout, LRELU, cdot=self.cdot[l, 2:3])
+                               self.d_rstd[l][I], self.gt_a[l], self.zt[l], cout, LRELU, cdot=self.cdot[l, 2:3],
+                               q_nslab=ns, q_slab_stride=st)
             src = self.gt_a[l]
         gw5 = self.D.gviews["model.11.weight"].view(512, 16)
         ops.c5_wgrad(self.gt_a[3], gw5, 512, consts=(1.0, 1.0, 1.0), group_n=B)
@@ -666,7 +678,9 @@ class StepEngine:
                 self._conv(f"G.up{k + 1}.wgrad", fl, ops.conv_wgrad, self.g_dzu[k], ins[k], self.g_slab_u[k], coutt,
                            cint)                                                        # roles swapped (ConvTranspose)
             self._on_side(up_wgrad)
-            self._conv(f"G.up{k + 1}.dgrad", fl, ops.conv_fwd, self.g_dzu[k], self.gu_wf[k], dcat[k], coutt, cint)
+            ns4, st4 = self._split("fwd", self.g_dd4, B, S >> 3, coutt, cint, grad=True) if k == 0 else (1, 0)
+            self._conv(f"G.up{k + 1}.dgrad", fl, ops.conv_fwd, self.g_dzu[k], self.gu_wf[k], dcat[k], coutt, cint,
+                       split_stride=st4)
         d_act = [self.g_cat3[..., 64:], self.g_cat2[..., 128:], self.g_cat1[..., 256:]]            # d1, d2, d3
         dskip = [self.g_dcat3[..., 64:], self.g_dcat2[..., 128:], self.g_dcat1[..., 256:]]
         for k in (3, 2, 1, 0):
@@ -674,10 +688,10 @@ class StepEngine:
             cp = _pad8(cin)
             if k == 3:
                 ops.in_act_bwd(self.g_zd[3], self.g_dmean[3], self.g_drstd[3], self.g_dzd[3], 512, LRELU,
-                               da=self.g_dd4, mask=self.g_masks[0], ws=self.ws)
+                               da=self.g_dd4, mask=self.g_masks[0], ws=self.ws, da_nslab=ns4, da_slab_stride=st4)
             elif k > 0:
                 ops.in_act_bwd(self.g_zd[k], self.g_dmean[k], self.g_drstd[k], self.g_dzd[k], cout, LRELU,
-                               da=self.g_dd[k + 1], da2=dskip[k], ws=self.ws)
+                               da=self.g_dd[k + 1], da2=dskip[k], ws=self.ws, da_nslab=nsd, da_slab_stride=std)
             else:
                 ops.act_bwd(self.g_dd[1], d_act[0], self.g_dzd[0], 64, da2=dskip[0])
             xin = self.x0[:B] if k == 0 else d_act[k - 1]
@@ -686,8 +700,13 @@ class StepEngine:
             def down_wgrad(k=k, cout=cout, cp=cp, xin=xin, fl=fl):
                 self._conv(f"G.down{k + 1}.wgrad", fl, ops.conv_wgrad, xin, self.g_dzd[k], self.g_slab_d[k], cp, cout)
             self._on_side(down_wgrad)
+            if k > 1:
+                nsd, std = self._split("dgrad", self.g_dd[k], B, S >> k, cin, cout, grad=True)
+            else:
+                nsd, std = 1, 0                                   # g_dd[1] feeds the norm-less act_bwd: atomic form
             if k > 0:
-                self._conv(f"G.down{k + 1}.dgrad", fl, ops.conv_dgrad, self.g_dzd[k], self.gd_wt[k], self.g_dd[k], cin, cout)
+                self._conv(f"G.down{k + 1}.dgrad", fl, ops.conv_dgrad, self.g_dzd[k], self.gd_wt[k], self.g_dd[k], cin, cout,
+                           split_stride=std)
         self._join_side()
         self._reduce_batches()[1].run()                           # all eight weight gradients, one launch
 

@@ -182,21 +182,22 @@ def in_act_fwd(z, a, mean, rstd, C, act, mask=None, pool=None, nslab=1, slab_str
 
 
 def in_act_bwd(z, mean, rstd, dzs, C, act, da=None, da2=None, da_bcast=None, mask=None, zt=None, zt_n0=0,
-               gscale=None, group_n=0, bias=None, dbias=None, cdot=None, ws=None, nrep=1, rep_stride=0):
-    """nrep > 1: dbias / cdot point at replica 0 of nrep replicas rep_stride floats apart (fold with ReplicaSum)."""
+               gscale=None, group_n=0, bias=None, dbias=None, cdot=None, ws=None, nrep=1, rep_stride=0, da_nslab=1,
+               da_slab_stride=0):
+    """da_nslab > 1: da is the first of that many split-K slabs (da_slab_stride floats apart), added on load.  nrep > 1: dbias / cdot point at replica 0 of nrep replicas rep_stride floats apart (fold with ReplicaSum)."""
     N, H, W, _ = z.shape
     assert z.dtype == torch.float32 and all(t is None or t.dtype == torch.float32 for t in (da, da2, zt))
     call("gcssl_in_act_bwd", code(dzs), da, _ld(da) if da is not None else 0, da2, _ld(da2) if da2 is not None else 0,
          da_bcast, z, _ld(z), mean, rstd, mask, zt, zt_n0, gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot, nrep, rep_stride,
-         ws, N, H * W, C, act)
+         da_nslab, int(da_slab_stride), ws, N, H * W, C, act)
 
 
-def in_dbl_bwd(gb_a, qz, gb_zs, z, mean, rstd, gt_a, zt, C, act, cdot=None):
+def in_dbl_bwd(gb_a, qz, gb_zs, z, mean, rstd, gt_a, zt, C, act, cdot=None, q_nslab=1, q_slab_stride=0):
     N, H, W, _ = z.shape
     assert z.dtype == torch.float32 and gb_a.dtype == torch.float32 and qz.dtype == torch.float32
     assert zt.dtype == torch.float32
     call("gcssl_in_dbl_bwd", code(gt_a), gb_a, _ld(gb_a), qz, _ld(qz), gb_zs, _ld(gb_zs) if gb_zs is not None else 0,
-         z, _ld(z), mean, rstd, gt_a, _ld(gt_a), zt, cdot, N, H * W, C, act)
+         z, _ld(z), mean, rstd, gt_a, _ld(gt_a), zt, cdot, q_nslab, int(q_slab_stride), N, H * W, C, act)
 
 
 def act_bwd(da, a, dzs, C, da2=None, gscale=None, group_n=0, bias=None, dbias=None, cdot=None, nrep=1, rep_stride=0):

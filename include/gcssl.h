@@ -123,13 +123,17 @@ int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean
 int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const float* da_bcast,
                      const float* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask, const float* zt,
                      int zt_n0, const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias,
-                     float* cdot, int nrep, int rep_stride, float* ws, int N, int HW, int C, int act, void* stream);
+                     float* cdot, int nrep, int rep_stride, int da_nslab, long da_slab_stride,
+                     float* ws, int N, int HW, int C, int act, void* stream);
 /* ws: caller-owned scratch of 2*N*C floats, required when H*W > 64 (two-kernel path), else may be NULL. */
 /* second-order backward (create_graph=True, cgan/losses.py:213-220): adjoint of dz=IN_bwd(z, act'*gb_a) for an
  * incoming adjoint qz: gt_a = act'(xhat) * d/d(dn), zt = d/dz; cdot += sum gb_zs*qz. */
 int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, int ldq, const void* gb_zs, int ldgz,
                      const float* z, int ldz, const float* mean, const float* rstd, void* gt_a, int ldga, float* zt,
-                     float* cdot, int N, int HW, int C, int act, void* stream);
+                     float* cdot, int q_nslab, long q_slab_stride, int N, int HW, int C, int act, void* stream);
+/* da_nslab / q_nslab > 1: da / qz is the first of that many split-K partial-sum slabs (stride in floats) written by a
+ * gcssl_conv4x4s2_* call with split_stride > 0; the kernel adds them on load (maps up to 16x16 / 8x8);
+ * gcssl_in_act_bwd also writes the total back to slab 0 (da is read again by gcssl_in_dbl_bwd as gb_a). */
 /* LeakyReLU backward for the norm-less layers (D.c1, G.down1; cgan/models.py:103,246), from the activation OUTPUT a. */
 int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const void* a, int lda,
                   const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias, float* cdot,

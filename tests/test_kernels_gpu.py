@@ -463,6 +463,43 @@ def test_split_k_slab_mode_matches_atomic_mode(ops, kind):
     assert rel_err(a2.float().cpu(), a1.float().cpu()) < 1e-2 and rel_err(r2.cpu(), r1.cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("H", [2, 4, 8, 16])
+def test_norm_backward_adds_incoming_gradient_slabs(ops, H):
+    """in_act_bwd(da_nslab) / in_dbl_bwd(q_nslab): the incoming gradient given as K-split slabs == given as their sum."""
+    dt = torch.bfloat16
+    N, C, ks = 12, 64, 3
+    z = nhwc(rnd(N, C, H, H, seed=70), torch.float32)
+    parts = torch.stack([nhwc(rnd(N, C, H, H, seed=71 + k), torch.float32) for k in range(ks)])      # [ks][N][H][W][C]
+    total = parts.sum(0)
+    a = torch.empty(N, H, H, C, device="cuda", dtype=dt)
+    mean = torch.empty(N, C, device="cuda"); rstd = torch.empty(N, C, device="cuda")
+    ops.in_act_fwd(z, a, mean, rstd, C, 1)
+    ws = torch.empty(2 * N * C, device="cuda")
+    dz1 = torch.empty(N, H, H, C, device="cuda", dtype=dt); dz2 = torch.empty_like(dz1)
+    ops.in_act_bwd(z, mean, rstd, dz1, C, 1, da=total, ws=ws)
+    slabs = parts.clone()
+    ops.in_act_bwd(z, mean, rstd, dz2, C, 1, da=slabs[0], ws=ws, da_nslab=ks, da_slab_stride=slabs.stride(0))
+    torch.cuda.synchronize()
+    assert rel_err(dz2.float().cpu(), dz1.float().cpu()) < 1e-2
+    assert rel_err(slabs[0].cpu(), total.cpu()) < 1e-6                       # the total is left in slab 0 (read again as gb_a)
+    if H <= 8:                                                              # the double backward sums slabs on maps up to 8x8
+        gb_a = nhwc(rnd(N, C, H, H, seed=80), torch.float32)
+        gzs = nhwc(q(rnd(N, C, H, H, seed=81), dt), dt)
+        outs = []
+        for qz, kw in ((total, {}), (parts[0], dict(q_nslab=ks, q_slab_stride=parts.stride(0)))):
+            gt_a = torch.empty(N, H, H, C, device="cuda", dtype=dt); zt = torch.empty(N, H, H, C, device="cuda")
+            cd = torch.zeros(1, device="cuda")
+            ops.in_dbl_bwd(gb_a, qz, gzs, z, mean, rstd, gt_a, zt, C, 1, cdot=cd, **kw)
+            outs.append((gt_a.float().cpu(), zt.cpu(), cd.cpu()))
+        torch.cuda.synchronize()
+        for (u, v), tol in zip(zip(*outs), (1e-2, 1e-4, 1e-3)):            # gt_a is bf16; zt fp32; cdot a long atomic sum
+            assert rel_err(v, u) < tol
+    else:
+        with pytest.raises(RuntimeError):
+            ops.in_dbl_bwd(total, parts[0], None, z, mean, rstd, a, torch.empty(N, H, H, C, device="cuda"), C, 1,
+                           q_nslab=ks, q_slab_stride=parts.stride(0))
+
+
 def test_pack_fake_interp_equals_the_two_separate_packs(ops):
     B, S = 5, 32
     pred, gt, ref = rnd(B, 3, S, S, seed=60).cuda(), rnd(B, 3, S, S, seed=61).cuda(), rnd(B, 3, S, S, seed=62).cuda()
