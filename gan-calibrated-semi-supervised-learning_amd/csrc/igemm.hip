@@ -144,6 +144,20 @@ __device__ __forceinline__ void mma_slab(const TA& As, const TB& Bs, int wm0, in
 // C-fragment coordinates of accumulator register r in a 32x32 tile (dtype independent on gfx950)
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// filter geometry: KS = 4 -> 4x4 stride 2 pad 1 (the cGAN's convs); KS = 3 -> 3x3 stride 1 pad 1 (GeneratorSimpleRegressor,
+// cgan/models.py:163-193).  Both use tap = ky*KS + kx inside a [tap][channel] K axis; packed weight rows are p.wk elements.
+template <int KS> struct Geo;
+template <> struct Geo<4> {
+    static constexpr int ST = 2, TAPS = 16;
+    __device__ static int ky(int t) { return t >> 2; }
+    __device__ static int kx(int t) { return t & 3; }
+};
+template <> struct Geo<3> {
+    static constexpr int ST = 1, TAPS = 9;
+    __device__ static int ky(int t) { return (t * 11) >> 5; }            // t / 3 for 0 <= t < 16
+    __device__ static int kx(int t) { return t - 3 * ((t * 11) >> 5); }
+};
+
 struct ConvParams {
     const void* x;      // fwd: input act; dgrad: dy; wgrad: x (high-res input of the conv)
     const void* w;      // fwd: Wf; dgrad: Wt; wgrad: dy (low-res)
@@ -153,6 +167,7 @@ struct ConvParams {
     int group_n;        // samples per group
     float inv_group_n;  // 1 / group_n (sample -> group index in the epilogues)
     int ldx, ldw, ldy;  // pixel strides (elements); ldw = lddy for wgrad
+    int wk;             // 3x3 forms: elements per packed weight row (9*Cin rounded up to 64) = length of the K loop
     int N, Hi, Wi, Cin, Cout;   // conv geometry: x is [N][Hi][Wi][Cin], y is [N][Hi/2][Wi/2][Cout]
     int lgWo, lgHoWo, lgCin, lgCout;
     int M;              // GEMM rows
@@ -171,8 +186,9 @@ struct ConvParams {
 // forward: y[m][co] = act( gscale[g(m)] * sum_{tap,ci} x[n, 2oy-1+ky, 2ox-1+kx, ci] Wf[co][tap][ci] + bias[co] )
 // GEMM M = N*Ho*Wo, N = Cout, K = 16*Cin
 // ------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int KS = 4>
 __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
+    typedef Geo<KS> G;
     constexpr int BK = BKOf<T>::v;
     constexpr int KV = Elem<T>::KV, CH = BK / KV, RPT = NT / CH;   // rows covered per pass
     constexpr int NVA = BM / RPT, NVB = BN / RPT;
@@ -185,8 +201,8 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
     const T* x = static_cast<const T*>(p.x);
     const T* w = static_cast<const T*>(p.w);
     const int chunk = tid % CH, row_t = tid / CH;
-    const int K = 16 * p.Cin;
-    const int Ho = p.Hi >> 1, Wo = p.Wi >> 1;
+    const int K = KS == 4 ? 16 * p.Cin : p.wk;
+    const int Ho = p.Hi / G::ST, Wo = p.Wi / G::ST;
 
     constexpr int ES = (int)sizeof(T);
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
@@ -197,13 +213,13 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
         rowoff[i] = 0; rowmask[i] = 0;
         if (m < p.M) {
             const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
-            const int iy0 = 2 * (rem >> p.lgWo) - 1, ix0 = 2 * (rem & (Wo - 1)) - 1;
+            const int iy0 = G::ST * (rem >> p.lgWo) - 1, ix0 = G::ST * (rem & (Wo - 1)) - 1;
             rowoff[i] = ((n * p.Hi + iy0) * p.Wi + ix0) * p.ldx * ES;
             unsigned mk = 0;
 #pragma unroll
-            for (int t = 0; t < 16; ++t)
-                if ((unsigned)(iy0 + (t >> 2)) < (unsigned)p.Hi && (unsigned)(ix0 + (t & 3)) < (unsigned)p.Wi) mk |= 1u << t;
-            rowmask[i] = mk;
+            for (int t = 0; t < G::TAPS; ++t)
+                if ((unsigned)(iy0 + G::ky(t)) < (unsigned)p.Hi && (unsigned)(ix0 + G::kx(t)) < (unsigned)p.Wi) mk |= 1u << t;
+            rowmask[i] = mk;                      // (3x3, 8-channel first layer: the K axis is padded to 16 taps, bits 9-15 stay 0)
         }
     }
     (void)Ho;
@@ -214,7 +230,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
     auto gload = [&](Vec16<T> (&qa)[NVA], Vec16<T> (&qb)[NVB], int k0) {
         const int k = k0 + chunk * KV;
         const int tap = k >> p.lgCin, ci = k & (p.Cin - 1);
-        const int tapoff = (((tap >> 2) * p.Wi + (tap & 3)) * p.ldx + ci) * ES;
+        const int tapoff = ((G::ky(tap) * p.Wi + G::kx(tap)) * p.ldx + ci) * ES;
 #pragma unroll
         for (int i = 0; i < NVA; ++i)
             qa[i] = bload<T>(xr, ((rowmask[i] >> tap) & 1u) ? (unsigned)(rowoff[i] + tapoff) : OOB);
@@ -600,8 +616,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 // Both operands arrive row(k)-major with channels contiguous -> MMajor tiles, transposed LDS reads.
 // ------------------------------------------------------------------------------------------
 // SMALLC (first layers, Cin padded to 8): the N tile is all 16 taps x 8 channels (BN must be 128).
-template <typename T, int BM, int BN, bool SMALLC>
+template <typename T, int BM, int BN, bool SMALLC, int KS = 4>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
+    typedef Geo<KS> G;
     constexpr int BK = BKOf<T>::v;
     constexpr int KV = Elem<T>::KV;
     static_assert(!SMALLC || BN == 128, "SMALLC covers 16 taps x 8 channels");
@@ -615,11 +632,11 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
     const int co0 = blockIdx.x * BM;
     const int ntile_ci = SMALLC ? 1 : p.Cin / BN;
     const int tap = SMALLC ? 0 : blockIdx.y / ntile_ci, ci0 = SMALLC ? 0 : (blockIdx.y % ntile_ci) * BN;
-    const int ky = tap >> 2, kx = tap & 3;
+    const int ky = G::ky(tap), kx = G::kx(tap);
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
     const T* x = static_cast<const T*>(p.x);
     const T* dy = static_cast<const T*>(p.w);
-    const int Wo = p.Wi >> 1;
+    const int Wo = p.Wi / G::ST;
     const int Ktot = p.M;                                      // N*Ho*Wo
     const int kt_beg = blockIdx.z * p.ktiles_per_split;
     int kt_end = kt_beg + p.ktiles_per_split;
@@ -642,9 +659,10 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
             const int k = k0 + kr;
             const int n = k >> p.lgHoWo, rem = k & ((1 << p.lgHoWo) - 1);
             int kyy = ky, kxx = kx, coff = ci0 + c * KV;
-            if (SMALLC) { const int tp = (c * KV) >> 3; kyy = tp >> 2; kxx = tp & 3; coff = (c * KV) & 7; }
-            const int iy = 2 * (rem >> p.lgWo) - 1 + kyy, ix = 2 * (rem & (Wo - 1)) - 1 + kxx;
-            const bool ok = k < Ktot && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            bool tap_ok = true;
+            if (SMALLC) { const int tp = (c * KV) >> 3; kyy = G::ky(tp); kxx = G::kx(tp); coff = (c * KV) & 7; tap_ok = tp < G::TAPS; }
+            const int iy = G::ST * (rem >> p.lgWo) - 1 + kyy, ix = G::ST * (rem & (Wo - 1)) - 1 + kxx;
+            const bool ok = tap_ok && k < Ktot && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             qb[i] = bload<T>(xr, ok ? (unsigned)((((n * p.Hi + iy) * p.Wi + ix) * p.ldx + coff) * ES) : OOB);
         }
     };
@@ -976,6 +994,63 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     const float val = ci < Cin ? w[((size_t)co * Cin + ci) * 16 + tap] : 0.f;
     if (wf) Elem<T>::st(wf + idx, val);
     if (wt) Elem<T>::st(wt + ((size_t)ci * 16 + tap) * Cout + co, val);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// 3x3 stride-1 pad-1 convolutions (GeneratorSimpleRegressor.features, cgan/models.py:163-193): the same implicit-GEMM
+// kernels with Geo<3>.  Packed operands, both with rows of `wk` = 9*C rounded up to 64 elements (zero padded):
+//   W3f[Cout][tap][CinP]                      forward
+//   W3t[Cin][8 - tap][Cout]                   data gradient = the same stride-1 conv of dy with the taps rotated by 180
+//                                             degrees and the channel roles swapped (no separate dgrad kernel)
+// ------------------------------------------------------------------------------------------
+struct Prep3Layer { const float* w; void* wf; void* wt; int Cout, Cin, CinP, wkf, wkt; };
+struct Prep3Batch { Prep3Layer l[8]; };
+template <typename T>
+__global__ __launch_bounds__(256) void prep3_weight_batch_kernel(Prep3Batch b) {
+    const Prep3Layer& L = b.l[blockIdx.y];
+    T* wf = static_cast<T*>(L.wf);
+    T* wt = static_cast<T*>(L.wt);
+    const size_t nf = wf ? (size_t)L.Cout * L.wkf : 0, nt = wt ? (size_t)L.Cin * L.wkt : 0;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nf + nt; idx += (size_t)gridDim.x * 256) {
+        if (idx < nf) {
+            const int co = (int)(idx / L.wkf), k = (int)(idx % L.wkf);
+            const int tap = k / L.CinP, ci = k % L.CinP;
+            Elem<T>::st(wf + idx, (tap < 9 && ci < L.Cin) ? L.w[((size_t)co * L.Cin + ci) * 9 + tap] : 0.f);
+        } else {
+            const size_t j = idx - nf;
+            const int ci = (int)(j / L.wkt), k = (int)(j % L.wkt);
+            const int tap = k / L.Cout, co = k % L.Cout;
+            Elem<T>::st(wt + j, tap < 9 ? L.w[((size_t)co * L.Cin + ci) * 9 + (8 - tap)] : 0.f);
+        }
+    }
+}
+
+// dw[co][ci][tap] = sum_s slab[s][co][tap][ci] over taps 0..8 of the 16-tap slab layout; one workgroup = one co x 64 ci:
+// coalesced slab reads along ci, LDS transpose, one contiguous 576-float run of dw written.  Up to 8 layers per launch.
+struct Red3Layer { const float* slab; float* dw; int nsplit, Cout, Cin, Cin_real, blk0; };
+struct Red3Batch { Red3Layer l[8]; int nl; };
+__global__ __launch_bounds__(256) void wgrad3_reduce_batch_kernel(Red3Batch b) {
+    __shared__ float tile[9][65];
+    int li = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < b.nl && (int)blockIdx.x >= b.l[i].blk0) li = i;
+    const Red3Layer& L = b.l[li];
+    const int local = blockIdx.x - L.blk0, nch = (L.Cin + 63) / 64;
+    const int ci0 = (local % nch) * 64, co = local / nch;
+    const int cw = min(64, L.Cin - ci0), cr = min(cw, L.Cin_real - ci0);
+    const size_t total = (size_t)L.Cout * 16 * L.Cin;
+    for (int e = threadIdx.x; e < 9 * 64; e += 256) {
+        const int tap = e >> 6, cil = e & 63;
+        if (cil >= cw) continue;
+        const size_t idx = ((size_t)co * 16 + tap) * L.Cin + ci0 + cil;
+        float sum = 0.f;
+        for (int k = 0; k < L.nsplit; ++k) sum += L.slab[(size_t)k * total + idx];
+        tile[tap][cil] = sum;
+    }
+    __syncthreads();
+    float* out = L.dw + ((size_t)co * L.Cin_real + ci0) * 9;
+    for (int e = threadIdx.x; e < cr * 9; e += 256) out[e] = tile[e % 9][e / 9];
 }
 
 bool use_dma() {
@@ -1510,6 +1585,123 @@ int gcssl_prep_conv_weight(int dtype, const float* w, void* wf, void* wt, int Co
     else if (dtype == GCSSL_BF16)
         hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, w,
                            (bf16_t*)wf, (bf16_t*)wt, Cout, Cin, CinP);
+    else return GCSSL_EBADDTYPE;
+    return gcssl_launch_status();
+}
+
+// ---- 3x3 stride-1 pad-1 forms (GeneratorSimpleRegressor, cgan/models.py:163-193) ----
+static int wk3(int c) { return (9 * c + 63) / 64 * 64; }
+
+int gcssl_conv3x3_wk(int C) { return C > 0 ? wk3(C) : GCSSL_EBADSHAPE; }
+
+int gcssl_conv3x3_fwd(int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
+                      int N, int H, int W, int Cin, int Cout, int out_f32, void* stream) {
+    if (!x || !w || !y) return GCSSL_ENULL;
+    int rc = check_geom(N, H, W, Cin, Cout);
+    if (rc) return rc;
+    if (Cout < 64 || ldx < Cin || ldy < Cout) return GCSSL_EBADSHAPE;
+    const int kv = dtype == GCSSL_F32 ? 4 : 8;
+    if (dtype != GCSSL_F32 && dtype != GCSSL_BF16) return GCSSL_EBADDTYPE;
+    if (ldx % kv || !aligned16(x) || !aligned16(w)) return GCSSL_EALIGN;
+    ConvParams p{}; p.x = x; p.w = w; p.y = y; p.bias = bias; p.ldx = ldx; p.ldy = ldy; p.out_f32 = out_f32;
+    p.N = N; p.Hi = H; p.Wi = W; p.Cin = Cin; p.Cout = Cout; p.wk = wk3(Cin);
+    p.lgWo = ilog2(W); p.lgHoWo = ilog2(H * W); p.lgCin = ilog2(Cin); p.lgCout = ilog2(Cout);
+    p.M = N * H * W;
+    if (!fill_bytes(p, (size_t)N * H * W * ldx, (size_t)Cout * p.wk, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const bool big = (long)((p.M + 127) / 128) * (Cout / 64) >= 256;
+    dim3 grid((p.M + (big ? 127 : 63)) / (big ? 128 : 64), Cout / 64, 1);
+#define C3(T, BM) hipLaunchKernelGGL((conv_fwd_kernel<T, BM, 64, 3>), grid, dim3(NT), 0, st, p)
+    if (dtype == GCSSL_F32) { if (big) C3(float, 128); else C3(float, 64); }
+    else { if (big) C3(bf16_t, 128); else C3(bf16_t, 64); }
+#undef C3
+    return gcssl_launch_status();
+}
+
+int gcssl_conv3x3_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
+    if (check_geom(N, H, W, Cin, Cout)) return GCSSL_EBADSHAPE;
+    if ((Cin < 64 && Cin != 8) || Cout < 64) return GCSSL_EBADSHAPE;
+    const int bm = Cout >= 128 ? 128 : 64, bn = Cin >= 128 ? 128 : (Cin >= 64 ? 64 : 8);
+    const long tiles = Cin == 8 ? Cout / bm : (long)(Cout / bm) * 9 * (Cin / bn);
+    const int nkt = (N * H * W + 63) / 64;
+    long want = (512 + tiles - 1) / tiles;
+    if (want > 128) want = 128;
+    if (want > nkt) want = nkt;
+    int per = (nkt + (int)want - 1) / (int)want;
+    if (per < 8) per = 8 < nkt ? 8 : nkt;
+    return (nkt + per - 1) / per;
+}
+
+// slab: [splits][Cout][16][Cin] fp32 (the 16-tap layout of the 4x4 form; taps 9-15 are not written when Cin >= 64)
+int gcssl_conv3x3_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, float* slab, int N, int H, int W,
+                        int Cin, int Cout, void* stream) {
+    if (!x || !dy || !slab) return GCSSL_ENULL;
+    const int nsplit = gcssl_conv3x3_wgrad_splits(N, H, W, Cin, Cout);
+    if (nsplit <= 0) return GCSSL_EBADSHAPE;
+    if (ldx < Cin || lddy < Cout) return GCSSL_EBADSHAPE;
+    if (dtype != GCSSL_F32 && dtype != GCSSL_BF16) return GCSSL_EBADDTYPE;
+    const int kv = dtype == GCSSL_F32 ? 4 : 8;
+    if (ldx % kv || lddy % kv || !aligned16(x) || !aligned16(dy)) return GCSSL_EALIGN;
+    ConvParams p{}; p.x = x; p.w = dy; p.y = slab; p.ldx = ldx; p.ldw = lddy;
+    p.N = N; p.Hi = H; p.Wi = W; p.Cin = Cin; p.Cout = Cout;
+    p.lgWo = ilog2(W); p.lgHoWo = ilog2(H * W); p.lgCin = ilog2(Cin); p.lgCout = ilog2(Cout);
+    p.M = N * H * W;
+    if (!fill_bytes(p, (size_t)N * H * W * ldx, (size_t)N * H * W * lddy, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
+    const int nkt = (p.M + 63) / 64;
+    p.ktiles_per_split = ((nkt + nsplit - 1) / nsplit) * (64 / (dtype == GCSSL_F32 ? BKOf<float>::v : BKOf<bf16_t>::v));
+    hipStream_t st = (hipStream_t)stream;
+    const int bm = Cout >= 128 ? 128 : 64, bn = Cin >= 128 ? 128 : 64;
+    const bool smallc = Cin == 8;
+    dim3 grid(Cout / bm, smallc ? 1 : 9 * (Cin / bn), nsplit);
+#define WG(T, A, B, S) hipLaunchKernelGGL((conv_wgrad_kernel<T, A, B, S, 3>), grid, dim3(NT), 0, st, p)
+    if (dtype == GCSSL_F32) {
+        if (smallc) { if (bm == 128) WG(float, 128, 128, true); else WG(float, 64, 128, true); }
+        else if (bm == 128 && bn == 128) WG(float, 128, 128, false); else if (bm == 128) WG(float, 128, 64, false);
+        else if (bn == 128) WG(float, 64, 128, false); else WG(float, 64, 64, false);
+    } else {
+        if (smallc) { if (bm == 128) WG(bf16_t, 128, 128, true); else WG(bf16_t, 64, 128, true); }
+        else if (bm == 128 && bn == 128) WG(bf16_t, 128, 128, false); else if (bm == 128) WG(bf16_t, 128, 64, false);
+        else if (bn == 128) WG(bf16_t, 64, 128, false); else WG(bf16_t, 64, 64, false);
+    }
+#undef WG
+    return gcssl_launch_status();
+}
+
+int gcssl_conv3x3_wgrad_reduce(int nl, const float* const* slab, const int* nsplit, float* const* dw, const int* Cout,
+                               const int* Cin, const int* Cin_real, void* stream) {
+    if (!slab || !nsplit || !dw || !Cout || !Cin || !Cin_real) return GCSSL_ENULL;
+    if (nl < 1 || nl > 8) return GCSSL_EBADSHAPE;
+    Red3Batch b{};
+    int blk = 0;
+    for (int i = 0; i < nl; ++i) {
+        if (!slab[i] || !dw[i]) return GCSSL_ENULL;
+        if (nsplit[i] <= 0 || Cout[i] <= 0 || Cin[i] <= 0 || Cin_real[i] <= 0 || Cin_real[i] > Cin[i]) return GCSSL_EBADSHAPE;
+        b.l[i] = Red3Layer{slab[i], dw[i], nsplit[i], Cout[i], Cin[i], Cin_real[i], blk};
+        blk += ((Cin[i] + 63) / 64) * Cout[i];
+    }
+    b.nl = nl;
+    hipLaunchKernelGGL(wgrad3_reduce_batch_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, b);
+    return gcssl_launch_status();
+}
+
+// w[i]: fp32 [Cout][Cin][3][3]; wf[i] (nullable): [Cout][wk(CinP)]; wt[i] (nullable): [Cin][wk(Cout)] in the compute dtype
+int gcssl_conv3x3_prep_weights(int dtype, int nl, const float* const* w, void* const* wf, void* const* wt, const int* Cout,
+                               const int* Cin, const int* CinP, void* stream) {
+    if (!w || !wf || !wt || !Cout || !Cin || !CinP) return GCSSL_ENULL;
+    if (nl < 1 || nl > 8) return GCSSL_EBADSHAPE;
+    Prep3Batch b{};
+    size_t mx = 0;
+    for (int i = 0; i < nl; ++i) {
+        if (!w[i] || (!wf[i] && !wt[i])) return GCSSL_ENULL;
+        if (Cout[i] <= 0 || Cin[i] <= 0 || CinP[i] < Cin[i]) return GCSSL_EBADSHAPE;
+        b.l[i] = Prep3Layer{w[i], wf[i], wt[i], Cout[i], Cin[i], CinP[i], wk3(CinP[i]), wk3(Cout[i])};
+        const size_t t = (wf[i] ? (size_t)Cout[i] * wk3(CinP[i]) : 0) + (wt[i] ? (size_t)Cin[i] * wk3(Cout[i]) : 0);
+        if (t > mx) mx = t;
+    }
+    unsigned gx = (unsigned)((mx + 1023) / 1024); if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
+    dim3 grid(gx, nl);
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(prep3_weight_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, b);
+    else if (dtype == GCSSL_BF16) hipLaunchKernelGGL(prep3_weight_batch_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, b);
     else return GCSSL_EBADDTYPE;
     return gcssl_launch_status();
 }

@@ -1,0 +1,326 @@
+// The non-conv pieces of GeneratorSimpleRegressor (cgan/models.py:147-216) for gfx950:
+//   nn.MaxPool2d(2, 2) forward / backward                        models.py:169,178,187,196
+//   nn.AdaptiveAvgPool2d(1) + Flatten                              models.py:201-202
+//   Linear(512,256)+ReLU+Dropout, Linear(256,64)+ReLU+Dropout, Linear(64,4)+Tanh, * delta_scale   models.py:203-216
+// The 3x3 convolutions are the Geo<3> instantiations in igemm.hip; InstanceNorm + ReLU are the kernels of norm.hip.
+// All of this is HBM/L2-bound byte shuffling or tiny dense algebra (147k weights): no MFMA here.  Activations are NHWC in
+// the compute dtype T, gradients that feed a norm backward kernel are fp32 (norm.hip header), the head is fp32 throughout.
+#include "common.h"
+
+namespace {
+
+constexpr int D0 = 512, D1 = 256, D2 = 64, D3 = 4;      // regressor widths (models.py:203-210)
+constexpr int NS = 4;                                    // samples per workgroup of the head kernels
+
+// ---- MaxPool2d(2,2): one thread = one output pixel x one 16-byte channel vector
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ a, int lda, T* __restrict__ o, int ldo,
+                                                           int N, int H, int W, int C) {
+    constexpr int KV = Elem<T>::KV;
+    const int Ho = H >> 1, Wo = W >> 1, cv = C / KV;
+    const size_t total = (size_t)N * Ho * Wo * cv;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * KV;
+        const size_t pix = idx / cv;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), n = (int)(pix / ((size_t)Wo * Ho));
+        const T* p = a + (((size_t)n * H + 2 * oy) * W + 2 * ox) * lda + c;
+        const Vec16<T> v00 = Vec16<T>::load(p), v01 = Vec16<T>::load(p + lda);
+        const Vec16<T> v10 = Vec16<T>::load(p + (size_t)W * lda), v11 = Vec16<T>::load(p + (size_t)(W + 1) * lda);
+        T* q = o + pix * ldo + c;
+#pragma unroll
+        for (int i = 0; i < KV; ++i)
+            Elem<T>::st(q + i, fmaxf(fmaxf(v00.get(i), v01.get(i)), fmaxf(v10.get(i), v11.get(i))));
+    }
+}
+
+// backward: the window's gradient goes to its FIRST maximum in row-major order (what max_pool2d's saved indices hold),
+// zero elsewhere.  dpool is [N][H/2][W/2][C] fp32, or with bcast a per-sample vector [N][C] scaled by bscale (the
+// AdaptiveAvgPool2d(1) backward folded in: every pooled pixel receives dfeat / (Ho*Wo)).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ a, int lda, const float* __restrict__ dpool,
+                                                           int ldd, int bcast, float bscale, float* __restrict__ da, int ldda,
+                                                           int N, int H, int W, int C) {
+    constexpr int KV = Elem<T>::KV;
+    const int Ho = H >> 1, Wo = W >> 1, cv = C / KV;
+    const size_t total = (size_t)N * Ho * Wo * cv;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * KV;
+        const size_t pix = idx / cv;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), n = (int)(pix / ((size_t)Wo * Ho));
+        const size_t in0 = (((size_t)n * H + 2 * oy) * W + 2 * ox);
+        const T* p = a + in0 * lda + c;
+        const Vec16<T> v00 = Vec16<T>::load(p), v01 = Vec16<T>::load(p + lda);
+        const Vec16<T> v10 = Vec16<T>::load(p + (size_t)W * lda), v11 = Vec16<T>::load(p + (size_t)(W + 1) * lda);
+        const float* g = bcast ? dpool + (size_t)n * ldd + c : dpool + pix * ldd + c;
+        float* d = da + in0 * ldda + c;
+#pragma unroll
+        for (int i = 0; i < KV; ++i) {
+            const float x0 = v00.get(i), x1 = v01.get(i), x2 = v10.get(i), x3 = v11.get(i);
+            int am = 0; float m = x0;
+            if (x1 > m) { m = x1; am = 1; }
+            if (x2 > m) { m = x2; am = 2; }
+            if (x3 > m) { m = x3; am = 3; }
+            const float gv = g[i] * bscale;
+            d[i] = am == 0 ? gv : 0.f;
+            d[ldda + i] = am == 1 ? gv : 0.f;
+            d[(size_t)W * ldda + i] = am == 2 ? gv : 0.f;
+            d[(size_t)(W + 1) * ldda + i] = am == 3 ? gv : 0.f;
+        }
+    }
+}
+
+// AdaptiveAvgPool2d(1): feat[n][c] = mean over the HW pixels
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, int ldx, float* __restrict__ feat, int N, int HW, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * C) return;
+    const int n = idx / C, c = idx % C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += Elem<T>::ld(x + ((size_t)n * HW + p) * ldx + c);
+    feat[idx] = s / (float)HW;
+}
+
+// ---- regressor head, forward.  One workgroup = NS samples; a wave owns every 4th output neuron and its lanes split
+// the inputs (coalesced weight rows), so the 590 KB of weights are read once per NS samples.
+template <int DI, int DO>
+__device__ __forceinline__ void dense_rows(const float* __restrict__ w, const float* __restrict__ b, const float (*in)[DI],
+                                           float (*out)[DO], int wave, int lane) {
+    for (int o = wave; o < DO; o += 4) {
+        float acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = 0.f;
+        for (int i = lane; i < DI; i += 64) {
+            const float wv = w[(size_t)o * DI + i];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] += wv * in[s][i];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = wave_sum(acc[s]);
+        if (lane == 0) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) out[s][o] = acc[s] + b[o];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mlp_head_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w1,
+        const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
+        const float* __restrict__ b3, const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2, float delta_scale,
+        float* __restrict__ h1g, float* __restrict__ h2g, float* __restrict__ traw, float* __restrict__ delta, int N) {
+    __shared__ float f[NS][D0], h1[NS][D1], h2[NS][D2], t[NS][D3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * NS;
+    for (int e = tid; e < NS * D0; e += 256) {
+        const int s = e / D0, i = e % D0;
+        f[s][i] = n0 + s < N ? feat[(size_t)(n0 + s) * D0 + i] : 0.f;
+    }
+    __syncthreads();
+    dense_rows<D0, D1>(w1, b1, f, h1, wave, lane);
+    __syncthreads();
+    for (int e = tid; e < NS * D1; e += 256) {                    // ReLU + Dropout(0.5) (keep mask given; eval: m1 == null)
+        const int s = e / D1, i = e % D1, n = n0 + s;
+        float v = fmaxf(h1[s][i], 0.f);
+        if (m1 && n < N) v *= m1[(size_t)n * D1 + i] ? 2.f : 0.f;
+        h1[s][i] = v;
+        if (n < N) h1g[(size_t)n * D1 + i] = v;
+    }
+    __syncthreads();
+    dense_rows<D1, D2>(w2, b2, h1, h2, wave, lane);
+    __syncthreads();
+    for (int e = tid; e < NS * D2; e += 256) {
+        const int s = e / D2, i = e % D2, n = n0 + s;
+        float v = fmaxf(h2[s][i], 0.f);
+        if (m2 && n < N) v *= m2[(size_t)n * D2 + i] ? 2.f : 0.f;
+        h2[s][i] = v;
+        if (n < N) h2g[(size_t)n * D2 + i] = v;
+    }
+    __syncthreads();
+    dense_rows<D2, D3>(w3, b3, h2, t, wave, lane);
+    __syncthreads();
+    if (tid < NS * D3) {
+        const int s = tid / D3, j = tid % D3, n = n0 + s;
+        if (n < N) {
+            const float th = tanhf(t[s][j]);
+            traw[(size_t)n * D3 + j] = th;
+            delta[(size_t)n * D3 + j] = th * delta_scale;
+        }
+    }
+}
+
+// ---- backward, data path: per sample the pre-activation gradients dp3 [4], dp2 [64], dp1 [256] and dfeat [512].
+// Column access w[o][i] for a fixed i: thread i walks o, so a wave reads 256-byte runs of each row.
+__global__ __launch_bounds__(256) void mlp_head_bwd_data_kernel(const float* __restrict__ gdelta, const float* __restrict__ traw,
+        const float* __restrict__ h1g, const float* __restrict__ h2g, const float* __restrict__ w1, const float* __restrict__ w2,
+        const float* __restrict__ w3, float delta_scale, float drop_scale, float* __restrict__ dp1, float* __restrict__ dp2,
+        float* __restrict__ dp3, float* __restrict__ dfeat, int N) {
+    __shared__ float g3[NS][D3], g2[NS][D2], g1[NS][D1];
+    const int tid = threadIdx.x, n0 = blockIdx.x * NS;
+    if (tid < NS * D3) {
+        const int s = tid / D3, j = tid % D3, n = n0 + s;
+        float v = 0.f;
+        if (n < N) {
+            const float th = traw[(size_t)n * D3 + j];
+            v = gdelta[(size_t)n * D3 + j] * delta_scale * (1.f - th * th);
+            dp3[(size_t)n * D3 + j] = v;
+        }
+        g3[s][j] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < NS * D2; e += 256) {
+        const int s = e / D2, i = e % D2, n = n0 + s;
+        float v = 0.f;
+        if (n < N) {
+#pragma unroll
+            for (int o = 0; o < D3; ++o) v += g3[s][o] * w3[o * D2 + i];
+            v = h2g[(size_t)n * D2 + i] > 0.f ? v * drop_scale : 0.f;      // Dropout keep * 2 and ReLU' in one test (h = relu*mask*2)
+            dp2[(size_t)n * D2 + i] = v;
+        }
+        g2[s][i] = v;
+    }
+    __syncthreads();
+    {
+        const int i = tid;                                           // D1 == 256 threads
+        float acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = 0.f;
+        for (int o = 0; o < D2; ++o) {
+            const float wv = w2[o * D1 + i];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] += g2[s][o] * wv;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int n = n0 + s;
+            float v = 0.f;
+            if (n < N) {
+                v = h1g[(size_t)n * D1 + i] > 0.f ? acc[s] * drop_scale : 0.f;
+                dp1[(size_t)n * D1 + i] = v;
+            }
+            g1[s][i] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < D0; i += 256) {
+        float acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = 0.f;
+        for (int o = 0; o < D1; ++o) {
+            const float wv = w1[(size_t)o * D0 + i];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] += g1[s][o] * wv;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (n0 + s < N) dfeat[(size_t)(n0 + s) * D0 + i] = acc[s];
+    }
+}
+
+// ---- backward, weights: dW[o][i] = sum_n dp[n][o] in[n][i], db[o] = sum_n dp[n][o]; one thread per element of the
+// three weight matrices and biases (flattened), the batch walked serially (coalesced along i).
+__global__ __launch_bounds__(256) void mlp_head_wgrad_kernel(const float* __restrict__ feat, const float* __restrict__ h1g,
+        const float* __restrict__ h2g, const float* __restrict__ dp1, const float* __restrict__ dp2, const float* __restrict__ dp3,
+        float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
+        float* __restrict__ dw3, float* __restrict__ db3, int N) {
+    constexpr int E1 = D1 * D0, E2 = D2 * D1, E3 = D3 * D2, EW = E1 + E2 + E3, EB = D1 + D2 + D3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= EW + EB) return;
+    const float* dp; const float* in; float* out; int o, i, DO, DI;
+    if (idx < E1) { o = idx / D0; i = idx % D0; dp = dp1; in = feat; out = dw1 + idx; DO = D1; DI = D0; }
+    else if (idx < E1 + E2) { const int e = idx - E1; o = e / D1; i = e % D1; dp = dp2; in = h1g; out = dw2 + e; DO = D2; DI = D1; }
+    else if (idx < EW) { const int e = idx - E1 - E2; o = e / D2; i = e % D2; dp = dp3; in = h2g; out = dw3 + e; DO = D3; DI = D2; }
+    else {
+        int e = idx - EW;
+        if (e < D1) { dp = dp1; out = db1 + e; DO = D1; }
+        else if (e < D1 + D2) { e -= D1; dp = dp2; out = db2 + e; DO = D2; }
+        else { e -= D1 + D2; dp = dp3; out = db3 + e; DO = D3; }
+        o = e; i = 0; in = nullptr; DI = 0;
+    }
+    float s = 0.f;
+    if (in) { for (int n = 0; n < N; ++n) s += dp[(size_t)n * DO + o] * in[(size_t)n * DI + i]; }
+    else { for (int n = 0; n < N; ++n) s += dp[(size_t)n * DO + o]; }
+    *out = s;
+}
+
+unsigned grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    return g ? (unsigned)g : 1u;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gcssl_maxpool2_fwd(int dtype, const void* a, int lda, void* o, int ldo, int N, int H, int W, int C, void* stream) {
+    if (!a || !o) return GCSSL_ENULL;
+    if (dtype != GCSSL_F32 && dtype != GCSSL_BF16) return GCSSL_EBADDTYPE;
+    const int kv = dtype == GCSSL_F32 ? 4 : 8;
+    if (N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C <= 0 || C % kv || lda < C || ldo < C) return GCSSL_EBADSHAPE;
+    if (lda % kv || ldo % kv || !aligned16(a) || !aligned16(o)) return GCSSL_EALIGN;
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / kv);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GCSSL_F32)
+        hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)a, lda, (float*)o, ldo, N, H, W, C);
+    else
+        hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)a, lda, (bf16_t*)o, ldo, N, H, W, C);
+    return gcssl_launch_status();
+}
+
+int gcssl_maxpool2_bwd(int dtype, const void* a, int lda, const float* dpool, int ldd, int bcast, float bscale, float* da,
+                       int ldda, int N, int H, int W, int C, void* stream) {
+    if (!a || !dpool || !da) return GCSSL_ENULL;
+    if (dtype != GCSSL_F32 && dtype != GCSSL_BF16) return GCSSL_EBADDTYPE;
+    const int kv = dtype == GCSSL_F32 ? 4 : 8;
+    if (N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C <= 0 || C % kv || lda < C || ldd < C || ldda < C) return GCSSL_EBADSHAPE;
+    if (lda % kv || !aligned16(a)) return GCSSL_EALIGN;
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / kv);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GCSSL_F32)
+        hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)a, lda, dpool, ldd, bcast, bscale, da, ldda, N, H, W, C);
+    else
+        hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)a, lda, dpool, ldd, bcast, bscale, da, ldda, N, H, W, C);
+    return gcssl_launch_status();
+}
+
+int gcssl_avgpool_fwd(int dtype, const void* x, int ldx, float* feat, int N, int HW, int C, void* stream) {
+    if (!x || !feat) return GCSSL_ENULL;
+    if (N <= 0 || HW <= 0 || C <= 0 || ldx < C) return GCSSL_EBADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(((size_t)N * C + 255) / 256));
+    if (dtype == GCSSL_F32) hipLaunchKernelGGL(avgpool_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, feat, N, HW, C);
+    else if (dtype == GCSSL_BF16) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, feat, N, HW, C);
+    else return GCSSL_EBADDTYPE;
+    return gcssl_launch_status();
+}
+
+/* regressor head (models.py:200-216): feat [N][512] -> h1 [N][256], h2 [N][64] (post ReLU+Dropout), traw = tanh [N][4],
+ * delta = traw * delta_scale.  m1 [N][256] / m2 [N][64]: Dropout keep masks (bytes), both NULL in eval mode. */
+int gcssl_mlp_head_fwd(const float* feat, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                       const float* b3, const uint8_t* m1, const uint8_t* m2, float delta_scale, float* h1, float* h2,
+                       float* traw, float* delta, int N, void* stream) {
+    if (!feat || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !h1 || !h2 || !traw || !delta) return GCSSL_ENULL;
+    if (N <= 0 || (!m1) != (!m2)) return GCSSL_EBADSHAPE;
+    hipLaunchKernelGGL(mlp_head_fwd_kernel, dim3((N + NS - 1) / NS), dim3(256), 0, (hipStream_t)stream, feat, w1, b1, w2, b2, w3, b3,
+                       m1, m2, delta_scale, h1, h2, traw, delta, N);
+    return gcssl_launch_status();
+}
+
+/* backward of the head for d loss / d delta = gdelta [N][4]: writes the weight and bias gradients (plain stores), the
+ * scratch dp1 [N][256], dp2 [N][64], dp3 [N][4] and dfeat [N][512] (gradient wrt the pooled features). */
+int gcssl_mlp_head_bwd(const float* gdelta, const float* traw, const float* h1, const float* h2, const float* feat,
+                       const float* w1, const float* w2, const float* w3, float delta_scale, int train, float* dp1, float* dp2,
+                       float* dp3, float* dfeat, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, int N,
+                       void* stream) {
+    if (!gdelta || !traw || !h1 || !h2 || !feat || !w1 || !w2 || !w3 || !dp1 || !dp2 || !dp3 || !dfeat || !dw1 || !db1 || !dw2 ||
+        !db2 || !dw3 || !db3) return GCSSL_ENULL;
+    if (N <= 0) return GCSSL_EBADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mlp_head_bwd_data_kernel, dim3((N + NS - 1) / NS), dim3(256), 0, st, gdelta, traw, h1, h2, w1, w2, w3,
+                       delta_scale, train ? 2.f : 1.f, dp1, dp2, dp3, dfeat, N);
+    constexpr int total = D1 * D0 + D2 * D1 + D3 * D2 + D1 + D2 + D3;
+    hipLaunchKernelGGL(mlp_head_wgrad_kernel, dim3((total + 255) / 256), dim3(256), 0, st, feat, h1, h2, dp1, dp2, dp3, dw1, db1,
+                       dw2, db2, dw3, db3, N);
+    return gcssl_launch_status();
+}
+
+}  // extern "C"

@@ -4,6 +4,8 @@ buffer: the pixel stride is taken from ``t.stride(2)``), and nothing is allocate
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -295,3 +297,85 @@ def uniform_gen(out, seed, counter=None):
 
 def group_mean(x, groups, out):
     call("gcssl_group_mean", x, groups, x.numel() // groups, out)
+
+
+# ---- GeneratorSimpleRegressor pieces (cgan/models.py:147-216): 3x3 convs, MaxPool2d, the regressor head
+def conv3_wk(c: int) -> int:
+    """elements per packed 3x3 weight row for c input channels (9*c rounded up to 64)."""
+    return _lib.call_nostream("gcssl_conv3x3_wk", c)
+
+
+class Prep3Batch:
+    """Argument block for gcssl_conv3x3_prep_weights: layers = [(w, wf|None, wt|None, cout, cin, cinp), ...] (<= 8)."""
+
+    def __init__(self, layers, dt):
+        self.n, self.dt = len(layers), dt
+        self._keep = layers
+        null = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() if t is not None else None for t in ts])
+        self._w, self._wf, self._wt = (null([l[k] for l in layers]) for k in (0, 1, 2))
+        self._co, self._ci, self._cp = (_lib.int_array([l[k] for l in layers]) for k in (3, 4, 5))
+
+    def run(self):
+        call("gcssl_conv3x3_prep_weights", self.dt, self.n, self._w, self._wf, self._wt, self._co, self._ci, self._cp)
+
+
+def conv3_fwd(x, w, y, cin, cout, bias=None):
+    """3x3 s1 p1 conv (or, with the rotated-transposed pack and swapped channel counts, its data gradient)."""
+    N, H, W, _ = x.shape
+    out_f32 = 1 if (y.dtype == torch.float32 and x.dtype != torch.float32) else 0
+    call("gcssl_conv3x3_fwd", code(x), x, _ld(x), w, bias, y, _ld(y), N, H, W, cin, cout, out_f32)
+
+
+def conv3_wgrad_splits(N, H, cin, cout) -> int:
+    r = _lib.call_nostream("gcssl_conv3x3_wgrad_splits", N, H, H, cin, cout)
+    if r <= 0:
+        raise RuntimeError(f"conv3_wgrad_splits{(N, H, cin, cout)} -> {r}")
+    return r
+
+
+def conv3_wgrad(x, dy, slab, cin, cout):
+    N, H, W, _ = x.shape
+    call("gcssl_conv3x3_wgrad", code(x), x, _ld(x), dy, _ld(dy), slab, N, H, W, cin, cout)
+
+
+class Reduce3Batch:
+    """Argument block for gcssl_conv3x3_wgrad_reduce: layers = [dict(slab, nsplit, dw, cout, cin, cin_real), ...] (<= 8)."""
+
+    def __init__(self, layers):
+        self.n = len(layers)
+        self._keep = layers
+        self._slab = _lib.ptr_array([l["slab"] for l in layers])
+        self._dw = _lib.ptr_array([l["dw"] for l in layers])
+        self._ns, self._co, self._ci, self._cr = (_lib.int_array([l[k] for l in layers])
+                                                  for k in ("nsplit", "cout", "cin", "cin_real"))
+
+    def run(self):
+        call("gcssl_conv3x3_wgrad_reduce", self.n, self._slab, self._ns, self._dw, self._co, self._ci, self._cr)
+
+
+def maxpool2_fwd(a, o, C):
+    N, H, W, _ = a.shape
+    call("gcssl_maxpool2_fwd", code(a), a, _ld(a), o, _ld(o), N, H, W, C)
+
+
+def maxpool2_bwd(a, dpool, da, C, bcast_scale=None):
+    """dpool: [N][H/2][W/2][C] fp32, or (bcast_scale given) [N][C] broadcast over the pooled pixels times bcast_scale."""
+    N, H, W, _ = a.shape
+    if bcast_scale is None:
+        call("gcssl_maxpool2_bwd", code(a), a, _ld(a), dpool, _ld(dpool), 0, 1.0, da, _ld(da), N, H, W, C)
+    else:
+        call("gcssl_maxpool2_bwd", code(a), a, _ld(a), dpool, dpool.stride(0), 1, float(bcast_scale), da, _ld(da), N, H, W, C)
+
+
+def avgpool_fwd(x, feat, C):
+    N, H, W, _ = x.shape
+    call("gcssl_avgpool_fwd", code(x), x, _ld(x), feat, N, H * W, C)
+
+
+def mlp_head_fwd(feat, w1, b1, w2, b2, w3, b3, delta_scale, h1, h2, traw, delta, m1=None, m2=None):
+    call("gcssl_mlp_head_fwd", feat, w1, b1, w2, b2, w3, b3, m1, m2, float(delta_scale), h1, h2, traw, delta, feat.shape[0])
+
+
+def mlp_head_bwd(gdelta, traw, h1, h2, feat, w1, w2, w3, delta_scale, train, dp1, dp2, dp3, dfeat, dw1, db1, dw2, db2, dw3, db3):
+    call("gcssl_mlp_head_bwd", gdelta, traw, h1, h2, feat, w1, w2, w3, float(delta_scale), int(bool(train)), dp1, dp2, dp3,
+         dfeat, dw1, db1, dw2, db2, dw3, db3, feat.shape[0])

@@ -211,6 +211,45 @@ int gcssl_group_mean(const float* x, int groups, int per_group, float* out, void
 int gcssl_cast(int dtype, const float* x, void* y, long n, void* stream);
 int gcssl_uncast(int dtype, const void* x, float* y, long n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * GeneratorSimpleRegressor (generator_type "simple", cgan/models.py:147-216; selected at cgan/cgan_train_enhanced.py:26-31)
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* nn.Conv2d(Cin, Cout, 3, padding=1) (models.py:163-193) as an implicit GEMM on MFMA: x [N][H][W][ldx>=Cin] in `dtype`,
+ * w = packed rows of gcssl_conv3x3_wk(Cin) elements (gcssl_conv3x3_prep_weights), y [N][H][W][ldy>=Cout] (fp32 when
+ * out_f32 or dtype is fp32).  The data gradient is this same call on dy with the transposed-and-rotated pack `wt` and the
+ * channel counts swapped.  H, W, Cin (>= 8), Cout (>= 64) powers of two. */
+int gcssl_conv3x3_wk(int C);
+int gcssl_conv3x3_fwd(int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
+                      int N, int H, int W, int Cin, int Cout, int out_f32, void* stream);
+/* weight gradient: split-K fp32 slabs [splits][Cout][16][Cin] (taps 0..8 of the 16-tap slab layout are meaningful),
+ * summed into the PyTorch layout dw[Cout][Cin_real][3][3] by gcssl_conv3x3_wgrad_reduce (up to 8 layers per launch). */
+int gcssl_conv3x3_wgrad_splits(int N, int H, int W, int Cin, int Cout);
+int gcssl_conv3x3_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, float* slab, int N, int H, int W,
+                        int Cin, int Cout, void* stream);
+int gcssl_conv3x3_wgrad_reduce(int nl, const float* const* slab, const int* nsplit, float* const* dw, const int* Cout,
+                               const int* Cin, const int* Cin_real, void* stream);
+/* w[i]: fp32 [Cout][Cin][3][3] -> wf[i] [Cout][wk(CinP)] (k = tap*CinP + ci) and wt[i] [Cin][wk(Cout)] (k = (8-tap)*Cout + co);
+ * either may be NULL. */
+int gcssl_conv3x3_prep_weights(int dtype, int nl, const float* const* w, void* const* wf, void* const* wt, const int* Cout,
+                               const int* Cin, const int* CinP, void* stream);
+/* nn.MaxPool2d(2,2) (models.py:169,178,187,196).  Backward routes each window's gradient to its first maximum; dpool is
+ * [N][H/2][W/2][C] fp32, or with bcast != 0 a per-sample vector [N][C] multiplied by bscale (AdaptiveAvgPool2d backward). */
+int gcssl_maxpool2_fwd(int dtype, const void* a, int lda, void* o, int ldo, int N, int H, int W, int C, void* stream);
+int gcssl_maxpool2_bwd(int dtype, const void* a, int lda, const float* dpool, int ldd, int bcast, float bscale, float* da,
+                       int ldda, int N, int H, int W, int C, void* stream);
+/* nn.AdaptiveAvgPool2d(1) + Flatten (models.py:201-202): feat[N][C] fp32 */
+int gcssl_avgpool_fwd(int dtype, const void* x, int ldx, float* feat, int N, int HW, int C, void* stream);
+/* regressor (models.py:203-216): Linear(512,256)+ReLU+Dropout, Linear(256,64)+ReLU+Dropout, Linear(64,4), Tanh, * delta_scale.
+ * m1 [N][256], m2 [N][64]: Dropout(0.5) keep masks (bytes), both NULL in eval mode.  h1/h2: post-dropout activations kept
+ * for the backward; traw = tanh output. */
+int gcssl_mlp_head_fwd(const float* feat, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                       const float* b3, const uint8_t* m1, const uint8_t* m2, float delta_scale, float* h1, float* h2,
+                       float* traw, float* delta, int N, void* stream);
+int gcssl_mlp_head_bwd(const float* gdelta, const float* traw, const float* h1, const float* h2, const float* feat,
+                       const float* w1, const float* w2, const float* w3, float delta_scale, int train, float* dp1, float* dp2,
+                       float* dp3, float* dfeat, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, int N,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,11 +61,11 @@ def build() -> Path:
     out = Path("/tmp/gcssl_trace")
     out.mkdir(exist_ok=True)
     (out / "igemm.hip").write_text(instrumented_source())
-    for f in ("common.h", "norm.hip", "misc.hip", "recrop.hip"):
+    for f in ("common.h", "norm.hip", "misc.hip", "recrop.hip", "simple_gen.hip"):
         (out / f).write_text((PKG / "csrc" / f).read_text())
     so = out / "libgcssl_trace.so"
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", str(so)] + [str(out / f) for f in ("igemm.hip", "norm.hip", "misc.hip", "recrop.hip")]
+           "-o", str(so)] + [str(out / f) for f in ("igemm.hip", "norm.hip", "misc.hip", "recrop.hip", "simple_gen.hip")]
     subprocess.run(cmd, check=True)
     return so
 
