@@ -104,6 +104,32 @@ def generator_state(seed: int) -> dict:
     return sd
 
 
+GS_CONV = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 512), (512, 512)]
+GS_CONV_IDX = (0, 3, 7, 10, 14, 17, 21, 24)
+GS_FC = [(512, 256), (256, 64), (64, 4)]
+GS_FC_IDX = (2, 5, 8)
+
+
+def simple_generator_state(seed: int) -> dict:
+    """state_dict-shaped numpy arrays for GeneratorSimpleRegressor (cgan/models.py:147-216): conv weights N(0, 0.02) as
+    weights_init_normal leaves them (models.py:37-48), conv biases and the Linear layers in their default uniform ranges."""
+    sd = {}
+    for j, ((cin, cout), i) in enumerate(zip(GS_CONV, GS_CONV_IDX)):
+        sd[f"features.{i}.weight"] = normal(f"GS.conv{j}", seed, (cout, cin, 3, 3), 0.02)
+        bound = 1.0 / np.sqrt(cin * 9)
+        sd[f"features.{i}.bias"] = uniform(f"GS.conv{j}.b", seed, (cout,), -bound, bound)
+    for j, ((fin, fout), i) in enumerate(zip(GS_FC, GS_FC_IDX)):
+        bound = 1.0 / np.sqrt(fin)
+        sd[f"regressor.{i}.weight"] = uniform(f"GS.fc{j}.w", seed, (fout, fin), -bound, bound)
+        sd[f"regressor.{i}.bias"] = uniform(f"GS.fc{j}.b", seed, (fout,), -bound, bound)
+    return sd
+
+
+def gs_mask_shapes(batch: int):
+    """Shapes of the two Dropout(0.5) sites of GeneratorSimpleRegressor.regressor (cgan/models.py:205,208)."""
+    return [(batch, 256), (batch, 64)]
+
+
 def g_mask_shapes(batch: int, size: int):
     """Shapes (NCHW) of the three Dropout(0.5) sites in GeneratorUNet (cgan/models.py:106,109,110)."""
     return [(batch, 512, size // 16, size // 16),
@@ -111,7 +137,7 @@ def g_mask_shapes(batch: int, size: int):
             (batch, 128, size // 4, size // 4)]
 
 
-def step_inputs(seed: int, batch: int, size: int, n_critic: int = 2, tag: str = "") -> dict:
+def step_inputs(seed: int, batch: int, size: int, n_critic: int = 2, tag: str = "", generator_type: str = "unet") -> dict:
     """One iteration's worth of inputs (numpy, NCHW fp32) for the cGAN step.
 
     ``refined``: one tensor per critic step plus one for the G step (stand-ins for the host
@@ -130,7 +156,7 @@ def step_inputs(seed: int, batch: int, size: int, n_critic: int = 2, tag: str = 
                     for k in range(n_critic + 1)],
         "alpha": [uniform(f"{t}/alpha{k}", seed, (batch, 1, 1, 1)) for k in range(n_critic)],
         "masks": [[keep_mask(f"{t}/mask{k}.{j}", seed, shp)
-                   for j, shp in enumerate(g_mask_shapes(batch, size))]
+                   for j, shp in enumerate(gs_mask_shapes(batch) if generator_type == "simple" else g_mask_shapes(batch, size))]
                   for k in range(n_critic + 1)],
     }
     return out

@@ -112,6 +112,33 @@ def g_forward(sd: Dict[str, Tensor], x: Tensor, delta_scale: float,
     return raw * delta_scale
 
 
+GS_CONV_IDX = (0, 3, 7, 10, 14, 17, 21, 24)      # nn.Conv2d positions in GeneratorSimpleRegressor.features (models.py:161-197)
+GS_FC_IDX = (2, 5, 8)                             # nn.Linear positions in .regressor (models.py:200-211)
+
+
+def g_simple_forward(sd: Dict[str, Tensor], x: Tensor, delta_scale: float,
+                     masks: Optional[Sequence[Tensor]] = None, taps: Optional[dict] = None) -> Tensor:
+    """GeneratorSimpleRegressor.forward (cgan/models.py:147-216): four blocks of 2x [Conv3x3(+bias), InstanceNorm, ReLU] +
+    MaxPool2d(2,2), then AdaptiveAvgPool2d(1) -> Linear(512,256) ReLU Dropout -> Linear(256,64) ReLU Dropout ->
+    Linear(64,4) -> Tanh, times delta_scale.  masks=None is eval mode; otherwise the two keep-masks [B,256], [B,64]."""
+    h = x
+    for j, i in enumerate(GS_CONV_IDX):
+        h = F.conv2d(h, sd[f"features.{i}.weight"], sd[f"features.{i}.bias"], padding=1)
+        h = F.relu(F.instance_norm(h, eps=IN_EPS))
+        if taps is not None:
+            taps[f"gs.a{j}"] = h.detach().clone()
+        if j & 1:
+            h = F.max_pool2d(h, 2, 2)
+    feat = h.mean(dim=(2, 3))
+    m = masks if masks is not None else (None, None)
+    h1 = _drop(F.relu(F.linear(feat, sd["regressor.2.weight"], sd["regressor.2.bias"])), m[0])
+    h2 = _drop(F.relu(F.linear(h1, sd["regressor.5.weight"], sd["regressor.5.bias"])), m[1])
+    raw = torch.tanh(F.linear(h2, sd["regressor.8.weight"], sd["regressor.8.bias"]))
+    if taps is not None:
+        taps["gs.feat"], taps["gs.h1"], taps["gs.h2"] = feat.detach().clone(), h1.detach().clone(), h2.detach().clone()
+    return raw * delta_scale
+
+
 # ----------------------------------------------------------------------------------------------
 # losses (cgan/losses.py)
 # ----------------------------------------------------------------------------------------------
@@ -226,6 +253,8 @@ D_PARAM_KEYS = [k for i in D_IDX for k in (f"model.{i}.bias", f"model.{i}.weight
 G_PARAM_KEYS = ["down1.model.0.weight", "down2.model.0.weight", "down3.model.0.weight",
                 "down4.model.0.weight", "up1.model.0.weight", "up2.model.0.weight",
                 "up3.model.0.weight", "up4.0.weight", "fc_delta.1.weight", "fc_delta.1.bias"]
+GS_PARAM_KEYS = ([k for i in GS_CONV_IDX for k in (f"features.{i}.weight", f"features.{i}.bias")]
+                 + [k for i in GS_FC_IDX for k in (f"regressor.{i}.weight", f"regressor.{i}.bias")])   # named_parameters() order
 
 
 class StepOracle:
@@ -238,14 +267,17 @@ class StepOracle:
 
     def __init__(self, sd_g: Dict[str, Tensor], sd_d: Dict[str, Tensor], lr: float = 2e-4,
                  betas=(0.5, 0.999), delta_scale: float = 0.3, lambda_gp: float = 1.0,
-                 lambda_iou: float = 1.0, n_critic: int = 2):
+                 lambda_iou: float = 1.0, n_critic: int = 2, generator_type: str = "unet"):
+        # generator_type: get_generator(), cgan/cgan_train_enhanced.py:26-31
+        self.g_keys = GS_PARAM_KEYS if generator_type == "simple" else G_PARAM_KEYS
+        self.g_fwd = g_simple_forward if generator_type == "simple" else g_forward
         self.g = {k: v.clone().float() for k, v in sd_g.items()}
         self.d = {k: v.clone().float() for k, v in sd_d.items()}
-        for k in G_PARAM_KEYS:
+        for k in self.g_keys:
             self.g[k].requires_grad_(True)
         for k in D_PARAM_KEYS:
             self.d[k].requires_grad_(True)
-        self.opt_g = Adam([self.g[k] for k in G_PARAM_KEYS], lr, betas)
+        self.opt_g = Adam([self.g[k] for k in self.g_keys], lr, betas)
         self.opt_d = Adam([self.d[k] for k in D_PARAM_KEYS], lr, betas)
         self.delta_scale, self.lambda_gp, self.lambda_iou, self.n_critic = \
             delta_scale, lambda_gp, lambda_iou, n_critic
@@ -260,7 +292,7 @@ class StepOracle:
                 self.d[k].grad = None
             real = d_forward(self.d, pred, gt, True)                         # :308
             with torch.no_grad():                                            # :311-315
-                delta_det = g_forward(self.g, pred, self.delta_scale, masks[c])
+                delta_det = self.g_fwd(self.g, pred, self.delta_scale, masks[c])
                 refined = refine_fn(delta_det, c)
             fake = d_forward(self.d, pred, refined, True)                    # :316
             gp = gradient_penalty(self.d, (pred, gt), (pred, refined), alphas[c], taps=tp)  # :319-324
@@ -277,9 +309,9 @@ class StepOracle:
             log["d_loss"].append(float(d_loss)); log["gp"].append(float(gp))
             log["wd"].append(float(wd)); log["d_grad_norm"].append(float(total))
         # ---- generator update (:345-369) ----
-        for k in G_PARAM_KEYS:
+        for k in self.g_keys:
             self.g[k].grad = None
-        delta_pred = g_forward(self.g, pred, self.delta_scale, masks[self.n_critic])        # :348
+        delta_pred = self.g_fwd(self.g, pred, self.delta_scale, masks[self.n_critic])       # :348
         cal = apply_delta_to_bbox(pred_box, delta_pred, True)                # :351
         gtb = apply_delta_to_bbox(pred_box, delta_true, True)                # :352
         loss_iou = eiou_loss(cal, gtb)                                       # :353-355
@@ -288,11 +320,11 @@ class StepOracle:
         with torch.no_grad():                                                # value only
             fake_g = d_forward(self.d, pred, refined_g, True)                # :361 (advances u,v)
         loss_wgan = -fake_g.mean()                                           # :362
-        grads = list(torch.autograd.grad(loss_reg, [self.g[k] for k in G_PARAM_KEYS]))      # :366
+        grads = list(torch.autograd.grad(loss_reg, [self.g[k] for k in self.g_keys]))         # :366
         if taps is not None:
             taps["delta_pred"] = delta_pred.detach().clone()
             taps["fake_validity_for_G"] = fake_g.detach().clone()
-            for k, g in zip(G_PARAM_KEYS, grads):
+            for k, g in zip(self.g_keys, grads):
                 taps[f"g.grad.{k}"] = g.detach().clone()
         total_g = clip_grad_norm_(grads, 1.0)                                # :368
         self.opt_g.step(grads)                                               # :369

@@ -54,11 +54,22 @@ class FixedDropout(nn.Module):
         return x * (self.mask.to(x.dtype) * 2.0)
 
 
-def build_nets(seed: int):
-    G = ref_models.GeneratorUNet(delta_scale=0.3)
+def g_state(seed: int, generator_type: str):
+    return synth.simple_generator_state(seed) if generator_type == "simple" else synth.generator_state(seed)
+
+
+def build_nets(seed: int, generator_type: str = "unet"):
     D = ref_models.Discriminator(spectral_norm=True)
-    G.load_state_dict({k: T(v) for k, v in synth.generator_state(seed).items()})
     D.load_state_dict({k: T(v) for k, v in synth.discriminator_state(seed).items()})
+    if generator_type == "simple":                       # get_generator(), cgan/cgan_train_enhanced.py:26-31
+        G = ref_models.GeneratorSimpleRegressor(delta_scale=0.3)
+        G.load_state_dict({k: T(v) for k, v in synth.simple_generator_state(seed).items()})
+        drops = [FixedDropout(), FixedDropout()]
+        assert isinstance(G.regressor[4], nn.Dropout) and isinstance(G.regressor[7], nn.Dropout)
+        G.regressor[4], G.regressor[7] = drops
+        return G, D, drops
+    G = ref_models.GeneratorUNet(delta_scale=0.3)
+    G.load_state_dict({k: T(v) for k, v in synth.generator_state(seed).items()})
     drops = [FixedDropout(), FixedDropout(), FixedDropout()]
     assert isinstance(G.down4.model[3], nn.Dropout) and isinstance(G.up1.model[3], nn.Dropout)
     G.down4.model[3], G.up1.model[3], G.up2.model[3] = drops
@@ -87,19 +98,19 @@ def pin(out: dict, name: str, t: torch.Tensor, full_limit: int = 70000):
 
 
 def run_case(name: str, seed: int, B: int, S: int, n_critic: int, iters: int, taps_full: bool,
-             gray28: bool = False):
-    G, D, drops = build_nets(seed)
+             gray28: bool = False, generator_type: str = "unet"):
+    G, D, drops = build_nets(seed, generator_type)
     G.train(); D.train()
     opt_g = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
     opt_d = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
     crit = ref_losses.HybridLoss(lambda_iou=1.0)
     out = {"meta": np.array([seed, B, S, n_critic, iters, int(gray28)]),
-           "wsum_g": checksum(synth.generator_state(seed)),
+           "wsum_g": checksum(g_state(seed, generator_type)),
            "wsum_d": checksum(synth.discriminator_state(seed))}
     lambda_gp = 1.0
     orig_rand = torch.rand
     for it in range(iters):
-        inp = synth.step_inputs(seed + 1000 * it, B, S, n_critic, tag=name)
+        inp = synth.step_inputs(seed + 1000 * it, B, S, n_critic, tag=name, generator_type=generator_type)
         if gray28:  # MNIST-shaped plumbing case: 28x28 gray, zero-padded to 32, 3 channels
             for key in ("pred", "gt"):
                 g = inp[key][:, :1, 2:30, 2:30]
@@ -185,19 +196,20 @@ def run_case(name: str, seed: int, B: int, S: int, n_critic: int, iters: int, ta
     st = opt_d.state[D.model[2].weight_orig]
     pin(out, "final.adam_m.D.model.2.weight_orig", st["exp_avg"], 5000)
     pin(out, "final.adam_v.D.model.2.weight_orig", st["exp_avg_sq"], 5000)
-    st = opt_g.state[G.up4[0].weight]
-    pin(out, "final.adam_m.G.up4.0.weight", st["exp_avg"], 5000)
-    pin(out, "final.adam_v.G.up4.0.weight", st["exp_avg_sq"], 5000)
+    gkey, gparam = ("features.24.weight", G.features[24].weight) if generator_type == "simple" else ("up4.0.weight", G.up4[0].weight)
+    st = opt_g.state[gparam]
+    pin(out, f"final.adam_m.G.{gkey}", st["exp_avg"], 5000)
+    pin(out, f"final.adam_v.G.{gkey}", st["exp_avg_sq"], 5000)
     np.savez_compressed(HERE / f"{name}.npz", **out)
     print(f"{name}: {len(out)} arrays, {os.path.getsize(HERE / (name + '.npz')) / 1024:.0f} KiB")
 
 
-def forward_case(name: str, seed: int, B: int, S: int):
+def forward_case(name: str, seed: int, B: int, S: int, generator_type: str = "unet"):
     """Per-layer activations (train and eval mode), single forward of D and G."""
-    G, D, drops = build_nets(seed)
-    inp = synth.step_inputs(seed, B, S, 1, tag=name)
+    G, D, drops = build_nets(seed, generator_type)
+    inp = synth.step_inputs(seed, B, S, 1, tag=name, generator_type=generator_type)
     pred, gt = T(inp["pred"]), T(inp["gt"])
-    out = {"meta": np.array([seed, B, S]), "wsum_g": checksum(synth.generator_state(seed)),
+    out = {"meta": np.array([seed, B, S]), "wsum_g": checksum(g_state(seed, generator_type)),
            "wsum_d": checksum(synth.discriminator_state(seed))}
     acts = {}
 
@@ -206,8 +218,12 @@ def forward_case(name: str, seed: int, B: int, S: int):
             acts[key] = o.detach().clone()
         return fn
     hs = [D.model[i].register_forward_hook(hook(f"d.act{j}")) for j, i in enumerate((1, 4, 7, 10), 1)]
-    hs += [getattr(G, n).register_forward_hook(hook(f"g.{n}")) for n in
-           ("down1", "down2", "down3", "down4", "up1", "up2", "up3", "up4")]
+    if generator_type == "simple":      # the ReLU behind every conv + InstanceNorm, and the pooled features
+        hs += [G.features[i].register_forward_hook(hook(f"gs.a{j}")) for j, i in enumerate((2, 5, 9, 12, 16, 19, 23, 26))]
+        hs += [G.regressor[1].register_forward_hook(hook("gs.feat"))]
+    else:
+        hs += [getattr(G, n).register_forward_hook(hook(f"g.{n}")) for n in
+               ("down1", "down2", "down3", "down4", "up1", "up2", "up3", "up4")]
     for mode in ("eval", "train"):
         G.train(mode == "train"); D.train(mode == "train")
         for d, m in zip(drops, inp["masks"][0]):
@@ -261,6 +277,11 @@ def loss_vectors():
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["simple"]:          # only the GeneratorSimpleRegressor fixtures (generator_type "simple")
+        forward_case("fwd_simple_B2_S32", 42, 2, 32, generator_type="simple")
+        run_case("step_simple_B4_S32", 46, 4, 32, n_critic=2, iters=2, taps_full=True, generator_type="simple")
+        run_case("step_simple_B2_S64", 47, 2, 64, n_critic=1, iters=1, taps_full=False, generator_type="simple")
+        sys.exit(0)
     loss_vectors()
     forward_case("fwd_B2_S32", 42, 2, 32)
     forward_case("fwd_B2_S64", 42, 2, 64)

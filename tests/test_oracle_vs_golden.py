@@ -11,8 +11,16 @@ T = torch.from_numpy
 TOL = 2e-5   # oracle vs reference, fp32 CPU both sides
 
 
-def _state(synth, seed):
-    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+def _gtype(name):
+    return "simple" if "simple" in name else "unet"
+
+
+def _gstate(synth, seed, gtype="unet"):
+    return synth.simple_generator_state(seed) if gtype == "simple" else synth.generator_state(seed)
+
+
+def _state(synth, seed, gtype="unet"):
+    g = {k: T(v) for k, v in _gstate(synth, seed, gtype).items()}
     d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
     return g, d
 
@@ -22,11 +30,11 @@ def _wsum(sd):
                     + [float(np.abs(np.asarray(v, dtype=np.float64)).sum()) for _, v in sorted(sd.items())])
 
 
-@pytest.mark.parametrize("name", ["fwd_B2_S32", "fwd_B2_S64", "step_B4_S32"])
+@pytest.mark.parametrize("name", ["fwd_B2_S32", "fwd_B2_S64", "step_B4_S32", "fwd_simple_B2_S32", "step_simple_B4_S32"])
 def test_deterministic_weights_regenerate_bit_exact(synth, name):
     fix = load_golden(name)
     seed = int(fix["meta"][0])
-    assert np.array_equal(_wsum(synth.generator_state(seed)), fix["wsum_g"])
+    assert np.array_equal(_wsum(_gstate(synth, seed, _gtype(name))), fix["wsum_g"])
     assert np.array_equal(_wsum(synth.discriminator_state(seed)), fix["wsum_d"])
 
 
@@ -72,14 +80,34 @@ def test_forward_activations(synth, name):
             assert rel_err(d[f"model.{i}.weight_v"], fix[f"{mode}.v.{i}"]) < TOL
 
 
+def test_simple_generator_forward_activations(synth):
+    """GeneratorSimpleRegressor (generator_type "simple", cgan/models.py:147-216): every ReLU output, the pooled features
+    and delta, in eval and train mode, against the reference module's own forward."""
+    name = "fwd_simple_B2_S32"
+    fix = load_golden(name)
+    seed, B, S = (int(v) for v in fix["meta"])
+    inp = synth.step_inputs(seed, B, S, 1, tag=name, generator_type="simple")
+    g, _ = _state(synth, seed, "simple")
+    for mode in ("eval", "train"):
+        taps = {}
+        masks = [T(m) for m in inp["masks"][0]] if mode == "train" else None
+        with torch.no_grad():
+            delta = O.g_simple_forward(g, T(inp["pred"]), 0.3, masks, taps=taps)
+        assert rel_err(delta, fix[f"{mode}.g_delta"]) < TOL
+        for j in range(8):
+            check_pinned(fix, f"{mode}.gs.a{j}", taps[f"gs.a{j}"], TOL, synth)
+        check_pinned(fix, f"{mode}.gs.feat", taps["gs.feat"], TOL, synth)
+
+
 def run_oracle_case(synth, name):
     fix = load_golden(name)
     seed, B, S, n_critic, iters, gray = (int(v) for v in fix["meta"])
-    g, d = _state(synth, seed)
-    orc = O.StepOracle(g, d, n_critic=n_critic)
+    gtype = _gtype(name)
+    g, d = _state(synth, seed, gtype)
+    orc = O.StepOracle(g, d, n_critic=n_critic, generator_type=gtype)
     logs, taps0 = [], {}
     for it in range(iters):
-        inp = synth.step_inputs(seed + 1000 * it, B, S, n_critic, tag=name)
+        inp = synth.step_inputs(seed + 1000 * it, B, S, n_critic, tag=name, generator_type=gtype)
         if gray:
             for key in ("pred", "gt"):
                 z = np.zeros_like(inp[key]); z[:, :, 2:30, 2:30] = inp[key][:, :1, 2:30, 2:30]
@@ -92,7 +120,8 @@ def run_oracle_case(synth, name):
     return fix, orc, logs, taps0
 
 
-@pytest.mark.parametrize("name", ["step_B4_S32", "step_B2_S64", "step_B2_S128", "step_mnist_B4_S32"])
+@pytest.mark.parametrize("name", ["step_B4_S32", "step_B2_S64", "step_B2_S128", "step_mnist_B4_S32",
+                                  "step_simple_B4_S32", "step_simple_B2_S64"])
 def test_training_step(synth, name):
     fix, orc, logs, taps = run_oracle_case(synth, name)
     n_critic, iters = int(fix["meta"][3]), int(fix["meta"][4])
@@ -121,7 +150,9 @@ def test_training_step(synth, name):
             if k in ("model.2.bias", "model.5.bias", "model.8.bias"):
                 continue   # exactly-zero gradient (bias cancelled by InstanceNorm): rounding noise only
             check_pinned(fix, f"it0.c0.dgrad.{k}", taps[f"d.grad.{k}"], 2e-4, synth)
-        for k in O.G_PARAM_KEYS:
+        for k in orc.g_keys:
+            if k.startswith("features.") and k.endswith(".bias"):
+                continue   # conv bias in front of InstanceNorm: exactly-zero gradient, rounding noise only
             check_pinned(fix, f"it0.ggrad.{k}", taps[f"g.grad.{k}"], 2e-4, synth)
     # state after the last iteration.  Adam's first steps are ~lr*sign(g): compare with an
     # absolute tolerance of a few % of lr per step taken.
@@ -139,6 +170,8 @@ def test_training_step(synth, name):
             bad = np.abs(smp - fix[key + "@sample"]) > 0.05 * lr * (last + 1) * n_critic + 1e-6
             assert bad.mean() <= 0.01, (k, bad.mean())
     for k, v in orc.g.items():
+        if k.startswith("features.") and k.endswith(".bias"):
+            continue       # Adam turns the rounding-noise gradient of these biases into +-lr steps of either sign
         a = v.detach().numpy().reshape(-1)
         key = f"it{last}.G.{k}"
         if key in fix:
