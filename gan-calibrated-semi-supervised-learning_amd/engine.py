@@ -21,6 +21,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import torch
 
 from . import _lib, ops
+from .gen_simple import GS_PARAM_KEYS, SimpleGenerator
 from .ops import LRELU, RELU
 
 D_IDX = (0, 2, 5, 8)
@@ -99,7 +100,10 @@ class StepEngine:
                  n_critic: int = 2, dtype="bf16", device="cuda", lr: float = 2e-4, betas=(0.5, 0.999),
                  delta_scale: float = 0.3, lambda_gp: float = 1.0, lambda_iou: float = 1.0, seed: int = 42,
                  allreduce: Optional[Callable[[torch.Tensor], None]] = None, keep_clipped_grads: bool = True,
-                 overlap: int = 0):
+                 overlap: int = 0, generator_type: str = "unet"):
+        if generator_type not in ("unet", "simple"):
+            raise ValueError(f"generator_type must be 'unet' or 'simple' (cgan/cgan_train_enhanced.py:26-31), got {generator_type!r}")
+        self.generator_type = generator_type
         if size < 32 or size & (size - 1):
             raise ValueError("img size must be a power of two >= 32 (the reference raises below 32: SURVEY §0)")
         self.B, self.S, self.c = batch, size, n_critic
@@ -116,13 +120,15 @@ class StepEngine:
         dev = self.dev
         f32 = dict(device=dev, dtype=torch.float32)
         self.D = FlatParams({k: sd_d[k].to(dev, torch.float32) for k in D_PARAM_KEYS}, D_PARAM_KEYS, dev)
-        self.G = FlatParams({k: sd_g[k].to(dev, torch.float32) for k in G_PARAM_KEYS}, G_PARAM_KEYS, dev)
+        g_keys = GS_PARAM_KEYS if generator_type == "simple" else G_PARAM_KEYS
+        self.G = FlatParams({k: sd_g[k].to(dev, torch.float32) for k in g_keys}, g_keys, dev)
         self.u = [sd_d[f"model.{i}.weight_u"].to(dev, torch.float32).clone() for i in D_IDX]
         self.v = [sd_d[f"model.{i}.weight_v"].to(dev, torch.float32).clone() for i in D_IDX]
         self.sn = ops.SnState([self.D.views[f"model.{i}.weight_orig"] for i in D_IDX], self.u, self.v, 3, dev)
         self._zcap, self._zkeep, self._splits = {}, [], {}
         self.grad_slabs = os.environ.get("GCSSL_GRAD_SLABS", "1") != "0"
         self._alloc()
+        self.gen = SimpleGenerator(self) if generator_type == "simple" else None
         self._d_dirty = True
         self._g_dirty = True
         self._prep_d_batch = self._prep_g_batch = None
@@ -353,6 +359,8 @@ class StepEngine:
                 [dict(slab=self.d_slab[l], nsplit=sum(self.d_ns[l]), dw=self.D.gviews[f"model.{i}.weight_orig"], cout=cout,
                       cin=_pad8(cin), cin_real=cin, coef=self.cdot[l], u=self.sn.u_hist[l], v=self.sn.v_hist[l])
                  for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX))], nrank=3)
+            if self.gen is not None:                               # the simple generator reduces its own 3x3 slabs
+                return self._red_d, None
             gW = self.G.gviews
             up = [dict(slab=self.g_slab_u[k], nsplit=self.g_ns_u[k],
                        dw=gW[f"up{k + 1}.model.0.weight" if k < 3 else "up4.0.weight"], cout=cint, cin=coutt, cin_real=coutt)
@@ -376,6 +384,10 @@ class StepEngine:
 
     def _prep_g(self):
         if not self._g_dirty:
+            return
+        if self.gen is not None:
+            self.gen.prep()
+            self._g_dirty = False
             return
         if self._prep_g_batch is None:
             layers = [(self.G.views[f"down{k + 1}.model.0.weight"], self.gd_wf[k], self.gd_wt[k], cout, cin, _pad8(cin))
@@ -422,7 +434,9 @@ class StepEngine:
         (seed, phase, generator step count): the count lives on the device (Adam state), so graph replays draw fresh
         masks, and it is constant within an iteration, so the draw does not depend on where d_pre runs relative to the
         critic updates; phase 10+k = critic step k, 1 = the generator step, 2 = generator_delta()."""
-        if masks is None:
+        if self.gen is not None:
+            self.gen.set_masks(masks, phase)
+        elif masks is None:
             ops.dropout_mask_gen(self.g_maskbuf, self.seed * 131 + phase, self.G.state)
         else:
             for m, src in zip(self.g_masks, masks):
@@ -430,6 +444,8 @@ class StepEngine:
 
     def _g_forward(self, x8: torch.Tensor, train: bool = True):
         """GeneratorUNet.forward (cgan/models.py:125-141) on an NHWC8 input whose first 3 channels are pred."""
+        if self.gen is not None:
+            return self.gen.forward(x8, train)
         B = self.B
         d1, d2, d3 = self.g_cat3[..., 64:], self.g_cat2[..., 128:], self.g_cat1[..., 256:]
         mk = self.g_masks if train else [None, None, None]
@@ -658,6 +674,9 @@ class StepEngine:
         if not self.G.grads_zero:
             self.G.g.zero_()
         self.G.grads_zero = False
+        if self.gen is not None:
+            self.gen.backward(self.g_gdelta)
+            return
         gW = self.G.gviews
         ops.head_bwd(self.g_gdelta, self.g_traw, self.g_pooled, self.G.views["fc_delta.1.weight"], self.delta_scale,
                      B, S * S, gW["fc_delta.1.weight"], gW["fc_delta.1.bias"], self.g_dab)

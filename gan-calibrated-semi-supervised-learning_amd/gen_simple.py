@@ -1,0 +1,142 @@
+"""GeneratorSimpleRegressor (generator_type "simple": cgan/models.py:147-216, selected at
+cgan/cgan_train_enhanced.py:26-31) as an explicit kernel schedule on the step engine's buffers.
+
+    features : 4 x [ Conv3x3(+bias) -> InstanceNorm -> ReLU ] x2 -> MaxPool2d(2,2)     (64, 128, 256, 512 channels)
+    regressor: AdaptiveAvgPool2d(1) -> Linear(512,256) ReLU Dropout -> Linear(256,64) ReLU Dropout -> Linear(64,4) -> Tanh
+    delta = tanh * delta_scale
+
+The engine owns the optimiser state (one flat fp32 parameter / gradient / moment buffer), the clip+Adam launch, the
+hipGraph capture and the data-parallel all-reduce; this class provides ``prep`` (weight re-pack after an update),
+``forward(x8, train)`` and ``backward(gdelta)``, which writes every gradient into the flat buffer.  Layout as everywhere
+in the engine: NHWC activations in the compute dtype, fp32 pre-norm tensors, fp32 gradients where a norm / pool backward
+consumes them, compute-dtype gradients (dz) where an MFMA does.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import ops
+from .ops import RELU
+
+GS_CONV = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 512), (512, 512)]
+GS_CONV_IDX = (0, 3, 7, 10, 14, 17, 21, 24)           # positions of the nn.Conv2d modules in .features
+GS_FC_IDX = (2, 5, 8)                                  # positions of the nn.Linear modules in .regressor
+GS_PARAM_KEYS = ([k for i in GS_CONV_IDX for k in (f"features.{i}.weight", f"features.{i}.bias")]
+                 + [k for i in GS_FC_IDX for k in (f"regressor.{i}.weight", f"regressor.{i}.bias")])   # named_parameters() order
+
+
+def conv3_flops(n: int, h: int, cin: int, cout: int) -> float:
+    """Algorithmic FLOPs (2*MAC) of one 3x3 s1 p1 conv pass over n samples of h x h maps."""
+    return 2.0 * n * h * h * cout * 9 * cin
+
+
+class SimpleGenerator:
+    def __init__(self, eng):
+        self.eng = eng
+        B, S, T, dev = eng.B, eng.S, eng.T, eng.dev
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.res = [S >> (j // 2) for j in range(8)]
+        self.cinp = [max(8, cin) for cin, _ in GS_CONV]
+        self.wf, self.wt, self.z, self.a, self.mean, self.rstd, self.dz, self.da, self.slab, self.ns = ([] for _ in range(10))
+        for j, ((cin, cout), r) in enumerate(zip(GS_CONV, self.res)):
+            cp = self.cinp[j]
+            self.wf.append(torch.empty(cout, ops.conv3_wk(cp), device=dev, dtype=T))
+            self.wt.append(torch.empty(cin, ops.conv3_wk(cout), device=dev, dtype=T) if j > 0 else None)
+            self.z.append(torch.empty(B, r, r, cout, **f32))
+            self.a.append(torch.empty(B, r, r, cout, device=dev, dtype=T))
+            self.mean.append(torch.empty(B, cout, **f32))
+            self.rstd.append(torch.empty(B, cout, **f32))
+            self.dz.append(torch.empty(B, r, r, cout, device=dev, dtype=T))
+            self.da.append(torch.empty(B, r, r, cout, **f32))
+            ns = ops.conv3_wgrad_splits(B, r, cp, cout)
+            self.ns.append(ns)
+            self.slab.append(torch.empty(ns, cout, 16, cp, **f32))
+        # pooled outputs of the four blocks and the gradients that arrive at them (blocks 0..2: from the next conv's dgrad)
+        self.p = [torch.empty(B, self.res[2 * b + 1] // 2, self.res[2 * b + 1] // 2, GS_CONV[2 * b + 1][1], device=dev, dtype=T)
+                  for b in range(4)]
+        self.dp = [torch.empty(B, self.res[2 * b + 1] // 2, self.res[2 * b + 1] // 2, GS_CONV[2 * b + 1][1], **f32)
+                   for b in range(3)]
+        self.feat = torch.empty(B, 512, **f32)
+        self.h1, self.h2 = torch.empty(B, 256, **f32), torch.empty(B, 64, **f32)
+        self.dp1, self.dp2, self.dp3 = torch.empty(B, 256, **f32), torch.empty(B, 64, **f32), torch.empty(B, 4, **f32)
+        self.dfeat = torch.empty(B, 512, **f32)
+        self.maskbuf = torch.empty(B * (256 + 64), device=dev, dtype=torch.uint8)       # one launch draws both
+        self.masks = [self.maskbuf[:B * 256].view(B, 256), self.maskbuf[B * 256:].view(B, 64)]
+        self._prep = self._red = None
+
+    # ---------------------------------------------------------------------------------------------- weights
+    def _w(self, j: int):
+        i = GS_CONV_IDX[j]
+        return f"features.{i}.weight", f"features.{i}.bias"
+
+    def prep(self):
+        """fp32 [Cout][Cin][3][3] -> the forward and the rotated-transposed (data gradient) operand packs, one launch."""
+        if self._prep is None:
+            V = self.eng.G.views
+            self._prep = ops.Prep3Batch([(V[self._w(j)[0]], self.wf[j], self.wt[j], cout, cin, self.cinp[j])
+                                         for j, (cin, cout) in enumerate(GS_CONV)], self.eng.code)
+        self._prep.run()
+
+    def set_masks(self, masks: Optional[Sequence[torch.Tensor]], phase: int):
+        """The two Dropout(0.5) keep-masks (models.py:205,208): given (fixture / parity mode) or drawn on the device with
+        the engine's counter-based generator (same keying as the U-Net's masks: StepEngine._set_masks)."""
+        if masks is None:
+            ops.dropout_mask_gen(self.maskbuf, self.eng.seed * 131 + phase, self.eng.G.state)
+        else:
+            for m, src in zip(self.masks, masks):
+                m.copy_(src)
+
+    # ---------------------------------------------------------------------------------------------- forward
+    def forward(self, x8: torch.Tensor, train: bool = True) -> torch.Tensor:
+        """models.py:213-216 on an NHWC8 input whose first 3 channels are pred."""
+        eng, B, V = self.eng, self.eng.B, self.eng.G.views
+        src = self.x8 = x8                         # (kept: the first conv's weight gradient contracts against it)
+        for j, (cin, cout) in enumerate(GS_CONV):
+            wk, bk = self._w(j)
+            eng._conv(f"GS.c{j + 1}.fwd", conv3_flops(B, self.res[j], cin, cout), ops.conv3_fwd, src, self.wf[j], self.z[j],
+                      self.cinp[j], cout, bias=V[bk])
+            ops.in_act_fwd(self.z[j], self.a[j], self.mean[j], self.rstd[j], cout, RELU)
+            if j & 1:
+                ops.maxpool2_fwd(self.a[j], self.p[j // 2], cout)
+                src = self.p[j // 2]
+            else:
+                src = self.a[j]
+        ops.avgpool_fwd(self.p[3], self.feat, 512)
+        m1, m2 = self.masks if train else (None, None)
+        ops.mlp_head_fwd(self.feat, V["regressor.2.weight"], V["regressor.2.bias"], V["regressor.5.weight"],
+                         V["regressor.5.bias"], V["regressor.8.weight"], V["regressor.8.bias"], eng.delta_scale,
+                         self.h1, self.h2, eng.g_traw, eng.g_delta, m1=m1, m2=m2)
+        return eng.g_delta
+
+    # ---------------------------------------------------------------------------------------------- backward
+    def backward(self, gdelta: torch.Tensor):
+        """Gradient of the generator loss wrt every parameter, given d loss / d delta (the EIoU kernel's output), written
+        into the engine's flat gradient buffer (plain stores for the weights; the zero-true-gradient conv biases in
+        front of InstanceNorm are summed the way autograd sums them, rounding noise included)."""
+        eng, B = self.eng, self.eng.B
+        V, gW = eng.G.views, eng.G.gviews
+        ops.mlp_head_bwd(gdelta, eng.g_traw, self.h1, self.h2, self.feat, V["regressor.2.weight"], V["regressor.5.weight"],
+                         V["regressor.8.weight"], eng.delta_scale, True, self.dp1, self.dp2, self.dp3, self.dfeat,
+                         gW["regressor.2.weight"], gW["regressor.2.bias"], gW["regressor.5.weight"], gW["regressor.5.bias"],
+                         gW["regressor.8.weight"], gW["regressor.8.bias"])
+        for j in range(7, -1, -1):
+            cin, cout = GS_CONV[j]
+            r = self.res[j]
+            if j == 7:        # AdaptiveAvgPool2d(1) backward folded into the pool backward: dfeat / (h*w) at every pooled pixel
+                ops.maxpool2_bwd(self.a[7], self.dfeat, self.da[7], cout, bcast_scale=1.0 / ((r // 2) * (r // 2)))
+            elif j & 1:
+                ops.maxpool2_bwd(self.a[j], self.dp[j // 2], self.da[j], cout)
+            ops.in_act_bwd(self.z[j], self.mean[j], self.rstd[j], self.dz[j], cout, RELU, da=self.da[j],
+                           dbias=gW[self._w(j)[1]], ws=eng.ws)
+            src = self.x8 if j == 0 else (self.p[j // 2 - 1] if not (j & 1) else self.a[j - 1])
+            fl = conv3_flops(B, r, cin, cout)
+            eng._conv(f"GS.c{j + 1}.wgrad", fl, ops.conv3_wgrad, src, self.dz[j], self.slab[j], self.cinp[j], cout)
+            if j > 0:         # gradient wrt this conv's input: the previous ReLU output (odd j) or the previous block's pool
+                dst = self.da[j - 1] if (j & 1) else self.dp[j // 2 - 1]
+                eng._conv(f"GS.c{j + 1}.dgrad", fl, ops.conv3_fwd, self.dz[j], self.wt[j], dst, cout, cin)
+        if self._red is None:
+            self._red = ops.Reduce3Batch([dict(slab=self.slab[j], nsplit=self.ns[j], dw=gW[self._w(j)[0]], cout=cout,
+                                               cin=self.cinp[j], cin_real=cin) for j, (cin, cout) in enumerate(GS_CONV)])
+        self._red.run()
