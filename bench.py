@@ -28,21 +28,21 @@ F_D = {32: 0.0535e9, 64: 0.2141e9, 128: 0.8564e9}       # forward FLOPs / image 
 F_G = {32: 0.2029e9, 64: 0.8116e9, 128: 3.2464e9}
 
 
-def synthetic_inputs(synth, seed, B, S, c, dev):
+def synthetic_inputs(synth, seed, B, S, c, dev, gtype="unet"):
     T = torch.from_numpy
-    inp = synth.step_inputs(seed, B, S, c, tag="bench")
+    inp = synth.step_inputs(seed, B, S, c, tag="bench", generator_type=gtype)
     return dict(pred=T(inp["pred"]).to(dev), gt=T(inp["gt"]).to(dev), delta_true=T(inp["delta_true"]).to(dev),
                 pred_box=T(inp["pred_box"]).to(dev), refined=[T(r).to(dev) for r in inp["refined"]]), inp
 
 
-def cpu_baseline(synth, seed, B, S, c, budget_s=25.0):
+def cpu_baseline(synth, seed, B, S, c, budget_s=25.0, gtype="unet"):
     """The CPU oracle (oracle/cgan_oracle.py, a port pinned to the reference's golden vectors) on the host cores."""
     from oracle import cgan_oracle as O
     T = torch.from_numpy
-    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+    g = {k: T(v) for k, v in (synth.simple_generator_state(seed) if gtype == "simple" else synth.generator_state(seed)).items()}
     d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
-    inp = synth.step_inputs(seed, B, S, c, tag="bench")
-    orc = O.StepOracle(g, d, n_critic=c)
+    inp = synth.step_inputs(seed, B, S, c, tag="bench", generator_type=gtype)
+    orc = O.StepOracle(g, d, n_critic=c, generator_type=gtype)
     refined = [T(r) for r in inp["refined"]]
     args = (T(inp["pred"]), T(inp["gt"]), T(inp["delta_true"]), T(inp["pred_box"]), lambda dl, k: refined[k],
             [T(a) for a in inp["alpha"]], [[T(m) for m in ms] for ms in inp["masks"]])
@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--size", type=int, default=32)
     ap.add_argument("--n_critic", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--generator", default="unet", choices=["unet", "simple"],
+                    help="generator_type (cgan/cgan_train_enhanced.py:26-31); the headline config is the default U-Net")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--probe-steps", type=int, default=3)
@@ -84,13 +86,13 @@ def main():
     engine = importlib.import_module(PKG + ".engine")
     B, S, c = args.batch, args.size, args.n_critic
     T = torch.from_numpy
-    g = {k: T(v) for k, v in synth.generator_state(42).items()}
+    g = {k: T(v) for k, v in (synth.simple_generator_state(42) if args.generator == "simple" else synth.generator_state(42)).items()}
     d = {k: T(v) for k, v in synth.discriminator_state(42).items()}
     averager = dist_mod.GradAverager() if world > 1 else None
     eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype=args.dtype, device=dev, seed=42 + rank,
                             allreduce=averager, keep_clipped_grads=False,
-                            overlap=int(os.environ.get("GCSSL_OVERLAP", "0")))
-    data, _ = synthetic_inputs(synth, 42 + rank, B, S, c, dev)          # resident in HBM before anything is timed
+                            overlap=int(os.environ.get("GCSSL_OVERLAP", "0")), generator_type=args.generator)
+    data, _ = synthetic_inputs(synth, 42 + rank, B, S, c, dev, args.generator)          # resident in HBM before anything is timed
     refine = lambda delta, k: data["refined"][k]
     call = (data["pred"], data["gt"], data["delta_true"], data["pred_box"], refine)
 
@@ -167,19 +169,20 @@ def main():
                     # MFMA utilisation of the critic's conv stack (every D.* conv launch of an iteration)
                     d_convs=dict(tflops=round(d_flops / (d_ms * 1e-3) / 1e12, 2), ms_per_iter=round(d_ms, 3),
                                  frac=round(d_flops / (d_ms * 1e-3) / 1e12 / peak, 4)))
-    flop_iter = ((12 * c + 1) * F_D[S] + (c + 3) * F_G[S]) * B * world if S in F_D else None
+    flop_iter = ((12 * c + 1) * F_D[S] + (c + 3) * F_G[S]) * B * world if (S in F_D and args.generator == "unet") else None
 
     out = dict(metric="images/sec (G+D step)", value=round(value, 1), unit="images/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(ms, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype=args.dtype, data="synthetic",
                config=dict(workload=f"cGAN WGAN-GP iteration (n_critic={c} critic steps + 1 generator step), "
-                                    f"{S}x{S}x3, batch {B}/GPU, reference G (U-Net) + D (SN PatchGAN)",
+                                    f"{S}x{S}x3, batch {B}/GPU, reference G ({'U-Net' if args.generator == 'unet' else 'GeneratorSimpleRegressor'}) "
+                                    f"+ D (SN PatchGAN)",
                            global_batch=B * world, img_size=S, n_critic=c, parallelism=f"dp{world}",
                            launch="hipGraph replay" if graphed is not None else "eager",
                            algorithmic_tflops=round(flop_iter / (ms * 1e-3) / 1e12, 2) if flop_iter else None),
                roofline=roofline)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(synth, 42, B, S, c)
+        out["cpu_baseline"] = cpu_baseline(synth, 42, B, S, c, gtype=args.generator)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -388,3 +388,69 @@ def generator_forward(module, x: torch.Tensor, masks=None) -> torch.Tensor:
     fc = module.fc_delta[1]
     params += [fc.weight, fc.bias]
     return GNetFn.apply(x, code, module.delta_scale, masks, *params)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GeneratorSimpleRegressor (cgan/models.py:147-216): the module-level path runs the same kernel schedule as the step
+# engine (gen_simple.SimpleGenerator) on a small host object that stands in for the engine
+# ------------------------------------------------------------------------------------------------------------------
+class _SimpleHost:
+    """What gen_simple.SimpleGenerator needs from its owner: sizes, the flat parameter / gradient buffers, the head's
+    output buffers and the InstanceNorm-backward scratch."""
+
+    def __init__(self, params: dict, B: int, S: int, code: int, scale: float, dev):
+        from .engine import FlatParams
+        self.B, self.S, self.code, self.T, self.dev = B, S, code, _lib.torch_dtype(code), dev
+        self.delta_scale, self.seed = scale, 0
+        self.G = FlatParams(params, list(params.keys()), dev)
+        self.ws = torch.empty(2 * B * 512, device=dev, dtype=F32)
+        self.g_traw = torch.empty(B, 4, device=dev, dtype=F32)
+        self.g_delta = torch.empty(B, 4, device=dev, dtype=F32)
+        self.x8 = torch.empty(B, S, S, 8, device=dev, dtype=self.T)
+
+    def _conv(self, _label, _flops, fn, *args, **kw):
+        return fn(*args, **kw)
+
+
+class GSimpleFn(Function):
+    @staticmethod
+    def forward(ctx, x, module, code, masks, train, *params):
+        from .gen_simple import GS_PARAM_KEYS, SimpleGenerator
+        B, S = x.shape[0], x.shape[-1]
+        key = (B, S, code, x.device)
+        cache = module.__dict__.setdefault("_hip_hosts", {})
+        if key not in cache:                                   # buffers are kept per (batch, size, dtype): inference loops
+            host = _SimpleHost({k: p.detach() for k, p in zip(GS_PARAM_KEYS, params)}, B, S, code, module.delta_scale, x.device)
+            cache[key] = (host, SimpleGenerator(host))
+        host, gen = cache[key]
+        for k, p in zip(GS_PARAM_KEYS, params):
+            host.G.views[k].copy_(p.detach())
+        gen.prep()
+        ops.pack_pair(x, None, host.x8)
+        if train:
+            if masks is None:
+                host.seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+            gen.set_masks(masks, 0)
+        ctx.gen, ctx.host = gen, host
+        return gen.forward(host.x8, train).clone()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_delta):
+        from .gen_simple import GS_PARAM_KEYS
+        host = ctx.host
+        host.G.g.zero_()
+        ctx.gen.backward(g_delta.contiguous().float())
+        return (None, None, None, None, None, *[host.G.gviews[k].clone() for k in GS_PARAM_KEYS])
+
+
+def simple_generator_forward(module, x: torch.Tensor, masks=None) -> torch.Tensor:
+    """GeneratorSimpleRegressor.forward (cgan/models.py:213-216).  In train mode the two Dropout(0.5) keep-masks
+    ([B,256], [B,64]) are drawn on the device unless given (parity runs).  One live forward per (batch, size) at a time:
+    the activations a backward needs stay in the module's cached buffers until the next forward."""
+    from .gen_simple import GS_PARAM_KEYS
+    x = _check_input(x, "x")
+    code = _lib.dtype_code(getattr(module, "compute_dtype", "fp32"))
+    sd = dict(module.named_parameters())
+    return GSimpleFn.apply(x, module, code, masks if module.training else None, bool(module.training),
+                           *[sd[k] for k in GS_PARAM_KEYS])

@@ -1,5 +1,5 @@
 """The reference's ``cgan/models.py`` Python surface on top of the HIP kernels: ``GeneratorUNet``,
-``Discriminator``, ``weights_init_normal`` with identical constructor arguments, parameter/buffer names
+``GeneratorSimpleRegressor``, ``Discriminator``, ``weights_init_normal`` with identical constructor arguments, parameter/buffer names
 (state_dict keys of SURVEY.md §2.1, incl. ``weight_orig/weight_u/weight_v``) and forward signatures.
 
 Parameters live in ordinary ``nn.Parameter``s in PyTorch layout (so ``state_dict()`` / ``load_state_dict()`` /
@@ -100,6 +100,37 @@ class GeneratorUNet(nn.Module):
     def forward(self, x: torch.Tensor, masks=None) -> torch.Tensor:
         from .autograd_nets import generator_forward
         return generator_forward(self, x, masks)
+
+
+class Conv3x3(nn.Module):
+    """Parameter holder for Conv2d(cin, cout, 3, padding=1): weight [Cout][Cin][3][3] + bias, nn.Conv2d's default init."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        bound = 1.0 / (cin * 9) ** 0.5
+        self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+
+
+class GeneratorSimpleRegressor(nn.Module):
+    """Plain CNN regressor -> 4-d box correction (cgan/models.py:147-216; generator_type "simple"): four blocks of
+    2 x [Conv3x3, InstanceNorm, ReLU] + MaxPool2d(2,2), then AdaptiveAvgPool2d(1) and a 512-256-64-4 MLP with
+    Dropout(0.5) and Tanh, times delta_scale.  Parameter names are the reference's (``features.N.*``, ``regressor.N.*``)."""
+
+    def __init__(self, delta_scale: float = None):
+        super().__init__()
+        if delta_scale is None:
+            delta_scale = _config_default("delta_scale")
+        self.delta_scale = float(delta_scale)
+        chans = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 512), (512, 512)]
+        self.features = _Holder({i: Conv3x3(ci, co) for i, (ci, co) in zip((0, 3, 7, 10, 14, 17, 21, 24), chans)})
+        self.regressor = _Holder({2: nn.Linear(512, 256), 5: nn.Linear(256, 64), 8: nn.Linear(64, 4)})
+        self.compute_dtype = "fp32"
+
+    def forward(self, x: torch.Tensor, masks=None) -> torch.Tensor:
+        from .autograd_nets import simple_generator_forward
+        return simple_generator_forward(self, x, masks)
 
 
 class Discriminator(nn.Module):

@@ -84,9 +84,10 @@ def main(argv=None):
     models = importlib.import_module(PKG + ".models")
     checkpoint = torch.load(args.weights, map_location="cpu", weights_only=False)
     delta_scale, generator_type = resolve_config(Path(args.weights), checkpoint)
-    if generator_type != "unet":
-        raise SystemExit("generator_type 'simple' (GeneratorSimpleRegressor) is a next-row item (SURVEY 8f f4)")
-    netG = models.GeneratorUNet(delta_scale=delta_scale).to(device)
+    if generator_type == "simple":                                                   # cgan/inference.py:131-134
+        netG = models.GeneratorSimpleRegressor(delta_scale=delta_scale).to(device)
+    else:
+        netG = models.GeneratorUNet(delta_scale=delta_scale).to(device)
     state = checkpoint["generator"] if isinstance(checkpoint, dict) and "generator" in checkpoint else checkpoint
     netG.load_state_dict(state)
     netG.eval()

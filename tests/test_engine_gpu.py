@@ -153,7 +153,7 @@ def test_fp32_first_critic_step_gradients(synth, name):
         check_grad(fix, f"it0.ggrad.{k}", g, synth, rtol_g, frac_ok=frac)
 
 
-@pytest.mark.parametrize("name", ["step_B4_S32", "step_B2_S64"])
+@pytest.mark.parametrize("name", ["step_B4_S32", "step_B2_S64", "step_simple_B4_S32"])
 def test_bf16_step_is_close(synth, name):
     """bf16 throughput mode: same schedule, bf16 operands.  Error is reported and bounded, not the parity claim."""
     fix, eng, (seed, B, S, n_critic, iters, gray) = make_engine(synth, name, "bf16")

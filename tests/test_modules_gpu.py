@@ -100,6 +100,45 @@ def test_generator_step_via_autograd_matches_oracle(synth, B, S, seed):
     assert rel_err(e1.cpu(), O.g_forward(gsd, pred, 0.3, None)) < 2e-4
 
 
+def test_simple_generator_module_matches_oracle(synth):
+    """models.GeneratorSimpleRegressor (generator_type "simple", cgan/models.py:147-216): state_dict keys, forward and the
+    parameter gradients of the EIoU loss through the module's autograd path, against the oracle."""
+    models, losses = load_pkg("models"), load_pkg("losses")
+    B, S, seed = 3, 32, 9
+    gsd = {k: T(v) for k, v in synth.simple_generator_state(seed).items()}
+    G = models.GeneratorSimpleRegressor(0.3).cuda()
+    assert [k for k, _ in G.named_parameters()] == O.GS_PARAM_KEYS and set(G.state_dict()) == set(gsd)
+    G.load_state_dict(gsd)
+    inp = synth.step_inputs(seed, B, S, 1, tag="modgs", generator_type="simple")
+    pred, box, dt = T(inp["pred"]), T(inp["pred_box"]), T(inp["delta_true"])
+    masks = [T(m) for m in inp["masks"][0]]
+    ga = {k: v.clone().requires_grad_(True) for k, v in gsd.items()}
+    delta = O.g_simple_forward(ga, pred, 0.3, masks)
+    loss = O.eiou_loss(O.apply_delta_to_bbox(box, delta, True), O.apply_delta_to_bbox(box, dt, True))
+    ref = dict(zip(O.GS_PARAM_KEYS, torch.autograd.grad(loss, [ga[k] for k in O.GS_PARAM_KEYS])))
+    G.train()
+    dl = G(pred.cuda(), masks=[m.cuda() for m in masks])
+    cal = losses.apply_delta_to_bbox(box.cuda(), dl, training=True)
+    gtb = losses.apply_delta_to_bbox(box.cuda(), dt.cuda(), training=True)
+    tot, li = losses.HybridLoss(lambda_iou=1.0)(dl, dt.cuda(), cal, gtb)
+    tot.backward()
+    assert rel_err(dl.detach().cpu(), delta.detach()) < 2e-4 and abs(float(li) - float(loss)) < 1e-5
+    named = dict(G.named_parameters())
+    for k in O.GS_PARAM_KEYS:
+        if k.startswith("features.") and k.endswith(".bias"):
+            continue                                # exactly-zero gradient (InstanceNorm removes the bias): rounding noise
+        e = rel_err(named[k].grad.cpu(), ref[k])
+        assert e < 1e-3, (k, e)
+    G.eval()
+    with torch.no_grad():
+        e1 = G(pred.cuda())
+    assert rel_err(e1.cpu(), O.g_simple_forward(gsd, pred, 0.3, None)) < 2e-4
+    G.compute_dtype = "bf16"                        # throughput mode: bounded, not the parity claim
+    with torch.no_grad():
+        e2 = G(pred.cuda())
+    assert rel_err(e2.cpu(), e1.cpu()) < 6e-2
+
+
 def test_inputs_are_validated():
     models = load_pkg("models")
     D = models.Discriminator(True).cuda()

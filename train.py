@@ -85,8 +85,8 @@ def dataset_source(ds, refine_mod, indices, batch, size, device, seed):
 def main(argv=None):
     config = load_config()
     args = build_parser(config).parse_args(argv)
-    if args.generator_type != "unet":
-        raise SystemExit("generator_type 'simple' (GeneratorSimpleRegressor) is a next-row item (SURVEY §8f f4)")
+    if args.generator_type not in ("unet", "simple"):
+        raise SystemExit(f"unknown generator_type {args.generator_type!r} (cgan/cgan_train_enhanced.py:26-31: 'unet' or 'simple')")
     if not args.spectral_norm:
         raise SystemExit("the step engine implements the reference default spectral_norm=true")
     torch.manual_seed(args.seed)
@@ -100,7 +100,10 @@ def main(argv=None):
     engine = importlib.import_module(PKG + ".engine")
     losses = importlib.import_module(PKG + ".losses")
     synth = importlib.import_module(PKG + ".synth")
-    netG = models.GeneratorUNet(delta_scale=args.delta_scale)
+    if args.generator_type == "simple":                                              # get_generator(), :26-31
+        netG = models.GeneratorSimpleRegressor(delta_scale=args.delta_scale)
+    else:
+        netG = models.GeneratorUNet(delta_scale=args.delta_scale)
     netD = models.Discriminator(spectral_norm=args.spectral_norm)
     netG.apply(models.weights_init_normal); netD.apply(models.weights_init_normal)
     if rank == 0:
@@ -110,7 +113,7 @@ def main(argv=None):
                             n_critic=args.n_critic, dtype=args.compute_dtype, device=device, lr=args.lr,
                             betas=(args.beta1, args.beta2), delta_scale=args.delta_scale, lambda_gp=args.lambda_gp,
                             lambda_iou=args.lambda_iou, seed=args.seed + rank,
-                            allreduce=dist_mod.GradAverager() if world > 1 else None)
+                            allreduce=dist_mod.GradAverager() if world > 1 else None, generator_type=args.generator_type)
     if world > 1:
         dist_mod.broadcast_state([eng.D.p, eng.G.p] + eng.u + eng.v)
     train_idx, val_idx = None, []
@@ -184,7 +187,9 @@ def main(argv=None):
             gsd, dsd = eng.state_dicts()
             torch.save({"generator": {k: v.cpu() for k, v in gsd.items()},
                         "discriminator": {k: v.cpu() for k, v in dsd.items()},
-                        "epoch": epoch, "delta_iou": delta_iou, "config": config}, ckpt_best)   # :481-489
+                        "epoch": epoch, "delta_iou": delta_iou,
+                        "config": dict(config, generator_type=args.generator_type, delta_scale=args.delta_scale)},
+                       ckpt_best)                                                       # :481-489 (config as built at :194-214)
     if rank == 0:
         with open(out_root / "training_history.json", "w") as f:
             json.dump(history, f, indent=2)
