@@ -80,67 +80,72 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, i
     feat[idx] = s / (float)HW;
 }
 
-// ---- regressor head, forward.  One workgroup = NS samples; a wave owns every 4th output neuron and its lanes split
-// the inputs (coalesced weight rows), so the 590 KB of weights are read once per NS samples.
-template <int DI, int DO>
-__device__ __forceinline__ void dense_rows(const float* __restrict__ w, const float* __restrict__ b, const float (*in)[DI],
-                                           float (*out)[DO], int wave, int lane) {
-    for (int o = wave; o < DO; o += 4) {
-        float acc[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] = 0.f;
-        for (int i = lane; i < DI; i += 64) {
-            const float wv = w[(size_t)o * DI + i];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[s] += wv * in[s][i];
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] = wave_sum(acc[s]);
-        if (lane == 0) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) out[s][o] = acc[s] + b[o];
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void mlp_head_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w1,
-        const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
+// ---- regressor head, forward.  One workgroup = NS samples.  w1t / w2t are the TRANSPOSED weights [in][out] (re-packed
+// once per optimiser step): thread o walks the inputs, a wave reads 256-byte runs of each row and the NS activations come
+// from LDS broadcasts -- no cross-lane reduction.  (The first version gave a wave one output at a time and reduced over
+// its lanes: 64 dependent global-load round trips per wave, 88 us per launch at B = 256.)
+__global__ __launch_bounds__(256) void mlp_head_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w1t,
+        const float* __restrict__ b1, const float* __restrict__ w2t, const float* __restrict__ b2, const float* __restrict__ w3,
         const float* __restrict__ b3, const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2, float delta_scale,
         float* __restrict__ h1g, float* __restrict__ h2g, float* __restrict__ traw, float* __restrict__ delta, int N) {
-    __shared__ float f[NS][D0], h1[NS][D1], h2[NS][D2], t[NS][D3];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * NS;
+    __shared__ float f[NS][D0], h1[NS][D1], part[4][NS][D2], h2[NS][D2];
+    static_assert(D1 == 256 && NS * D2 == 256, "thread mapping below assumes 256 threads = D1 = NS * D2");
+    const int tid = threadIdx.x, n0 = blockIdx.x * NS;
     for (int e = tid; e < NS * D0; e += 256) {
         const int s = e / D0, i = e % D0;
         f[s][i] = n0 + s < N ? feat[(size_t)(n0 + s) * D0 + i] : 0.f;
     }
     __syncthreads();
-    dense_rows<D0, D1>(w1, b1, f, h1, wave, lane);
-    __syncthreads();
-    for (int e = tid; e < NS * D1; e += 256) {                    // ReLU + Dropout(0.5) (keep mask given; eval: m1 == null)
-        const int s = e / D1, i = e % D1, n = n0 + s;
-        float v = fmaxf(h1[s][i], 0.f);
-        if (m1 && n < N) v *= m1[(size_t)n * D1 + i] ? 2.f : 0.f;
-        h1[s][i] = v;
-        if (n < N) h1g[(size_t)n * D1 + i] = v;
+    {   // Linear(512,256) + ReLU + Dropout(0.5) (keep mask given; eval: m1 == null): thread = output neuron
+        const int o = tid;
+        float acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = b1[o];
+#pragma unroll 8
+        for (int i = 0; i < D0; ++i) {
+            const float wv = w1t[i * D1 + o];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] += wv * f[s][i];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int n = n0 + s;
+            float v = fmaxf(acc[s], 0.f);
+            if (m1 && n < N) v *= m1[(size_t)n * D1 + o] ? 2.f : 0.f;
+            h1[s][o] = v;
+            if (n < N) h1g[(size_t)n * D1 + o] = v;
+        }
     }
     __syncthreads();
-    dense_rows<D1, D2>(w2, b2, h1, h2, wave, lane);
-    __syncthreads();
-    for (int e = tid; e < NS * D2; e += 256) {
-        const int s = e / D2, i = e % D2, n = n0 + s;
-        float v = fmaxf(h2[s][i], 0.f);
-        if (m2 && n < N) v *= m2[(size_t)n * D2 + i] ? 2.f : 0.f;
-        h2[s][i] = v;
-        if (n < N) h2g[(size_t)n * D2 + i] = v;
+    {   // Linear(256,64): 64 outputs x 4 quarters of the inputs, partial sums through LDS
+        const int q = tid >> 6, o = tid & 63;
+        float acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = 0.f;
+#pragma unroll 8
+        for (int i = q * 64; i < q * 64 + 64; ++i) {
+            const float wv = w2t[i * D2 + o];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] += wv * h1[s][i];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) part[q][s][o] = acc[s];
     }
     __syncthreads();
-    dense_rows<D2, D3>(w3, b3, h2, t, wave, lane);
+    {
+        const int s = tid / D2, o = tid % D2, n = n0 + s;
+        float v = fmaxf(b2[o] + part[0][s][o] + part[1][s][o] + part[2][s][o] + part[3][s][o], 0.f);
+        if (m2 && n < N) v *= m2[(size_t)n * D2 + o] ? 2.f : 0.f;
+        h2[s][o] = v;
+        if (n < N) h2g[(size_t)n * D2 + o] = v;
+    }
     __syncthreads();
-    if (tid < NS * D3) {
+    if (tid < NS * D3) {                                             // Linear(64,4) + Tanh, * delta_scale
         const int s = tid / D3, j = tid % D3, n = n0 + s;
+        float v = b3[j];
+        for (int i = 0; i < D2; ++i) v += w3[j * D2 + i] * h2[s][i];
         if (n < N) {
-            const float th = tanhf(t[s][j]);
+            const float th = tanhf(v);
             traw[(size_t)n * D3 + j] = th;
             delta[(size_t)n * D3 + j] = th * delta_scale;
         }
@@ -215,30 +220,40 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_data_kernel(const float* __r
     }
 }
 
-// ---- backward, weights: dW[o][i] = sum_n dp[n][o] in[n][i], db[o] = sum_n dp[n][o]; one thread per element of the
-// three weight matrices and biases (flattened), the batch walked serially (coalesced along i).
+// ---- backward, weights: dW[o][i] = sum_n dp[n][o] in[n][i], db[o] = sum_n dp[n][o].  One thread = four output rows
+// of one input column (the input value is loaded once for four FMAs, the four dp values are one 16-byte broadcast load);
+// the batch is walked serially, coalesced along i.
 __global__ __launch_bounds__(256) void mlp_head_wgrad_kernel(const float* __restrict__ feat, const float* __restrict__ h1g,
         const float* __restrict__ h2g, const float* __restrict__ dp1, const float* __restrict__ dp2, const float* __restrict__ dp3,
         float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
         float* __restrict__ dw3, float* __restrict__ db3, int N) {
-    constexpr int E1 = D1 * D0, E2 = D2 * D1, E3 = D3 * D2, EW = E1 + E2 + E3, EB = D1 + D2 + D3;
+    constexpr int G1 = D1 / 4 * D0, G2 = D2 / 4 * D1, G3 = D3 / 4 * D2, GW = G1 + G2 + G3, EB = D1 + D2 + D3;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= EW + EB) return;
-    const float* dp; const float* in; float* out; int o, i, DO, DI;
-    if (idx < E1) { o = idx / D0; i = idx % D0; dp = dp1; in = feat; out = dw1 + idx; DO = D1; DI = D0; }
-    else if (idx < E1 + E2) { const int e = idx - E1; o = e / D1; i = e % D1; dp = dp2; in = h1g; out = dw2 + e; DO = D2; DI = D1; }
-    else if (idx < EW) { const int e = idx - E1 - E2; o = e / D2; i = e % D2; dp = dp3; in = h2g; out = dw3 + e; DO = D3; DI = D2; }
-    else {
-        int e = idx - EW;
+    if (idx >= GW + EB) return;
+    if (idx >= GW) {
+        int e = idx - GW;
+        const float* dp; float* out; int DO;
         if (e < D1) { dp = dp1; out = db1 + e; DO = D1; }
         else if (e < D1 + D2) { e -= D1; dp = dp2; out = db2 + e; DO = D2; }
         else { e -= D1 + D2; dp = dp3; out = db3 + e; DO = D3; }
-        o = e; i = 0; in = nullptr; DI = 0;
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dp[(size_t)n * DO + e];
+        *out = s;
+        return;
     }
-    float s = 0.f;
-    if (in) { for (int n = 0; n < N; ++n) s += dp[(size_t)n * DO + o] * in[(size_t)n * DI + i]; }
-    else { for (int n = 0; n < N; ++n) s += dp[(size_t)n * DO + o]; }
-    *out = s;
+    const float* dp; const float* in; float* out; int og, i, DO, DI;
+    if (idx < G1) { og = idx / D0; i = idx % D0; dp = dp1; in = feat; out = dw1; DO = D1; DI = D0; }
+    else if (idx < G1 + G2) { const int e = idx - G1; og = e / D1; i = e % D1; dp = dp2; in = h1g; out = dw2; DO = D2; DI = D1; }
+    else { const int e = idx - G1 - G2; og = e / D2; i = e % D2; dp = dp3; in = h2g; out = dw3; DO = D3; DI = D2; }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+    for (int n = 0; n < N; ++n) {
+        const float x = in[(size_t)n * DI + i];
+        const float4 d = *reinterpret_cast<const float4*>(dp + (size_t)n * DO + 4 * og);
+        s0 += d.x * x; s1 += d.y * x; s2 += d.z * x; s3 += d.w * x;
+    }
+    float* o = out + (size_t)(4 * og) * DI + i;
+    o[0] = s0; o[DI] = s1; o[2 * DI] = s2; o[3 * DI] = s3;
 }
 
 unsigned grid_for(size_t total) {
@@ -294,13 +309,15 @@ int gcssl_avgpool_fwd(int dtype, const void* x, int ldx, float* feat, int N, int
 }
 
 /* regressor head (models.py:200-216): feat [N][512] -> h1 [N][256], h2 [N][64] (post ReLU+Dropout), traw = tanh [N][4],
- * delta = traw * delta_scale.  m1 [N][256] / m2 [N][64]: Dropout keep masks (bytes), both NULL in eval mode. */
-int gcssl_mlp_head_fwd(const float* feat, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+ * delta = traw * delta_scale.  w1t [512][256] and w2t [256][64] are the TRANSPOSES of the nn.Linear weights (coalesced
+ * reads with one thread per output neuron); w3 [4][64] is plain.  m1 [N][256] / m2 [N][64]: Dropout keep masks (bytes),
+ * both NULL in eval mode. */
+int gcssl_mlp_head_fwd(const float* feat, const float* w1t, const float* b1, const float* w2t, const float* b2, const float* w3,
                        const float* b3, const uint8_t* m1, const uint8_t* m2, float delta_scale, float* h1, float* h2,
                        float* traw, float* delta, int N, void* stream) {
-    if (!feat || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !h1 || !h2 || !traw || !delta) return GCSSL_ENULL;
+    if (!feat || !w1t || !b1 || !w2t || !b2 || !w3 || !b3 || !h1 || !h2 || !traw || !delta) return GCSSL_ENULL;
     if (N <= 0 || (!m1) != (!m2)) return GCSSL_EBADSHAPE;
-    hipLaunchKernelGGL(mlp_head_fwd_kernel, dim3((N + NS - 1) / NS), dim3(256), 0, (hipStream_t)stream, feat, w1, b1, w2, b2, w3, b3,
+    hipLaunchKernelGGL(mlp_head_fwd_kernel, dim3((N + NS - 1) / NS), dim3(256), 0, (hipStream_t)stream, feat, w1t, b1, w2t, b2, w3, b3,
                        m1, m2, delta_scale, h1, h2, traw, delta, N);
     return gcssl_launch_status();
 }
@@ -317,7 +334,7 @@ int gcssl_mlp_head_bwd(const float* gdelta, const float* traw, const float* h1, 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(mlp_head_bwd_data_kernel, dim3((N + NS - 1) / NS), dim3(256), 0, st, gdelta, traw, h1, h2, w1, w2, w3,
                        delta_scale, train ? 2.f : 1.f, dp1, dp2, dp3, dfeat, N);
-    constexpr int total = D1 * D0 + D2 * D1 + D3 * D2 + D1 + D2 + D3;
+    constexpr int total = (D1 * D0 + D2 * D1 + D3 * D2) / 4 + D1 + D2 + D3;
     hipLaunchKernelGGL(mlp_head_wgrad_kernel, dim3((total + 255) / 256), dim3(256), 0, st, feat, h1, h2, dp1, dp2, dp3, dw1, db1,
                        dw2, db2, dw3, db3, N);
     return gcssl_launch_status();

@@ -64,6 +64,7 @@ class SimpleGenerator:
         self.dfeat = torch.empty(B, 512, **f32)
         self.maskbuf = torch.empty(B * (256 + 64), device=dev, dtype=torch.uint8)       # one launch draws both
         self.masks = [self.maskbuf[:B * 256].view(B, 256), self.maskbuf[B * 256:].view(B, 64)]
+        self.w1t, self.w2t = torch.empty(512, 256, **f32), torch.empty(256, 64, **f32)   # transposed head weights (forward)
         self._prep = self._red = None
 
     # ---------------------------------------------------------------------------------------------- weights
@@ -78,6 +79,8 @@ class SimpleGenerator:
             self._prep = ops.Prep3Batch([(V[self._w(j)[0]], self.wf[j], self.wt[j], cout, cin, self.cinp[j])
                                          for j, (cin, cout) in enumerate(GS_CONV)], self.eng.code)
         self._prep.run()
+        self.w1t.copy_(self.eng.G.views["regressor.2.weight"].t())
+        self.w2t.copy_(self.eng.G.views["regressor.5.weight"].t())
 
     def set_masks(self, masks: Optional[Sequence[torch.Tensor]], phase: int):
         """The two Dropout(0.5) keep-masks (models.py:205,208): given (fixture / parity mode) or drawn on the device with
@@ -105,7 +108,7 @@ class SimpleGenerator:
                 src = self.a[j]
         ops.avgpool_fwd(self.p[3], self.feat, 512)
         m1, m2 = self.masks if train else (None, None)
-        ops.mlp_head_fwd(self.feat, V["regressor.2.weight"], V["regressor.2.bias"], V["regressor.5.weight"],
+        ops.mlp_head_fwd(self.feat, self.w1t, V["regressor.2.bias"], self.w2t,
                          V["regressor.5.bias"], V["regressor.8.weight"], V["regressor.8.bias"], eng.delta_scale,
                          self.h1, self.h2, eng.g_traw, eng.g_delta, m1=m1, m2=m2)
         return eng.g_delta
@@ -113,8 +116,8 @@ class SimpleGenerator:
     # ---------------------------------------------------------------------------------------------- backward
     def backward(self, gdelta: torch.Tensor):
         """Gradient of the generator loss wrt every parameter, given d loss / d delta (the EIoU kernel's output), written
-        into the engine's flat gradient buffer (plain stores for the weights; the zero-true-gradient conv biases in
-        front of InstanceNorm are summed the way autograd sums them, rounding noise included)."""
+        into the engine's flat gradient buffer (plain stores; the conv biases in front of InstanceNorm keep the exact
+        zero gradient they have analytically)."""
         eng, B = self.eng, self.eng.B
         V, gW = eng.G.views, eng.G.gviews
         ops.mlp_head_bwd(gdelta, eng.g_traw, self.h1, self.h2, self.feat, V["regressor.2.weight"], V["regressor.5.weight"],
@@ -128,8 +131,9 @@ class SimpleGenerator:
                 ops.maxpool2_bwd(self.a[7], self.dfeat, self.da[7], cout, bcast_scale=1.0 / ((r // 2) * (r // 2)))
             elif j & 1:
                 ops.maxpool2_bwd(self.a[j], self.dp[j // 2], self.da[j], cout)
-            ops.in_act_bwd(self.z[j], self.mean[j], self.rstd[j], self.dz[j], cout, RELU, da=self.da[j],
-                           dbias=gW[self._w(j)[1]], ws=eng.ws)
+            # (no dbias: the conv bias sits in front of InstanceNorm, its true gradient is exactly zero -- sum_p dz = 0 --
+            #  and the engine leaves it at the zero the gradient buffer was cleared to; autograd's value is rounding noise)
+            ops.in_act_bwd(self.z[j], self.mean[j], self.rstd[j], self.dz[j], cout, RELU, da=self.da[j], ws=eng.ws)
             src = self.x8 if j == 0 else (self.p[j // 2 - 1] if not (j & 1) else self.a[j - 1])
             fl = conv3_flops(B, r, cin, cout)
             eng._conv(f"GS.c{j + 1}.wgrad", fl, ops.conv3_wgrad, src, self.dz[j], self.slab[j], self.cinp[j], cout)

@@ -372,8 +372,10 @@ def avgpool_fwd(x, feat, C):
     call("gcssl_avgpool_fwd", code(x), x, _ld(x), feat, N, H * W, C)
 
 
-def mlp_head_fwd(feat, w1, b1, w2, b2, w3, b3, delta_scale, h1, h2, traw, delta, m1=None, m2=None):
-    call("gcssl_mlp_head_fwd", feat, w1, b1, w2, b2, w3, b3, m1, m2, float(delta_scale), h1, h2, traw, delta, feat.shape[0])
+def mlp_head_fwd(feat, w1t, b1, w2t, b2, w3, b3, delta_scale, h1, h2, traw, delta, m1=None, m2=None):
+    """w1t [512][256], w2t [256][64]: transposed nn.Linear weights (contiguous); w3 [4][64] plain."""
+    assert w1t.shape == (512, 256) and w2t.shape == (256, 64) and w1t.is_contiguous() and w2t.is_contiguous()
+    call("gcssl_mlp_head_fwd", feat, w1t, b1, w2t, b2, w3, b3, m1, m2, float(delta_scale), h1, h2, traw, delta, feat.shape[0])
 
 
 def mlp_head_bwd(gdelta, traw, h1, h2, feat, w1, w2, w3, delta_scale, train, dp1, dp2, dp3, dfeat, dw1, db1, dw2, db2, dw3, db3):

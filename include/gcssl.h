@@ -240,9 +240,10 @@ int gcssl_maxpool2_bwd(int dtype, const void* a, int lda, const float* dpool, in
 /* nn.AdaptiveAvgPool2d(1) + Flatten (models.py:201-202): feat[N][C] fp32 */
 int gcssl_avgpool_fwd(int dtype, const void* x, int ldx, float* feat, int N, int HW, int C, void* stream);
 /* regressor (models.py:203-216): Linear(512,256)+ReLU+Dropout, Linear(256,64)+ReLU+Dropout, Linear(64,4), Tanh, * delta_scale.
- * m1 [N][256], m2 [N][64]: Dropout(0.5) keep masks (bytes), both NULL in eval mode.  h1/h2: post-dropout activations kept
- * for the backward; traw = tanh output. */
-int gcssl_mlp_head_fwd(const float* feat, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+ * The forward takes the first two weights TRANSPOSED (w1t [512][256], w2t [256][64]: one thread per output neuron,
+ * coalesced rows), the backward the nn.Linear layouts.  m1 [N][256], m2 [N][64]: Dropout(0.5) keep masks (bytes), both
+ * NULL in eval mode.  h1/h2: post-dropout activations kept for the backward; traw = tanh output. */
+int gcssl_mlp_head_fwd(const float* feat, const float* w1t, const float* b1, const float* w2t, const float* b2, const float* w3,
                        const float* b3, const uint8_t* m1, const uint8_t* m2, float delta_scale, float* h1, float* h2,
                        float* traw, float* delta, int N, void* stream);
 int gcssl_mlp_head_bwd(const float* gdelta, const float* traw, const float* h1, const float* h2, const float* feat,

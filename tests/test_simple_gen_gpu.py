@@ -121,7 +121,8 @@ def test_regressor_head_forward_backward(ops, train):
     dev = lambda x: x.detach().cuda()
     H1, H2 = torch.empty(N, 256, device="cuda"), torch.empty(N, 64, device="cuda")
     T, D = torch.empty(N, 4, device="cuda"), torch.empty(N, 4, device="cuda")
-    ops.mlp_head_fwd(dev(feat), dev(w1), dev(b1), dev(w2), dev(b2), dev(w3), dev(b3), scale, H1, H2, T, D,
+    ops.mlp_head_fwd(dev(feat), dev(w1).t().contiguous(), dev(b1), dev(w2).t().contiguous(), dev(b2), dev(w3), dev(b3), scale,
+                     H1, H2, T, D,
                      m1=m1.cuda() if train else None, m2=m2.cuda() if train else None)
     assert rel_err(D.cpu(), delta.detach()) < 1e-5 and rel_err(T.cpu(), t.detach()) < 1e-5
     dp1, dp2, dp3 = torch.empty(N, 256, device="cuda"), torch.empty(N, 64, device="cuda"), torch.empty(N, 4, device="cuda")
