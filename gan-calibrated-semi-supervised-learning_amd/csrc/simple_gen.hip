@@ -84,57 +84,67 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, i
 // once per optimiser step): thread o walks the inputs, a wave reads 256-byte runs of each row and the NS activations come
 // from LDS broadcasts -- no cross-lane reduction.  (The first version gave a wave one output at a time and reduced over
 // its lanes: 64 dependent global-load round trips per wave, 88 us per launch at B = 256.)
-__global__ __launch_bounds__(256) void mlp_head_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w1t,
+__global__ __launch_bounds__(1024) void mlp_head_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w1t,
         const float* __restrict__ b1, const float* __restrict__ w2t, const float* __restrict__ b2, const float* __restrict__ w3,
         const float* __restrict__ b3, const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2, float delta_scale,
         float* __restrict__ h1g, float* __restrict__ h2g, float* __restrict__ traw, float* __restrict__ delta, int N) {
-    __shared__ float f[NS][D0], h1[NS][D1], part[4][NS][D2], h2[NS][D2];
-    static_assert(D1 == 256 && NS * D2 == 256, "thread mapping below assumes 256 threads = D1 = NS * D2");
+    // 1024 threads: every layer splits its input range over 4 (16) thread groups and adds the partial sums through LDS --
+    // a thread's serial chain of L2 round trips is what bounds this kernel (64 workgroups for a batch of 256)
+    __shared__ float f[NS][D0], h1[NS][D1], h2[NS][D2], part[16 * NS * D2];
+    static_assert(4 * NS * D1 <= 16 * NS * D2 && D1 == 256 && D2 == 64 && NS * D1 == 1024, "thread mappings below");
     const int tid = threadIdx.x, n0 = blockIdx.x * NS;
-    for (int e = tid; e < NS * D0; e += 256) {
+    for (int e = tid; e < NS * D0; e += 1024) {
         const int s = e / D0, i = e % D0;
         f[s][i] = n0 + s < N ? feat[(size_t)(n0 + s) * D0 + i] : 0.f;
     }
     __syncthreads();
-    {   // Linear(512,256) + ReLU + Dropout(0.5) (keep mask given; eval: m1 == null): thread = output neuron
-        const int o = tid;
+    {   // Linear(512,256): 256 outputs x 4 quarters of the inputs
+        const int q = tid >> 8, o = tid & 255;
         float acc[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] = b1[o];
+        for (int s = 0; s < NS; ++s) acc[s] = 0.f;
 #pragma unroll 8
-        for (int i = 0; i < D0; ++i) {
+        for (int i = q * (D0 / 4); i < (q + 1) * (D0 / 4); ++i) {
             const float wv = w1t[i * D1 + o];
 #pragma unroll
             for (int s = 0; s < NS; ++s) acc[s] += wv * f[s][i];
         }
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int n = n0 + s;
-            float v = fmaxf(acc[s], 0.f);
-            if (m1 && n < N) v *= m1[(size_t)n * D1 + o] ? 2.f : 0.f;
-            h1[s][o] = v;
-            if (n < N) h1g[(size_t)n * D1 + o] = v;
-        }
+        for (int s = 0; s < NS; ++s) part[(q * NS + s) * D1 + o] = acc[s];
     }
     __syncthreads();
-    {   // Linear(256,64): 64 outputs x 4 quarters of the inputs, partial sums through LDS
+    {   // + bias, ReLU, Dropout(0.5) (keep mask given; eval: m1 == null): thread = (sample, neuron)
+        const int s = tid >> 8, o = tid & 255, n = n0 + s;
+        float v = b1[o];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v += part[(q * NS + s) * D1 + o];
+        v = fmaxf(v, 0.f);
+        if (m1 && n < N) v *= m1[(size_t)n * D1 + o] ? 2.f : 0.f;
+        h1[s][o] = v;
+        if (n < N) h1g[(size_t)n * D1 + o] = v;
+    }
+    __syncthreads();
+    {   // Linear(256,64): 64 outputs x 16 slices of the inputs
         const int q = tid >> 6, o = tid & 63;
         float acc[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[s] = 0.f;
-#pragma unroll 8
-        for (int i = q * 64; i < q * 64 + 64; ++i) {
+#pragma unroll
+        for (int i = q * (D1 / 16); i < (q + 1) * (D1 / 16); ++i) {
             const float wv = w2t[i * D2 + o];
 #pragma unroll
             for (int s = 0; s < NS; ++s) acc[s] += wv * h1[s][i];
         }
 #pragma unroll
-        for (int s = 0; s < NS; ++s) part[q][s][o] = acc[s];
+        for (int s = 0; s < NS; ++s) part[(q * NS + s) * D2 + o] = acc[s];
     }
     __syncthreads();
-    {
+    if (tid < NS * D2) {
         const int s = tid / D2, o = tid % D2, n = n0 + s;
-        float v = fmaxf(b2[o] + part[0][s][o] + part[1][s][o] + part[2][s][o] + part[3][s][o], 0.f);
+        float v = b2[o];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += part[(q * NS + s) * D2 + o];
+        v = fmaxf(v, 0.f);
         if (m2 && n < N) v *= m2[(size_t)n * D2 + o] ? 2.f : 0.f;
         h2[s][o] = v;
         if (n < N) h2g[(size_t)n * D2 + o] = v;
@@ -317,7 +327,7 @@ int gcssl_mlp_head_fwd(const float* feat, const float* w1t, const float* b1, con
                        float* traw, float* delta, int N, void* stream) {
     if (!feat || !w1t || !b1 || !w2t || !b2 || !w3 || !b3 || !h1 || !h2 || !traw || !delta) return GCSSL_ENULL;
     if (N <= 0 || (!m1) != (!m2)) return GCSSL_EBADSHAPE;
-    hipLaunchKernelGGL(mlp_head_fwd_kernel, dim3((N + NS - 1) / NS), dim3(256), 0, (hipStream_t)stream, feat, w1t, b1, w2t, b2, w3, b3,
+    hipLaunchKernelGGL(mlp_head_fwd_kernel, dim3((N + NS - 1) / NS), dim3(1024), 0, (hipStream_t)stream, feat, w1t, b1, w2t, b2, w3, b3,
                        m1, m2, delta_scale, h1, h2, traw, delta, N);
     return gcssl_launch_status();
 }
