@@ -450,8 +450,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     const int ks = p.ksplit > 1 ? (MODE == 1 ? (int)blockIdx.z % p.ksplit : (int)blockIdx.z) : 0;
     const int py = cls >> 1, px = cls & 1;
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
-    const int Ho = p.Hi >> 1, Wo = p.Wi >> 1;
-    const int K = MODE == 0 ? 16 * p.Cin : 4 * p.Cout;
+    const int Ho = MODE == 2 ? p.Hi : p.Hi >> 1, Wo = MODE == 2 ? p.Wi : p.Wi >> 1;
+    const int K = MODE == 0 ? 16 * p.Cin : MODE == 2 ? p.wk : 4 * p.Cout;
     const int row_t = tid / CH;
     const int lc = (tid % CH) ^ ((row_t >> 1) & 7);                        // logical chunk this lane fetches
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
@@ -470,6 +470,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
                     if ((unsigned)(iy0 + (t >> 2)) < (unsigned)p.Hi && (unsigned)(ix0 + (t & 3)) < (unsigned)p.Wi) mk |= 1u << t;
+            } else if (MODE == 2) {                                        // 3x3 stride 1 pad 1 (Geo<3>): taps 0..8
+                const int iy0 = (rem >> p.lgWo) - 1, ix0 = (rem & (Wo - 1)) - 1;
+                rowoff[i] = ((n * p.Hi + iy0) * p.Wi + ix0) * p.ldx * ES;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    if ((unsigned)(iy0 + Geo<3>::ky(t)) < (unsigned)p.Hi && (unsigned)(ix0 + Geo<3>::kx(t)) < (unsigned)p.Wi) mk |= 1u << t;
             } else {
                 const int yy = (rem >> p.lgWo) + py, xx = (rem & (Wo - 1)) + px;
                 rowoff[i] = ((n * Ho + yy) * Wo + xx) * p.ldx * ES;
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 #pragma unroll
     for (int j = 0; j < NVB; ++j) {
         const int r = n0 + row_t + j * RPT;
-        if (MODE == 0) wrow[j] = r < p.Cout ? (unsigned)(r * K * ES) : OOB;
+        if (MODE != 1) wrow[j] = r < p.Cout ? (unsigned)(r * K * ES) : OOB;
         else wrow[j] = r < p.Cin ? (unsigned)(r * 16 * p.Cout * ES) : OOB;
         if (!SMALLK && wrow[j] != OOB) wrow[j] += lc * KV * ES;
     }
@@ -499,6 +505,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
         if (MODE == 0) {
             const int tap = kb >> p.lgCin, ci = kb & (p.Cin - 1);
             tapbit = tap; tapoff = (((tap >> 2) * p.Wi + (tap & 3)) * p.ldx + ci) * ES; woff = (unsigned)(kb * ES);
+        } else if (MODE == 2) {
+            const int tap = kb >> p.lgCin, ci = kb & (p.Cin - 1);
+            tapbit = tap; tapoff = ((Geo<3>::ky(tap) * p.Wi + Geo<3>::kx(tap)) * p.ldx + ci) * ES; woff = (unsigned)(kb * ES);
         } else {
             const int t4 = kb >> p.lgCout, co = kb & (p.Cout - 1);
             const int ty = t4 >> 1, tx = t4 & 1;
@@ -563,12 +572,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     // 16-32 dependent load -> store round trips per wave (measured with s_memtime: a third of the workgroup's life).
     float* y32 = static_cast<float*>(p.y);
     T* yt = static_cast<T*>(p.y);
-    const int ncols = MODE == 0 ? p.Cout : p.Cin;
+    const int ncols = MODE != 1 ? p.Cout : p.Cin;
     float bcol[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn0 + 32 * j + (lane & 31);
-        bcol[j] = (MODE == 0 && p.bias && col < ncols && (p.ksplit <= 1 || ks == 0)) ? p.bias[col] : 0.f;
+        bcol[j] = (MODE != 1 && p.bias && col < ncols && (p.ksplit <= 1 || ks == 0)) ? p.bias[col] : 0.f;
     }
     float sc[TM][16];
 #pragma unroll
@@ -1611,6 +1620,15 @@ int gcssl_conv3x3_fwd(int dtype, const void* x, int ldx, const void* w, const fl
     hipStream_t st = (hipStream_t)stream;
     const bool big = (long)((p.M + 127) / 128) * (Cout / 64) >= 256;
     dim3 grid((p.M + (big ? 127 : 63)) / (big ? 128 : 64), Cout / 64, 1);
+    static const bool dma3 = [] { const char* e = getenv("GCSSL_CONV3_DMA"); return !(e && e[0] == '0'); }();   // A/B knob
+    if (dtype == GCSSL_BF16 && use_dma() && dma3) {            // LDS-DMA pipeline (MODE 2 of conv_dma_kernel)
+        if (Cin < 64) {                                        // 8-channel first layer: a K tile spans several taps
+            if (big) hipLaunchKernelGGL((conv_dma_kernel<128, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv_dma_kernel<64, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p);
+        } else if (big) hipLaunchKernelGGL((conv_dma_kernel<128, 64, 2, 4, 2, false>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((conv_dma_kernel<64, 64, 2, 2, 2, false>), grid, dim3(256), 0, st, p);
+        return gcssl_launch_status();
+    }
 #define C3(T, BM) hipLaunchKernelGGL((conv_fwd_kernel<T, BM, 64, 3>), grid, dim3(NT), 0, st, p)
     if (dtype == GCSSL_F32) { if (big) C3(float, 128); else C3(float, 64); }
     else { if (big) C3(bf16_t, 128); else C3(bf16_t, 64); }

@@ -72,7 +72,7 @@ def test_two_rank_iteration_matches_single_process(tmp_path):
     assert np.abs(a["u"] - b["u"]).max() < 1e-5
 
 
-def _run_graphed(rank, world, port, out_dir):
+def _run_graphed(rank, world, port, gtype):
     """The graphed data-parallel path (all-reduces started early and finished behind independent launches) against the
     eager one on the same ranks: same device-side mask / alpha draws, same collectives, so the weights must agree."""
     import importlib
@@ -85,14 +85,16 @@ def _run_graphed(rank, world, port, out_dir):
     dist_mod.init_from_env()
     T = torch.from_numpy
     seed, B, S, c = 23, 8, 32, 2
-    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+    gtype = gtype or "unet"
+    g = {k: T(v) for k, v in (synth.simple_generator_state(seed) if gtype == "simple" else synth.generator_state(seed)).items()}
     d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
-    inp = synth.step_inputs(seed, B, S, c, tag="dpgraph")
+    inp = synth.step_inputs(seed, B, S, c, tag="dpgraph", generator_type=gtype)
     sh = lambda a: dist_mod.shard(T(a), rank, world).contiguous().cuda()
     refined = [sh(x) for x in inp["refined"]]
     call = (sh(inp["pred"]), sh(inp["gt"]), sh(inp["delta_true"]), sh(inp["pred_box"]), lambda delta, k: refined[k])
     mk = lambda: engine.StepEngine(g, d, batch=B // world, size=S, n_critic=c, dtype="fp32", device="cuda:0",
-                                   seed=77 + rank, allreduce=dist_mod.GradAverager(), keep_clipped_grads=False)
+                                   seed=77 + rank, allreduce=dist_mod.GradAverager(), keep_clipped_grads=False,
+                                   generator_type=gtype)
     eager, graphed = mk(), mk()
     for _ in range(2):
         eager.run_iteration(*call)
@@ -110,5 +112,6 @@ def _run_graphed(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_graphed_overlapped_allreduce_matches_eager():
-    mp.spawn(_run_graphed, args=(2, _free_port(), ""), nprocs=2, join=True)
+@pytest.mark.parametrize("gtype", ["unet", "simple"])
+def test_graphed_overlapped_allreduce_matches_eager(gtype):
+    mp.spawn(_run_graphed, args=(2, _free_port(), gtype), nprocs=2, join=True)

@@ -49,5 +49,9 @@ def test_models_expose_reference_state_dict_keys(synth):
         assert tuple(D.state_dict()[k].shape) == v.shape, k
     for k, v in synth.generator_state(1).items():
         assert tuple(G.state_dict()[k].shape) == v.shape, k
+    GS = M.GeneratorSimpleRegressor()                                # generator_type "simple" (cgan/models.py:147-216)
+    assert [k for k, _ in GS.named_parameters()] == list(synth.simple_generator_state(1))
+    for k, v in synth.simple_generator_state(1).items():
+        assert tuple(GS.state_dict()[k].shape) == v.shape, k
     D2 = M.Discriminator(spectral_norm=False)
     assert "model.0.weight" in D2.state_dict() and "model.0.weight_orig" not in D2.state_dict()
