@@ -1049,13 +1049,18 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_batch_kernel(Red3Batch b) {
     const int ci0 = (local % nch) * 64, co = local / nch;
     const int cw = min(64, L.Cin - ci0), cr = min(cw, L.Cin_real - ci0);
     const size_t total = (size_t)L.Cout * 16 * L.Cin;
-    for (int e = threadIdx.x; e < 9 * 64; e += 256) {
-        const int tap = e >> 6, cil = e & 63;
-        if (cil >= cw) continue;
-        const size_t idx = ((size_t)co * 16 + tap) * L.Cin + ci0 + cil;
-        float sum = 0.f;
-        for (int k = 0; k < L.nsplit; ++k) sum += L.slab[(size_t)k * total + idx];
-        tile[tap][cil] = sum;
+    if (threadIdx.x < 9 * 16) {                                  // 16-byte loads: thread -> (tap, 4 consecutive ci)
+        const int tap = threadIdx.x >> 4, cil = (threadIdx.x & 15) * 4;
+        if (cil < cw) {
+            const float* src = L.slab + ((size_t)co * 16 + tap) * L.Cin + ci0 + cil;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int k = 0; k < L.nsplit; ++k) {
+                const float4 t = *reinterpret_cast<const float4*>(src + (size_t)k * total);
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            tile[tap][cil] = s.x; tile[tap][cil + 1] = s.y; tile[tap][cil + 2] = s.z; tile[tap][cil + 3] = s.w;
+        }
     }
     __syncthreads();
     float* out = L.dw + ((size_t)co * L.Cin_real + ci0) * 9;
@@ -1642,7 +1647,8 @@ int gcssl_conv3x3_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
     const int bm = Cout >= 128 ? 128 : 64, bn = Cin >= 128 ? 128 : (Cin >= 64 ? 64 : 8);
     const long tiles = Cin == 8 ? Cout / bm : (long)(Cout / bm) * 9 * (Cin / bn);
     const int nkt = (N * H * W + 63) / 64;
-    long want = (512 + tiles - 1) / tiles;
+    static const long target = [] { const char* e = getenv("GCSSL_WGRAD3_WGS"); return e ? atol(e) : 512L; }();
+    long want = (target + tiles - 1) / tiles;
     if (want > 128) want = 128;
     if (want > nkt) want = nkt;
     int per = (nkt + (int)want - 1) / (int)want;

@@ -88,29 +88,29 @@ __global__ __launch_bounds__(1024) void mlp_head_fwd_kernel(const float* __restr
         const float* __restrict__ b1, const float* __restrict__ w2t, const float* __restrict__ b2, const float* __restrict__ w3,
         const float* __restrict__ b3, const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2, float delta_scale,
         float* __restrict__ h1g, float* __restrict__ h2g, float* __restrict__ traw, float* __restrict__ delta, int N) {
-    // 1024 threads: every layer splits its input range over 4 (16) thread groups and adds the partial sums through LDS --
-    // a thread's serial chain of L2 round trips is what bounds this kernel (64 workgroups for a batch of 256)
-    __shared__ float f[NS][D0], h1[NS][D1], h2[NS][D2], part[16 * NS * D2];
-    static_assert(4 * NS * D1 <= 16 * NS * D2 && D1 == 256 && D2 == 64 && NS * D1 == 1024, "thread mappings below");
+    // 1024 threads: every layer splits its input range over 4 (16) thread groups and adds the partial sums through LDS.
+    // Activations sit in LDS as [input][sample] so one 16-byte broadcast read feeds the NS = 4 FMAs of a weight: with one
+    // 4-byte read per (input, sample) the kernel was bound by LDS instruction issue, not by the weight reads.
+    __shared__ float4 f[D0], h1[D1];
+    __shared__ float h2[NS][D2], part[16 * NS * D2];
+    static_assert(NS == 4 && 4 * NS * D1 <= 16 * NS * D2 && D1 == 256 && D2 == 64 && NS * D1 == 1024, "thread mappings below");
     const int tid = threadIdx.x, n0 = blockIdx.x * NS;
     for (int e = tid; e < NS * D0; e += 1024) {
         const int s = e / D0, i = e % D0;
-        f[s][i] = n0 + s < N ? feat[(size_t)(n0 + s) * D0 + i] : 0.f;
+        reinterpret_cast<float*>(&f[i])[s] = n0 + s < N ? feat[(size_t)(n0 + s) * D0 + i] : 0.f;
     }
     __syncthreads();
     {   // Linear(512,256): 256 outputs x 4 quarters of the inputs
         const int q = tid >> 8, o = tid & 255;
-        float acc[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
         for (int i = q * (D0 / 4); i < (q + 1) * (D0 / 4); ++i) {
             const float wv = w1t[i * D1 + o];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[s] += wv * f[s][i];
+            const float4 x = f[i];
+            acc.x += wv * x.x; acc.y += wv * x.y; acc.z += wv * x.z; acc.w += wv * x.w;
         }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) part[(q * NS + s) * D1 + o] = acc[s];
+        part[(q * NS + 0) * D1 + o] = acc.x; part[(q * NS + 1) * D1 + o] = acc.y;
+        part[(q * NS + 2) * D1 + o] = acc.z; part[(q * NS + 3) * D1 + o] = acc.w;
     }
     __syncthreads();
     {   // + bias, ReLU, Dropout(0.5) (keep mask given; eval: m1 == null): thread = (sample, neuron)
@@ -120,23 +120,21 @@ __global__ __launch_bounds__(1024) void mlp_head_fwd_kernel(const float* __restr
         for (int q = 0; q < 4; ++q) v += part[(q * NS + s) * D1 + o];
         v = fmaxf(v, 0.f);
         if (m1 && n < N) v *= m1[(size_t)n * D1 + o] ? 2.f : 0.f;
-        h1[s][o] = v;
+        reinterpret_cast<float*>(&h1[o])[s] = v;
         if (n < N) h1g[(size_t)n * D1 + o] = v;
     }
     __syncthreads();
     {   // Linear(256,64): 64 outputs x 16 slices of the inputs
         const int q = tid >> 6, o = tid & 63;
-        float acc[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = q * (D1 / 16); i < (q + 1) * (D1 / 16); ++i) {
             const float wv = w2t[i * D2 + o];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[s] += wv * h1[s][i];
+            const float4 x = h1[i];
+            acc.x += wv * x.x; acc.y += wv * x.y; acc.z += wv * x.z; acc.w += wv * x.w;
         }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) part[(q * NS + s) * D2 + o] = acc[s];
+        part[(q * NS + 0) * D2 + o] = acc.x; part[(q * NS + 1) * D2 + o] = acc.y;
+        part[(q * NS + 2) * D2 + o] = acc.z; part[(q * NS + 3) * D2 + o] = acc.w;
     }
     __syncthreads();
     if (tid < NS * D2) {
