@@ -742,10 +742,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
-    const int Ho = p.Hi >> 1, Wo = p.Wi >> 1;
-    const int K = MODE == 0 ? 16 * p.Cin : 4 * p.Cout;
+    const int Ho = MODE == 2 ? p.Hi : p.Hi >> 1, Wo = MODE == 2 ? p.Wi : p.Wi >> 1;
+    const int K = MODE == 0 ? 16 * p.Cin : MODE == 2 ? p.wk : 4 * p.Cout;
     const int nk = K / BK;
-    const int ncols = MODE == 0 ? p.Cout : p.Cin;
+    const int ncols = MODE != 1 ? p.Cout : p.Cin;
     const int row_t = tid / CH;
     const int lc = (tid % CH) ^ ((row_t >> 1) & 7);
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes), yr = make_rsrc(p.y, p.y_bytes);
@@ -768,6 +768,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
 #pragma unroll
                     for (int t = 0; t < 16; ++t)
                         if ((unsigned)(iy0 + (t >> 2)) < (unsigned)p.Hi && (unsigned)(ix0 + (t & 3)) < (unsigned)p.Wi) mk |= 1u << t;
+                } else if (MODE == 2) {                                    // 3x3 stride 1 pad 1 (Geo<3>)
+                    const int iy0 = (rem >> p.lgWo) - 1, ix0 = (rem & (Wo - 1)) - 1;
+                    a.rowoff[i] = ((n * p.Hi + iy0) * p.Wi + ix0) * p.ldx * ES;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        if ((unsigned)(iy0 + Geo<3>::ky(t)) < (unsigned)p.Hi && (unsigned)(ix0 + Geo<3>::kx(t)) < (unsigned)p.Wi) mk |= 1u << t;
                 } else {
                     const int yy = (rem >> p.lgWo) + a.py, xx = (rem & (Wo - 1)) + a.px;
                     a.rowoff[i] = ((n * Ho + yy) * Wo + xx) * p.ldx * ES;
@@ -782,7 +788,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
 #pragma unroll
         for (int j = 0; j < NVB; ++j) {
             const int r = a.n0 + row_t + j * RPT;
-            if (MODE == 0) a.wrow[j] = r < p.Cout ? (unsigned)(r * K * ES) : OOB;
+            if (MODE != 1) a.wrow[j] = r < p.Cout ? (unsigned)(r * K * ES) : OOB;
             else a.wrow[j] = r < p.Cin ? (unsigned)(r * 16 * p.Cout * ES) : OOB;
             if (!SMALLK && a.wrow[j] != OOB) a.wrow[j] += lc * KV * ES;
         }
@@ -795,6 +801,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
         if (MODE == 0) {
             const int tap = kb >> p.lgCin, ci = kb & (p.Cin - 1);
             tapbit = tap; tapoff = (((tap >> 2) * p.Wi + (tap & 3)) * p.ldx + ci) * ES; woff = (unsigned)(kb * ES);
+        } else if (MODE == 2) {
+            const int tap = kb >> p.lgCin, ci = kb & (p.Cin - 1);
+            tapbit = tap; tapoff = ((Geo<3>::ky(tap) * p.Wi + Geo<3>::kx(tap)) * p.ldx + ci) * ES; woff = (unsigned)(kb * ES);
         } else {
             const int t4 = kb >> p.lgCout, co = kb & (p.Cout - 1);
             const int ty = t4 >> 1, tx = t4 & 1;
@@ -866,7 +875,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = cur.n0 + wn0 + 32 * j + (lane & 31);
-            bcol[j] = (MODE == 0 && p.bias && col < ncols) ? p.bias[col] : 0.f;
+            bcol[j] = (MODE != 1 && p.bias && col < ncols) ? p.bias[col] : 0.f;
         }
         float sc[TM][16];
 #pragma unroll
@@ -877,7 +886,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
                 sc[i][r] = 1.f;
                 if (p.gscale && m < p.M) sc[i][r] = p.gscale[(int)(((float)(m >> p.lgHoWo) + 0.5f) * p.inv_group_n)];
             }
-        if (p.gscale || (MODE == 0 && p.bias)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // see note below
+        if (p.gscale || (MODE != 1 && p.bias)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // see note below
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1622,6 +1631,10 @@ int gcssl_conv3x3_fwd(int dtype, const void* x, int ldx, const void* w, const fl
     p.lgWo = ilog2(W); p.lgHoWo = ilog2(H * W); p.lgCin = ilog2(Cin); p.lgCout = ilog2(Cout);
     p.M = N * H * W;
     if (!fill_bytes(p, (size_t)N * H * W * ldx, (size_t)Cout * p.wk, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
+    {   // output extent for the buffer stores of the persistent kernel
+        const size_t yb = (((size_t)N * H * W - 1) * ldy + Cout) * ((out_f32 || kv == 4) ? 4 : 2);
+        p.y_bytes = yb < 0x7FFFFFFFull ? (unsigned)yb : 0u;
+    }
     hipStream_t st = (hipStream_t)stream;
     const bool big = (long)((p.M + 127) / 128) * (Cout / 64) >= 256;
     dim3 grid((p.M + (big ? 127 : 63)) / (big ? 128 : 64), Cout / 64, 1);
@@ -1630,7 +1643,13 @@ int gcssl_conv3x3_fwd(int dtype, const void* x, int ldx, const void* w, const fl
         if (Cin < 64) {                                        // 8-channel first layer: a K tile spans several taps
             if (big) hipLaunchKernelGGL((conv_dma_kernel<128, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((conv_dma_kernel<64, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p);
-        } else if (big) hipLaunchKernelGGL((conv_dma_kernel<128, 64, 2, 4, 2, false>), grid, dim3(512), 0, st, p);
+        } else if (big) {
+            // more tiles than resident workgroups: the persistent form (the DMA ring never drains between tiles)
+            const int slots = cu_count() * ((160 * 1024) / (3 * (128 + 64) * 128)), total = (int)(grid.x * grid.y);
+            if ((persist_mode() & 1) && p.y_bytes && total > slots + slots / 4)
+                hipLaunchKernelGGL((conv_dma_persist_kernel<128, 64, 2, 4, 2>), dim3(slots), dim3(512), 0, st, p, (int)grid.x, (int)grid.y, total);
+            else hipLaunchKernelGGL((conv_dma_kernel<128, 64, 2, 4, 2, false>), grid, dim3(512), 0, st, p);
+        }
         else hipLaunchKernelGGL((conv_dma_kernel<64, 64, 2, 2, 2, false>), grid, dim3(256), 0, st, p);
         return gcssl_launch_status();
     }

@@ -35,6 +35,8 @@ C3_CASES = [  # N, H, Cin(real), CinP, Cout
     (2, 4, 256, 256, 512),
     (70, 32, 64, 64, 64),     # 560 tiles of 128x64 -> the 128-row tile
     (5, 2, 512, 512, 512),    # 2x2 maps (S = 16 ... or the last block at 32x32 is 4x4)
+    (201, 32, 64, 64, 64),    # 1608 tiles (ragged last one) > resident workgroups: the persistent LDS-DMA kernel in bf16
+    (90, 32, 3, 8, 64),       # 720 tiles of the 8-channel first layer
 ]
 
 
