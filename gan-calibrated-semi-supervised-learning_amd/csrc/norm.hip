@@ -327,6 +327,25 @@ __global__ __launch_bounds__(CGN * RGN) void in_apply_kernel(const float* __rest
     }
 }
 
+// An incoming gradient that a K-split conv left as `nslab` partial-sum slabs: this thread's rows (rg, rg+RG, ...) of its
+// 4-channel column are summed into slab 0, which the caller then reads like an ordinary tensor (same thread, same
+// addresses: program order).  Kept OUT of the callers' row loops: a store inside them stops the compiler from hoisting the
+// later rows' loads above it (measured: in_bwd_small 17.7 -> 27.9 us with the fold inline, slabs or not).
+template <int RG, int MR>
+__device__ __forceinline__ void fold_slabs(float* base, int ld, int nslab, long stride, int rg, int HW) {
+    for (int i = 0; i < MR; ++i) {
+        const int p = rg + RG * i;
+        if (p >= HW) break;
+        float t[VC]; ld4(base + (size_t)p * ld, t);
+        for (int k = 1; k < nslab; ++k) {
+            float u[VC]; ld4(base + (size_t)k * stride + (size_t)p * ld, u);
+#pragma unroll
+            for (int j = 0; j < VC; ++j) t[j] += u[j];
+        }
+        st4<float>(base + (size_t)p * ld, t);
+    }
+}
+
 struct InBwdParams {
     const float* da; int ldda;         // incoming gradient of the activation output, fp32 (nullable if da_bcast)
     const float* da2; int ldda2;       // optional second gradient added to da (skip connection), fp32
@@ -346,7 +365,9 @@ struct InBwdParams {
 };
 
 // small maps: fused backward, several samples per pass and several passes per workgroup (see combine_seg)
-template <typename T, int RG, int MR = MAXR>
+// SLAB: the incoming gradient arrives as split-K slabs.  A separate instantiation, because the mere presence of the fold's
+// store (taken or not) cost the plain kernel 17 -> 28 us: the compiler stops overlapping the samples' loads across it.
+template <typename T, int RG, int MR = MAXR, bool SLAB = false>
 __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, int N, int spb, int mixed_groups) {
     __shared__ float sm[2][RGN][CW];
     __shared__ float red[CGN * RGN / 64];
@@ -372,6 +393,8 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
             ld4(q.mean + (size_t)n * C + c, mu); ld4(q.rstd + (size_t)n * C + c, r);
             if (q.da_bcast) ld4(q.da_bcast + (size_t)n * C + c, dab);
         }
+        if (SLAB && dap && live)                                     // split-K slabs of the producing conv
+            fold_slabs<RG, MR>(const_cast<float*>(dap), q.ldda, q.da_nslab, q.da_slab_stride, rg, HW);
         float zv[MR][VC], dn[MR][VC];
         float s[2][VC] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -382,14 +405,6 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
             float d[VC] = {dab[0], dab[1], dab[2], dab[3]};
             if (dap) {
                 float t[VC]; ld4(dap + (size_t)p * q.ldda, t);
-                if (q.da_nslab > 1) {                                  // split-K slabs of the producing conv: add them and
-                    for (int k = 1; k < q.da_nslab; ++k) {             // leave the total in slab 0 for later readers of da
-                        float u[VC]; ld4(dap + (size_t)k * q.da_slab_stride + (size_t)p * q.ldda, u);
-#pragma unroll
-                        for (int j = 0; j < VC; ++j) t[j] += u[j];
-                    }
-                    st4<float>(const_cast<float*>(dap) + (size_t)p * q.ldda, t);
-                }
 #pragma unroll
                 for (int j = 0; j < VC; ++j) d[j] += t[j];
             }
@@ -600,7 +615,7 @@ __global__ __launch_bounds__(CW * RG) void in_dbl_bwd_kernel(InDblParams q) {
 }
 
 // small maps, vectorised double backward (same math as in_dbl_bwd_kernel)
-template <typename T, int RG>
+template <typename T, int RG, bool SLAB = false>
 __global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, int N, int spb) {
     __shared__ float sm[5][RGN][CW];
     __shared__ float red[CGN * RGN / 64];
@@ -620,6 +635,8 @@ __global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, 
         const T* gzp = q.gb_zs ? static_cast<const T*>(q.gb_zs) + (size_t)n * HW * q.ldgz + c : nullptr;
         float mu[VC] = {0.f, 0.f, 0.f, 0.f}, r[VC] = {0.f, 0.f, 0.f, 0.f};
         if (live) { ld4(q.mean + (size_t)n * C + c, mu); ld4(q.rstd + (size_t)n * C + c, r); }
+        if (SLAB && live)                                             // split-K slabs of the producing conv (see fold_slabs)
+            fold_slabs<RG, MAXR>(const_cast<float*>(qp), q.ldq, q.q_nslab, q.q_slab_stride, rg, HW);
         float xh[MAXR][VC], dn[MAXR][VC], qq[MAXR][VC], ag[MAXR][VC];
         float s[5][VC];
 #pragma unroll
@@ -632,11 +649,6 @@ __global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, 
             if (!live || p >= HW) continue;
             float zv[VC], g[VC];
             ld4(zp + (size_t)p * q.ldz, zv); ld4(gp + (size_t)p * q.ldgb, g); ld4(qp + (size_t)p * q.ldq, qq[i]);
-            for (int k = 1; k < q.q_nslab; ++k) {
-                float t[VC]; ld4(qp + (size_t)k * q.q_slab_stride + (size_t)p * q.ldq, t);
-#pragma unroll
-                for (int j = 0; j < VC; ++j) qq[i][j] += t[j];
-            }
             float gz[VC] = {0.f, 0.f, 0.f, 0.f};
             if (gzp) ldT4<T>(gzp + (size_t)p * q.ldgz, gz);
 #pragma unroll
@@ -865,7 +877,8 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, cdot ? q.group_n : 0);
         const int mixed = (cdot && q.group_n % spb) ? 1 : 0;
         dim3 grid(C / CW, (N + spb - 1) / spb);
-#define BWD_SMALL(T, RG, MR) hipLaunchKernelGGL((in_bwd_small_kernel<T, RG, MR>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed)
+#define BWD_SMALL(T, RG, MR) do { if (da_nslab > 1) hipLaunchKernelGGL((in_bwd_small_kernel<T, RG, MR, true>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed); \
+                                  else hipLaunchKernelGGL((in_bwd_small_kernel<T, RG, MR, false>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed); } while (0)
         if (dtype == GCSSL_F32) {
             if (rg == 1) BWD_SMALL(float, 1, MAXR); else if (rg == 4) BWD_SMALL(float, 4, MAXR);
             else if (HW <= SMALL_HW) BWD_SMALL(float, 16, MAXR); else BWD_SMALL(float, 16, BIGR);
@@ -902,7 +915,8 @@ int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, in
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, 0);
         dim3 sgrid(C / CW, (N + spb - 1) / spb);
         hipStream_t st = (hipStream_t)stream;
-#define DBL_SMALL(T, RG) hipLaunchKernelGGL((in_dbl_small_kernel<T, RG>), sgrid, dim3(CGN * RGN), 0, st, q, N, spb)
+#define DBL_SMALL(T, RG) do { if (q_nslab > 1) hipLaunchKernelGGL((in_dbl_small_kernel<T, RG, true>), sgrid, dim3(CGN * RGN), 0, st, q, N, spb); \
+                              else hipLaunchKernelGGL((in_dbl_small_kernel<T, RG, false>), sgrid, dim3(CGN * RGN), 0, st, q, N, spb); } while (0)
         if (dtype == GCSSL_F32) { if (rg == 1) DBL_SMALL(float, 1); else if (rg == 4) DBL_SMALL(float, 4); else DBL_SMALL(float, 16); }
         else { if (rg == 1) DBL_SMALL(bf16_t, 1); else if (rg == 4) DBL_SMALL(bf16_t, 4); else DBL_SMALL(bf16_t, 16); }
 #undef DBL_SMALL

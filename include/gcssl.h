@@ -132,8 +132,8 @@ int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, in
                      const float* z, int ldz, const float* mean, const float* rstd, void* gt_a, int ldga, float* zt,
                      float* cdot, int q_nslab, long q_slab_stride, int N, int HW, int C, int act, void* stream);
 /* da_nslab / q_nslab > 1: da / qz is the first of that many split-K partial-sum slabs (stride in floats) written by a
- * gcssl_conv4x4s2_* call with split_stride > 0; the kernel adds them on load (maps up to 16x16 / 8x8);
- * gcssl_in_act_bwd also writes the total back to slab 0 (da is read again by gcssl_in_dbl_bwd as gb_a). */
+ * gcssl_conv4x4s2_* call with split_stride > 0; the kernel first folds them into slab 0 (maps up to 16x16 / 8x8), so
+ * slab 0 holds the total afterwards (gcssl_in_dbl_bwd reads the same da again as gb_a). */
 /* LeakyReLU backward for the norm-less layers (D.c1, G.down1; cgan/models.py:103,246), from the activation OUTPUT a. */
 int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const void* a, int lda,
                   const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias, float* cdot,
