@@ -74,7 +74,8 @@ def lib():
         if not LIB_PATH.exists():
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                f"(there is no CPU fallback for the HIP path)")
-        _lib = ctypes.CDLL(str(LIB_PATH))
+        # GCSSL_LIB: load another build of the same ABI (same-box A/B of two builds; experiments only)
+        _lib = ctypes.CDLL(os.environ.get("GCSSL_LIB") or str(LIB_PATH))
         _protos = parse_header()
         for name, (ret, argtypes) in _protos.items():
             fn = getattr(_lib, name)          # AttributeError here == header/ABI mismatch: fail loudly

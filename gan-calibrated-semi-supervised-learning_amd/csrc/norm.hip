@@ -126,7 +126,7 @@ __device__ __forceinline__ void keep4(const uint8_t* mp, float (&k)[VC]) {
 }
 
 // ---- forward, small maps: a = act((z - mean) * rstd) [* keep * 2]; writes mean/rstd [N][C]
-template <typename T, int RG, int MR = MAXR>
+template <typename T, int RG, int MR = MAXR, bool SLAB = false>
 __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(float* __restrict__ z, int ldz, T* __restrict__ a, int lda,
                                                                 float* __restrict__ mean, float* __restrict__ rstd,
                                                                 const uint8_t* __restrict__ mask, int N, int HW, int C, int act,
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(float* __restri
             const int p = rg + RG * i;
             if (live && p < HW) {
                 ld4(zp + (size_t)p * ldz, v[i]);
-                if (nslab > 1) {                  // split-K partial sums of the producing conv: add the slabs, keep the total
+                if (SLAB) {                       // split-K partial sums of the producing conv: add the slabs, keep the total
                     for (int k = 1; k < nslab; ++k) {
                         float t[VC]; ld4(zp + (size_t)k * slab_stride + (size_t)p * ldz, t);
 #pragma unroll
@@ -820,7 +820,8 @@ int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean
     if (HW <= MID_HW && !pool) {
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, 0);
         dim3 grid(C / CW, (N + spb - 1) / spb);
-#define FWD_SMALL(T, RG, MR) hipLaunchKernelGGL((in_fwd_small_kernel<T, RG, MR>), grid, dim3(CGN * RGN), 0, st, z, ldz, (T*)a, lda, mean, rstd, mask, N, HW, C, act, spb, nslab, slab_stride)
+#define FWD_SMALL(T, RG, MR) do { if (nslab > 1) hipLaunchKernelGGL((in_fwd_small_kernel<T, RG, MR, true>), grid, dim3(CGN * RGN), 0, st, z, ldz, (T*)a, lda, mean, rstd, mask, N, HW, C, act, spb, nslab, slab_stride); \
+                                  else hipLaunchKernelGGL((in_fwd_small_kernel<T, RG, MR, false>), grid, dim3(CGN * RGN), 0, st, z, ldz, (T*)a, lda, mean, rstd, mask, N, HW, C, act, spb, nslab, slab_stride); } while (0)
         if (dtype == GCSSL_F32) {
             if (rg == 1) FWD_SMALL(float, 1, MAXR); else if (rg == 4) FWD_SMALL(float, 4, MAXR);
             else if (HW <= SMALL_HW) FWD_SMALL(float, 16, MAXR); else FWD_SMALL(float, 16, BIGR);
