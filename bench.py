@@ -88,7 +88,7 @@ def main():
     T = torch.from_numpy
     g = {k: T(v) for k, v in (synth.simple_generator_state(42) if args.generator == "simple" else synth.generator_state(42)).items()}
     d = {k: T(v) for k, v in synth.discriminator_state(42).items()}
-    averager = dist_mod.GradAverager() if world > 1 else None
+    averager = dist_mod.GradAverager() if (world > 1 or dist_mod.force_dp()) else None
     eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype=args.dtype, device=dev, seed=42 + rank,
                             allreduce=averager, keep_clipped_grads=False,
                             overlap=int(os.environ.get("GCSSL_OVERLAP", "0")), generator_type=args.generator)
@@ -185,7 +185,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(synth, 42, B, S, c, gtype=args.generator)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

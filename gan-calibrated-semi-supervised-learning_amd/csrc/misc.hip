@@ -349,8 +349,11 @@ __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __re
 // Few blocks (same-address fp64 atomics serialise at ~12 ns each); the last block to finish advances the step and
 // derives the scalars of this update, following torch's single-tensor Adam (python doubles, cast to float where
 // they meet the tensor).
+// gscale: the gradient the optimiser sees is g * gscale (1/world_size of a data-parallel SUM all-reduce: the averaging
+// multiply rides in the two passes that read g anyway); the norm, the clip coefficient and what is written back are those
+// of the scaled gradient.
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* state, double lr, double b1,
-                                                    double b2, double max_norm) {
+                                                    double b2, double max_norm, double gscale) {
     __shared__ double red[4];
     __shared__ int last;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // fp32 per-thread partials (<= ~100 elements each), fp64 from there
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
         last = atomicAdd(cnt, 1ull) == (unsigned long long)(gridDim.x - 1);
         if (last) {
             __threadfence();
-            const double ss = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double ss = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * gscale * gscale;
             const double t = state[0] + 1.0;
             const float total = (float)sqrt(ss);
             state[0] = t;
@@ -407,8 +410,8 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n, const double* __restrict__ state, double b1,
-                                                   double b2, double eps, int after) {
-    const float coef = (float)state[3], step = (float)state[4], bc2s = (float)state[5];
+                                                   double b2, double eps, int after, float gscale) {
+    const float coef = (float)state[3] * gscale, step = (float)state[4], bc2s = (float)state[5];
     const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2), epsf = (float)eps;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n4 = n / 4;
     if (i < n4) {
@@ -770,17 +773,17 @@ int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long
 
 // state: 8 doubles, zero-initialised by the caller once (layout at sumsq_kernel); no per-call memset is needed.
 int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* state, double lr, double b1, double b2,
-                    double eps, double max_norm, int write_clipped, void* stream) {
+                    double eps, double max_norm, int write_clipped, double grad_scale, void* stream) {
     if (!p || !g || !m || !v || !state) return GCSSL_ENULL;
-    if (n <= 0 || write_clipped < 0 || write_clipped > 2) return GCSSL_EBADSHAPE;
+    if (n <= 0 || write_clipped < 0 || write_clipped > 2 || !(grad_scale > 0.0)) return GCSSL_EBADSHAPE;
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return GCSSL_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     const size_t n4 = (size_t)n / 4;
     int blocks = (int)((n4 + 256 * 8 - 1) / (256 * 8)); if (blocks > 256) blocks = 256; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, (size_t)n, state, lr, b1, b2, max_norm);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, (size_t)n, state, lr, b1, b2, max_norm, grad_scale);
     const size_t items = n4 + ((size_t)n & 3);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, g, m, v, (size_t)n, state, b1, b2,
-                       eps, write_clipped);
+                       eps, write_clipped, (float)grad_scale);
     return gcssl_launch_status();
 }
 

@@ -23,7 +23,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # GCSSL_FORCE_DP=1: rehearse the data-parallel code path (process group, async all-reduce between the graph segments)
+    # with a single rank on the real RCCL backend -- the only way to exercise it on a one-GPU box
+    if (world > 1 or force_dp()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -37,6 +39,10 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     return rank, world, local
 
 
+def force_dp() -> bool:
+    return os.environ.get("GCSSL_FORCE_DP", "0") == "1"
+
+
 class GradAverager:
     """all-reduce(sum)/world of a flat gradient buffer, in place.  Callable, used as ``StepEngine(allreduce=...)``."""
 
@@ -45,7 +51,7 @@ class GradAverager:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
     def __call__(self, flat: torch.Tensor) -> None:
-        if self.world == 1:
+        if self.world == 1 and not force_dp():
             return
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.mul_(1.0 / self.world)
@@ -53,15 +59,18 @@ class GradAverager:
     # split form: the collective runs on the backend's own stream (RCCL) / thread (gloo) while the caller keeps launching
     # work that does not need the result; finish() orders the caller's stream behind it.
     def start(self, flat: torch.Tensor):
-        if self.world == 1:
+        if self.world == 1 and not force_dp():
             return None
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def finish(self, handle, flat: torch.Tensor) -> None:
+    def finish(self, handle, flat: torch.Tensor, scale: bool = True) -> None:
+        """scale=False: only order the stream behind the collective; the caller applies 1/world itself (the step engine
+        folds it into its fused clip+Adam launch: StepEngine._grad_scale)."""
         if handle is None:
             return
         handle.wait()
-        flat.mul_(1.0 / self.world)
+        if scale:
+            flat.mul_(1.0 / self.world)
 
 
 def shard(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:

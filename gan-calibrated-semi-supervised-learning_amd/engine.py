@@ -495,20 +495,29 @@ class StepEngine:
             return None
         return start(flat)
 
-    def _allreduce_finish(self, handle, flat: torch.Tensor) -> None:
-        if handle is not None:
+    def _allreduce_finish(self, handle, flat: torch.Tensor) -> float:
+        """Order this stream behind a started exchange; returns the factor the optimiser still has to apply to the (summed)
+        gradient: dist.GradAverager leaves the 1/world to the fused clip+Adam launch, other hooks average themselves."""
+        if handle is None:
+            return 1.0
+        world = getattr(self.allreduce, "world", None)
+        if world is None:
             self.allreduce.finish(handle, flat)
+            return 1.0
+        self.allreduce.finish(handle, flat, scale=False)
+        return 1.0 / world
 
     def d_update(self, handle="sync") -> None:
         """all-reduce (data parallel) -> clip_grad_norm_(1.0) -> Adam  (:331-332).  handle: what allreduce_start
         returned when the exchange was started earlier; "sync" = do it here."""
         self._join_side()
+        gs = 1.0
         if handle != "sync":
-            self._allreduce_finish(handle, self.D.g)
+            gs = self._allreduce_finish(handle, self.D.g)
         elif self.allreduce is not None:
             self.allreduce(self.D.g)
         ops.clip_adam(self.D.p, self.D.g, self.D.m, self.D.v, self.D.state, self.lr, self.betas[0], self.betas[1],
-                      write_clipped=1 if self.keep_clipped_grads else 2)     # 2: the update also re-zeroes the bucket
+                      write_clipped=1 if self.keep_clipped_grads else 2, grad_scale=gs)   # 2: the update also re-zeroes the bucket
         self.D.grads_zero = not self.keep_clipped_grads
         self._d_dirty = True
 
@@ -634,12 +643,13 @@ class StepEngine:
 
     def g_update(self, handle="sync") -> None:
         self._join_side()
+        gs = 1.0
         if handle != "sync":
-            self._allreduce_finish(handle, self.G.g)
+            gs = self._allreduce_finish(handle, self.G.g)
         elif self.allreduce is not None:
             self.allreduce(self.G.g)
         ops.clip_adam(self.G.p, self.G.g, self.G.m, self.G.v, self.G.state, self.lr, self.betas[0], self.betas[1],
-                      write_clipped=1 if self.keep_clipped_grads else 2)                # :368-369
+                      write_clipped=1 if self.keep_clipped_grads else 2, grad_scale=gs)  # :368-369
         self.G.grads_zero = not self.keep_clipped_grads
         self._g_dirty = True
 

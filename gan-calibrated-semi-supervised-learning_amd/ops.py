@@ -267,10 +267,11 @@ def scale_rows(x, coef, y, B):
     call("gcssl_scale_rows", code(y), x, coef, y, x.numel() // B, B)
 
 
-def clip_adam(p, g, m, v, state, lr, b1, b2, eps=1e-8, max_norm=1.0, write_clipped=False):
-    """write_clipped: False/0 leave g, True/1 store the clipped gradient, 2 zero g (fused zero_grad).  state: 8 doubles."""
+def clip_adam(p, g, m, v, state, lr, b1, b2, eps=1e-8, max_norm=1.0, write_clipped=False, grad_scale=1.0):
+    """write_clipped: False/0 leave g, True/1 store the clipped gradient, 2 zero g (fused zero_grad).  state: 8 doubles.
+    grad_scale: the optimiser sees g * grad_scale (1/world after a data-parallel SUM all-reduce)."""
     call("gcssl_clip_adam", p, g, m, v, p.numel(), state, float(lr), float(b1), float(b2), float(eps),
-         float(max_norm), int(write_clipped))
+         float(max_norm), int(write_clipped), float(grad_scale))
 
 
 def pool_fc_tanh_fwd(x, w, bias, scale, pooled, traw, delta, pool_sum=None):

@@ -166,9 +166,11 @@ int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long
  * sqrt(1-b2^t), completion counter, lr override}; the step is advanced on the device (graph replay safe); a
  * positive state[7] replaces `lr` (what ReduceLROnPlateau at cgan/cgan_train_enhanced.py:260-261,427-428 changes).
  * write_clipped: 0 leave g, 1 store g*clip_coef (what clip_grad_norm_ leaves in .grad), 2 zero g (fused zero_grad).
+ * grad_scale (> 0): the optimiser sees g * grad_scale -- 1/world_size after a data-parallel SUM all-reduce, 1 otherwise;
+ * norm, clip coefficient and the written-back gradient are those of the scaled gradient.
  * p, g, m, v must be 16-byte aligned. */
 int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* state, double lr, double b1, double b2,
-                    double eps, double max_norm, int write_clipped, void* stream);
+                    double eps, double max_norm, int write_clipped, double grad_scale, void* stream);
 
 /* ---- generator head (cgan/models.py:118-123,139-141) and box/EIoU loss (cgan/losses.py:19-73,99-150) ------------- */
 /* pool_sum (nullable): [B][64] sums over H*W already accumulated by gcssl_in_act_fwd(pool=...); then x is not read and

@@ -347,6 +347,17 @@ def test_clip_adam_matches_torch(ops):
     ops.clip_adam(pb, g2.clone(), mb, vb, sb, 2e-4, 0.5, 0.999)
     torch.cuda.synchronize()
     assert torch.equal(pa, pb)
+    # grad_scale: the 1/world of a data-parallel SUM all-reduce folded in == scaling the gradient first
+    pa, pb = p.clone(), p.clone()
+    ma, va, sa = m.clone(), v.clone(), state.clone()
+    mb, vb, sb = m.clone(), v.clone(), state.clone()
+    g3 = rnd(n, seed=92, scale=40.0).cuda()                      # large enough that the clip is active on the summed gradient
+    ga, gb = g3.clone(), g3 * 0.25
+    ops.clip_adam(pa, ga, ma, va, sa, 2e-4, 0.5, 0.999, write_clipped=1, grad_scale=0.25)
+    ops.clip_adam(pb, gb, mb, vb, sb, 2e-4, 0.5, 0.999, write_clipped=1)
+    torch.cuda.synchronize()
+    assert rel_err(pa.cpu(), pb.cpu()) < 1e-6 and rel_err(ga.cpu(), gb.cpu()) < 1e-6
+    assert abs(float(sa[2]) - float(sb[2])) < 1e-6 * float(sb[2]) and abs(float(sa[3]) - float(sb[3])) < 1e-6
 
 
 def test_generator_head_and_eiou(ops):
