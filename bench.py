@@ -75,13 +75,26 @@ def main():
     args = ap.parse_args()
 
     dist_mod = importlib.import_module(PKG + ".dist")
-    rank, world, local = dist_mod.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    # RCCL prints a version banner on STDOUT when its communicator is created: keep stdout to the one JSON line by pointing
+    # fd 1 at stderr until the process group and the communicator (first collective) exist
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        rank, world, local = dist_mod.init_from_env()
+        if world != args.gpus and world > 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+        if torch.distributed.is_initialized():
+            torch.distributed.all_reduce(torch.zeros(1, device=dev))
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     synth = importlib.import_module(PKG + ".synth")
     engine = importlib.import_module(PKG + ".engine")
     B, S, c = args.batch, args.size, args.n_critic

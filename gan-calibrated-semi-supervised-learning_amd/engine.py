@@ -495,6 +495,15 @@ class StepEngine:
             return None
         return start(flat)
 
+    def allreduce_wait(self, handle, flat: torch.Tensor) -> None:
+        """Order this stream behind a started exchange WITHOUT the update (GraphedIteration: the update itself is inside
+        the next captured segment, with the factor _allreduce_finish would return baked in)."""
+        self._allreduce_finish(handle, flat)
+
+    def dp_grad_scale(self) -> float:
+        world = getattr(self.allreduce, "world", None)
+        return 1.0 / world if world else 1.0
+
     def _allreduce_finish(self, handle, flat: torch.Tensor) -> float:
         """Order this stream behind a started exchange; returns the factor the optimiser still has to apply to the (summed)
         gradient: dist.GradAverager leaves the 1/world to the fused clip+Adam launch, other hooks average themselves."""
@@ -512,7 +521,9 @@ class StepEngine:
         returned when the exchange was started earlier; "sync" = do it here."""
         self._join_side()
         gs = 1.0
-        if handle != "sync":
+        if isinstance(handle, float):                             # exchange already waited for: only the averaging factor is left
+            gs = handle
+        elif handle != "sync":
             gs = self._allreduce_finish(handle, self.D.g)
         elif self.allreduce is not None:
             self.allreduce(self.D.g)
@@ -644,7 +655,9 @@ class StepEngine:
     def g_update(self, handle="sync") -> None:
         self._join_side()
         gs = 1.0
-        if handle != "sync":
+        if isinstance(handle, float):
+            gs = handle
+        elif handle != "sync":
             gs = self._allreduce_finish(handle, self.G.g)
         elif self.allreduce is not None:
             self.allreduce(self.G.g)
@@ -792,8 +805,9 @@ class StepEngine:
 class GraphedIteration:
     """One training iteration as hipGraphs: the launch-bound kernel sequences of each critic step and of the generator
     step are captured once (torch.cuda.CUDAGraph == hipGraph on ROCm; our ctypes launches go to the capturing stream)
-    and replayed.  With data parallelism the all-reduce + clip/Adam stay outside the graphs, between the segments;
-    single-GPU runs capture the update too.  Inputs are static device tensors; alpha and dropout masks are drawn on the
+    and replayed.  Single-GPU runs are ONE graph per iteration.  With data parallelism the iteration is cut where a
+    collective's result is needed: only the all-reduce launches and the stream waits sit between the segments, the
+    clip+Adam updates are captured at the head of the segment that consumes them.  Inputs are static device tensors; alpha and dropout masks are drawn on the
     device inside the graph (torch's graph-safe Philox / the counter-based mask kernel), so every replay differs."""
 
     def __init__(self, eng: "StepEngine", pred, gt, delta_true, pred_box, refine_fn):
@@ -830,17 +844,24 @@ class GraphedIteration:
         # data parallel: every all-reduce runs beside launches that do not need its result --
         #   critic step k's gradient  ||  d_pre of step k+1 (G's no-grad forward, re-crop, packing) or, after the last
         #                                 critic step, g_main (G's forward + backward)
-        #   the generator's gradient  ||  g_critic (the value-only critic forward of the generator step)
-        self.pre, self.main = [], []
-        for k in range(eng.c):
-            eng._g_dirty = (k == 0)
+        #   the generator's gradient  ||  the last critic update + g_critic (the value-only critic forward of the G step)
+        # and every optimiser update is captured at the head of the segment that needs its result (the stream only WAITS
+        # for the collective between two graph launches; the 1/world factor is baked into the fused clip+Adam node):
+        #   [pre0 main0] AR(D) [pre1] wait [updD main1] AR(D) ... [g_main] AR(G) wait(D) [updD g_critic] wait(G) [updG]
+        if getattr(eng.allreduce, "start", None) is None or getattr(eng.allreduce, "world", None) is None:
+            raise ValueError("GraphedIteration's data-parallel form needs a dist.GradAverager-like hook (start/finish/world)")
+        gs = eng.dp_grad_scale()
+        eng._g_dirty, eng._d_dirty = True, True
+        self.first = capture(lambda: (eng.d_pre(pred, gt, refine_fn, 0, None, None), eng.d_main()))
+        self.pre, self.upd_main = [None], [None]
+        for k in range(1, eng.c):
+            eng._g_dirty = False
             self.pre.append(capture(lambda k=k: eng.d_pre(pred, gt, refine_fn, k, None, None)))
-            eng._d_dirty = True
-            self.main.append(capture(eng.d_main))
+            self.upd_main.append(capture(lambda: (eng.d_update(gs), eng.d_main())))
         eng._g_dirty = False
         self.g_main = capture(lambda: eng.g_main(pred, delta_true, pred_box, refine_fn, None))
-        eng._d_dirty = True
-        self.g_crit = capture(lambda: eng.g_critic(pred))
+        self.upd_crit = capture(lambda: (eng.d_update(gs), eng.g_critic(pred)))
+        self.upd_g = capture(lambda: eng.g_update(gs))
 
     def replay(self):
         eng = self.eng
@@ -848,12 +869,16 @@ class GraphedIteration:
             for g in self.graphs:
                 g.replay()
             return
-        self.pre[0].replay()
-        for k in range(eng.c):
-            self.main[k].replay()
+        self.first.replay()
+        h = eng.allreduce_start(eng.D.g)
+        for k in range(1, eng.c):
+            self.pre[k].replay()
+            eng.allreduce_wait(h, eng.D.g)
+            self.upd_main[k].replay()
             h = eng.allreduce_start(eng.D.g)
-            (self.pre[k + 1] if k + 1 < eng.c else self.g_main).replay()
-            eng.d_update(h)
-        h = eng.allreduce_start(eng.G.g)
-        self.g_crit.replay()
-        eng.g_update(h)
+        self.g_main.replay()
+        hg = eng.allreduce_start(eng.G.g)                         # queued behind the critic's exchange on the backend's stream
+        eng.allreduce_wait(h, eng.D.g)
+        self.upd_crit.replay()
+        eng.allreduce_wait(hg, eng.G.g)
+        self.upd_g.replay()
