@@ -71,7 +71,7 @@ def main():
                     help="generator_type (cgan/cgan_train_enhanced.py:26-31); the headline config is the default U-Net")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--probe-steps", type=int, default=3)
+    ap.add_argument("--probe-steps", type=int, default=5)
     args = ap.parse_args()
 
     dist_mod = importlib.import_module(PKG + ".dist")

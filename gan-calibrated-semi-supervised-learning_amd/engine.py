@@ -186,8 +186,12 @@ class StepEngine:
         torch.cuda.synchronize()
         out = {}
         for k, rec in (self.probe or {}).items():
-            ts = [a.elapsed_time(b) for a, b in rec["events"]]
-            out[k] = (len(ts), sum(ts) / max(len(ts), 1), rec["flops"], rec["bytes"])
+            ts = sorted(a.elapsed_time(b) for a, b in rec["events"])
+            # an eager launch whose host-side enqueue stalls (GC pause, first-use lazy init) shows up as tens of ms between
+            # its two events: average the samples within 3x the median (all of them, when nothing stalled)
+            med = ts[len(ts) // 2] if ts else 0.0
+            keep = [t for t in ts if t <= 3.0 * med] or ts
+            out[k] = (len(ts), sum(keep) / max(len(keep), 1), rec["flops"], rec["bytes"])
         return out
 
     # ------------------------------------------------------------------------------------------ split-K slabs
