@@ -81,6 +81,23 @@ class FlatParams:
         raise KeyError(k)
 
 
+class GFwd:
+    """Forward-pass buffers of the U-Net generator for a batch of n samples (activations, pre-norm tensors with their
+    split-K slab room, statistics, dropout masks, head)."""
+    FIELDS = ("cat3", "cat2", "cat1", "d4", "u4", "pooled", "poolsum", "traw", "delta", "x8")
+    LISTS = ("zd", "zu", "dmean", "drstd", "umean", "urstd", "masks")
+
+    def group(self, g: int, b: int) -> "GFwd":
+        """views of samples [g*b, (g+1)*b) -- the buffers one generator call of the iteration reads and writes"""
+        sl, v = slice(g * b, (g + 1) * b), GFwd()
+        v.n, v.maskbuf = b, None
+        for f in self.FIELDS:
+            setattr(v, f, getattr(self, f)[sl])
+        for f in self.LISTS:
+            setattr(v, f, [None if t is None else t[sl] for t in getattr(self, f)])
+        return v
+
+
 def conv_flops(n: int, hi: int, cin: int, cout: int) -> float:
     """Algorithmic FLOPs (2*MAC) of one k4 s2 p1 conv pass (forward, dgrad or wgrad) over n samples of hi x hi input."""
     return 2.0 * n * (hi // 2) * (hi // 2) * cout * 16 * cin
@@ -127,6 +144,8 @@ class StepEngine:
         self.sn = ops.SnState([self.D.views[f"model.{i}.weight_orig"] for i in D_IDX], self.u, self.v, 3, dev)
         self._zcap, self._zkeep, self._splits = {}, [], {}
         self.grad_slabs = os.environ.get("GCSSL_GRAD_SLABS", "1") != "0"
+        # one batched generator forward per iteration (g_forward_all); GCSSL_BATCH_G=0: one forward per call, for A/B runs
+        self.batch_g = generator_type == "unet" and os.environ.get("GCSSL_BATCH_G", "1") != "0"
         self._alloc()
         self.gen = SimpleGenerator(self) if generator_type == "simple" else None
         self._d_dirty = True
@@ -206,7 +225,7 @@ class StepEngine:
             need = max(need, n * ops.conv_splits(kind, self.code, n, hi, cin, cout))
         buf = torch.empty(need, ho, ho, c, device=self.dev, dtype=torch.float32)
         z = buf[:n_full]
-        self._zcap[z.data_ptr()] = buf.numel()
+        self._zcap[z.data_ptr()] = (buf.numel(), n_full)
         self._zkeep.append(buf)
         return z
 
@@ -221,7 +240,8 @@ class StepEngine:
             per = n * z.shape[1] * z.shape[2] * z.shape[3]
             # (the fused InstanceNorm kernels that add the slabs handle maps up to 16x16 -- 8x8 for the double backward;
             # larger ones keep the atomic form)
-            ok = (ks > 1 and ks * per <= self._zcap.get(z.data_ptr(), 0) and z.is_contiguous()
+            cap, n_reg = self._zcap.get(z.data_ptr(), (0, -1))      # (a batch-slice view of a registered buffer has no slab room)
+            ok = (ks > 1 and n_reg == z.shape[0] and ks * per <= cap and z.is_contiguous()
                   and z.shape[1] * z.shape[2] <= max_hw)
             self._splits[key] = (ks, per) if ok else (1, 0)
         return self._splits[key]
@@ -309,29 +329,43 @@ class StepEngine:
             nc, nf = 0, ops.wgrad_splits(N4, hi, hi, cp, cout)
             self.d_ns.append((nc, nf))
             self.d_slab.append(torch.empty(nc + nf, cout, 16, cp, **f32))
-        # ---- generator (B samples)
-        self.g_cat3 = act(B, S // 2, 128)      # [up3 out (64) | d1 (64)]
-        self.g_cat2 = act(B, S // 4, 256)      # [up2 out (128) | d2 (128)]
-        self.g_cat1 = act(B, S // 8, 512)      # [up1 out (256) | d3 (256)]
-        self.g_d4 = act(B, S // 16, 512)
+        # ---- generator forward: ONE set of buffers for all n_critic + 1 generator calls of an iteration (g_forward_all runs
+        # them as one batch); group `c` -- the generator step's call, whose activations the backward reads -- is also what
+        # the stand-alone calls (d_step / g_step / generator_delta) use, under the historic attribute names
+        NG = self.c + 1
+        n = NG * B
+        ga = GFwd()
+        ga.n = n
+        ga.cat3 = act(n, S // 2, 128)          # [up3 out (64) | d1 (64)]
+        ga.cat2 = act(n, S // 4, 256)          # [up2 out (128) | d2 (128)]
+        ga.cat1 = act(n, S // 8, 512)          # [up1 out (256) | d3 (256)]
+        ga.d4 = act(n, S // 16, 512)
         z32 = torch.float32
-        self.g_zd = [None] + [self._zbuf("fwd", (B,), S >> k, G_DOWN[k][0], G_DOWN[k][1], B) for k in (1, 2, 3)]
-        self.g_zu = [self._zbuf("dgrad", (B,), S >> (3 - k), coutt, cint, B) for k, (cint, coutt) in enumerate(G_UP)]
-        self.g_u4 = act(B, S, 64)
-        self.g_dmean = [None] + [torch.empty(B, c, **f32) for c in (128, 256, 512)]
-        self.g_drstd = [None] + [torch.empty(B, c, **f32) for c in (128, 256, 512)]
-        ustats = [torch.empty(2, B, c, **f32) for c in (256, 128, 64, 64)]      # mean | rstd back to back: one fill
-        self.g_umean = [t[0] for t in ustats]
-        self.g_urstd = [t[1] for t in ustats]
-        shapes = [(B, S // 16, S // 16, 512), (B, S // 8, S // 8, 256), (B, S // 4, S // 4, 128)]
+        ga.zd = [None] + [self._zbuf("fwd", (n,), S >> k, G_DOWN[k][0], G_DOWN[k][1], n) for k in (1, 2, 3)]
+        ga.zu = [self._zbuf("dgrad", (n,), S >> (3 - k), coutt, cint, n) for k, (cint, coutt) in enumerate(G_UP)]
+        ga.u4 = act(n, S, 64)
+        ga.dmean = [None] + [torch.empty(n, c, **f32) for c in (128, 256, 512)]
+        ga.drstd = [None] + [torch.empty(n, c, **f32) for c in (128, 256, 512)]
+        ustats = [torch.empty(2, n, c, **f32) for c in (256, 128, 64, 64)]      # mean | rstd back to back: one fill
+        ga.umean = [t[0] for t in ustats]
+        ga.urstd = [t[1] for t in ustats]
+        shapes = [(n, S // 16, S // 16, 512), (n, S // 8, S // 8, 256), (n, S // 4, S // 4, 128)]
         sizes = [math.prod(sh) for sh in shapes]
-        self.g_maskbuf = torch.empty(sum(sizes), device=dev, dtype=torch.uint8)      # one launch draws all three
-        self.g_masks = [self.g_maskbuf[sum(sizes[:j]):sum(sizes[:j + 1])].view(sh) for j, sh in enumerate(shapes)]
-        self.g_pooled = torch.empty(B, 64, **f32)
-        self.g_poolsum = torch.zeros(B, 64, **f32)                 # sum over H*W of u4 (up4's IN apply pass adds, the head consumes and clears)
+        ga.maskbuf = torch.empty(sum(sizes), device=dev, dtype=torch.uint8)          # one launch draws all three
+        ga.masks = [ga.maskbuf[sum(sizes[:j]):sum(sizes[:j + 1])].view(sh) for j, sh in enumerate(shapes)]
+        ga.pooled = torch.empty(n, 64, **f32)
+        ga.poolsum = torch.zeros(n, 64, **f32)                     # sum over H*W of u4 (up4's IN apply pass adds, the head consumes and clears)
+        ga.traw = torch.empty(n, 4, **f32)
+        ga.delta = torch.empty(n, 4, **f32)
+        ga.x8 = act(n, S, 8)                                       # NHWC8 input of the batched forward (pred, replicated per call)
+        self.gfa = ga
+        self.gf = gf = ga.group(self.c, B)
+        self.g_cat3, self.g_cat2, self.g_cat1, self.g_d4, self.g_u4 = gf.cat3, gf.cat2, gf.cat1, gf.d4, gf.u4
+        self.g_zd, self.g_zu, self.g_dmean, self.g_drstd = gf.zd, gf.zu, gf.dmean, gf.drstd
+        self.g_umean, self.g_urstd, self.g_masks = gf.umean, gf.urstd, gf.masks
+        self.g_pooled, self.g_poolsum, self.g_traw, self.g_delta = gf.pooled, gf.poolsum, gf.traw, gf.delta
+        self._gall_valid = False
         self.ws = torch.empty(2 * N3 * 512, **f32)                 # scratch of the large-map InstanceNorm backward
-        self.g_traw = torch.empty(B, 4, **f32)
-        self.g_delta = torch.empty(B, 4, **f32)
         self.g_gdelta = torch.empty(B, 4, **f32)
         self.g_cal = torch.empty(B, 4, **f32)
         self.g_dab = torch.empty(B, 64, **f32)
@@ -441,7 +475,8 @@ class StepEngine:
         if self.gen is not None:
             self.gen.set_masks(masks, phase)
         elif masks is None:
-            ops.dropout_mask_gen(self.g_maskbuf, self.seed * 131 + phase, self.G.state)
+            for j, m in enumerate(self.g_masks):                   # (views into the all-calls buffers: one launch each)
+                ops.dropout_mask_gen(m, self.seed * 131 + phase + 7919 * j, self.G.state)
         else:
             for m, src in zip(self.g_masks, masks):
                 m.copy_(src.permute(0, 2, 3, 1))
@@ -450,31 +485,56 @@ class StepEngine:
         """GeneratorUNet.forward (cgan/models.py:125-141) on an NHWC8 input whose first 3 channels are pred."""
         if self.gen is not None:
             return self.gen.forward(x8, train)
-        B = self.B
-        d1, d2, d3 = self.g_cat3[..., 64:], self.g_cat2[..., 128:], self.g_cat1[..., 256:]
-        mk = self.g_masks if train else [None, None, None]
-        S = self.S
-        self._conv("G.down1.fwd", conv_flops(B, S, 3, 64), ops.conv_fwd, x8, self.gd_wf[0], d1, 8, 64, act=LRELU)
-        dins, douts, dmask = [None, d1, d2, d3], [None, d2, d3, self.g_d4], [None, None, None, mk[0]]
+        return self._unet_forward(x8, train, self.gf)
+
+    def _unet_forward(self, x8: torch.Tensor, train: bool, f: GFwd) -> torch.Tensor:
+        """The U-Net forward on the buffer set `f`: the generator step's group (B samples), or all n_critic + 1 calls of an
+        iteration at once (g_forward_all)."""
+        n, S = f.n, self.S
+        tag = "" if n == self.B else f"[n={n}]"
+        d1, d2, d3 = f.cat3[..., 64:], f.cat2[..., 128:], f.cat1[..., 256:]
+        mk = f.masks if train else [None, None, None]
+        self._conv(f"G.down1.fwd{tag}", conv_flops(n, S, 3, 64), ops.conv_fwd, x8, self.gd_wf[0], d1, 8, 64, act=LRELU)
+        dins, douts, dmask = [None, d1, d2, d3], [None, d2, d3, f.d4], [None, None, None, mk[0]]
         for k in (1, 2, 3):
             cin, cout = G_DOWN[k]
-            ns, st = self._split("fwd", self.g_zd[k], B, S >> k, cin, cout)
-            self._conv(f"G.down{k + 1}.fwd", conv_flops(B, S >> k, cin, cout), ops.conv_fwd, dins[k], self.gd_wf[k],
-                       self.g_zd[k], cin, cout, split_stride=st)
-            ops.in_act_fwd(self.g_zd[k], douts[k], self.g_dmean[k], self.g_drstd[k], cout, LRELU, mask=dmask[k],
+            ns, st = self._split("fwd", f.zd[k], n, S >> k, cin, cout)
+            self._conv(f"G.down{k + 1}.fwd{tag}", conv_flops(n, S >> k, cin, cout), ops.conv_fwd, dins[k], self.gd_wf[k],
+                       f.zd[k], cin, cout, split_stride=st)
+            ops.in_act_fwd(f.zd[k], douts[k], f.dmean[k], f.drstd[k], cout, LRELU, mask=dmask[k],
                            nslab=ns, slab_stride=st)
-        ins = [self.g_d4, self.g_cat1, self.g_cat2, self.g_cat3]
-        outs = [self.g_cat1[..., :256], self.g_cat2[..., :128], self.g_cat3[..., :64], self.g_u4]
+        ins = [f.d4, f.cat1, f.cat2, f.cat3]
+        outs = [f.cat1[..., :256], f.cat2[..., :128], f.cat3[..., :64], f.u4]
         for k, (cint, coutt) in enumerate(G_UP):
-            ns, st = self._split("dgrad", self.g_zu[k], B, S >> (3 - k), coutt, cint) if k < 3 else (1, 0)
-            self._conv(f"G.up{k + 1}.fwd", conv_flops(B, S >> (3 - k), coutt, cint), ops.conv_dgrad, ins[k],
-                       self.gu_wt[k], self.g_zu[k], coutt, cint, split_stride=st)
-            ops.in_act_fwd(self.g_zu[k], outs[k], self.g_umean[k], self.g_urstd[k], coutt, RELU,
-                           mask=mk[k + 1] if k < 2 else None, pool=self.g_poolsum if k == 3 else None,
+            ns, st = self._split("dgrad", f.zu[k], n, S >> (3 - k), coutt, cint) if k < 3 else (1, 0)
+            self._conv(f"G.up{k + 1}.fwd{tag}", conv_flops(n, S >> (3 - k), coutt, cint), ops.conv_dgrad, ins[k],
+                       self.gu_wt[k], f.zu[k], coutt, cint, split_stride=st)
+            ops.in_act_fwd(f.zu[k], outs[k], f.umean[k], f.urstd[k], coutt, RELU,
+                           mask=mk[k + 1] if k < 2 else None, pool=f.poolsum if k == 3 else None,
                            nslab=ns, slab_stride=st)
-        ops.pool_fc_tanh_fwd(self.g_u4, self.G.views["fc_delta.1.weight"], self.G.views["fc_delta.1.bias"],
-                             self.delta_scale, self.g_pooled, self.g_traw, self.g_delta, pool_sum=self.g_poolsum)
-        return self.g_delta
+        ops.pool_fc_tanh_fwd(f.u4, self.G.views["fc_delta.1.weight"], self.G.views["fc_delta.1.bias"],
+                             self.delta_scale, f.pooled, f.traw, f.delta, pool_sum=f.poolsum)
+        return f.delta
+
+    def g_forward_all(self, pred: torch.Tensor, masks=None) -> None:
+        """All n_critic + 1 generator forwards of an iteration as ONE batch (cgan/cgan_train_enhanced.py:311-312 per critic
+        step and :348): they read the same input with the same weights -- G is only updated at :369 -- and differ in their
+        Dropout draws, so the reference's separate calls are one (n_critic+1)*B-sample pass here, the way the three critic
+        forwards of a step are one 3B-sample pass.  Same FLOPs; the small-M layers stop being latency-bound.  d_pre(k) then
+        takes its delta from group k, g_main its activations from group n_critic.  masks: per call a triple (fixtures)
+        or None (drawn on the device, one launch)."""
+        B, fa = self.B, self.gfa
+        self._prep_g()
+        ops.pack_pair(pred, None, fa.x8[:B])
+        fa.x8.view(self.c + 1, -1)[1:].copy_(fa.x8.view(self.c + 1, -1)[0])       # the same input for every call
+        if masks is None:
+            ops.dropout_mask_gen(fa.maskbuf, self.seed * 131 + 20, self.G.state)
+        else:
+            for g, triple in enumerate(masks):
+                for m, src in zip(fa.masks, triple):
+                    m[g * B:(g + 1) * B].copy_(src.permute(0, 2, 3, 1))
+        self._unet_forward(fa.x8, True, fa)
+        self._gall_valid = True
 
     def generator_delta(self, pred: torch.Tensor, masks=None, train: bool = True) -> torch.Tensor:
         """GeneratorUNet.forward(pred) -> (B,4) delta."""
@@ -553,10 +613,13 @@ class StepEngine:
         (cgan/losses.py:199) and the packed fake / interpolated groups."""
         B = self.B
         I = slice(2 * B, 3 * B)
-        self._prep_g()
         ops.pack_pair(pred, gt, self.x0[:B])                       # real group; channels 0-2 = pred are G's input too
-        self._set_masks(masks, 10 + k)                             # keyed by (seed, step index, critic step count)
-        delta_det = self._g_forward(self.x0[:B], True)
+        if self._gall_valid:                                       # this call was part of the iteration's batched forward
+            delta_det = self.gfa.delta[k * B:(k + 1) * B]
+        else:
+            self._prep_g()
+            self._set_masks(masks, 10 + k)                         # keyed by (seed, step index, critic step count)
+            delta_det = self._g_forward(self.x0[:B], True)
         refined = refine_fn(delta_det, k)                          # :313-315
         # fake (pred, refined) and interpolated groups in one pass; alpha given (parity runs) or drawn in the kernel
         ops.pack_fake_interp(pred, gt, refined, alpha, self.x0[B:2 * B], self.x0[I], seed=self.seed * 131 + 7 + 16 * k,
@@ -689,10 +752,13 @@ class StepEngine:
     def g_main(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
         B, S = self.B, self.S
         self.scal[13:].zero_()
-        self._prep_g()
-        ops.pack_pair(pred, None, self.x0[:B])
-        self._set_masks(masks, 1)
-        self._g_forward(self.x0[:B], True)                                             # :348
+        if self._gall_valid:               # forward done with the iteration's batch (group n_critic = these very buffers)
+            self._gall_valid = False
+        else:
+            self._prep_g()
+            ops.pack_pair(pred, None, self.x0[:B])
+            self._set_masks(masks, 1)
+            self._g_forward(self.x0[:B], True)                                         # :348
         ops.eiou_fwd_bwd(pred_box, self.g_delta, delta_true, self.lambda_iou, self.g_gdelta, self.g_cal,
                          self.eiou_acc)                                                # :351-355
         self.delta_pred = self.g_delta                  # (alias: valid until the next generator forward; iteration() clones it)
@@ -759,6 +825,8 @@ class StepEngine:
     # ------------------------------------------------------------------------------------------ iteration
     def run_iteration(self, pred, gt, delta_true, pred_box, refine_fn, alphas=None, masks=None, on_critic=None):
         """Enqueue one full iteration (n_critic D steps + 1 G step); no host sync, nothing read back."""
+        if self.batch_g:
+            self.g_forward_all(pred, masks)
         for k in range(self.c):
             self.d_step(pred, gt, refine_fn, k, None if alphas is None else alphas[k],
                         None if masks is None else masks[k])
@@ -837,6 +905,7 @@ class GraphedIteration:
             steps = []
             for k in range(eng.c):
                 steps.append(lambda k=k: (setattr(eng, "_d_dirty", True), setattr(eng, "_g_dirty", k == 0),
+                                          eng.g_forward_all(pred, None) if (k == 0 and eng.batch_g) else None,
                                           eng.d_compute(pred, gt, refine_fn, k, None, None), eng.d_update()))
             steps.append(lambda: (setattr(eng, "_d_dirty", True), setattr(eng, "_g_dirty", False),
                                   eng.g_compute(pred, delta_true, pred_box, refine_fn, None), eng.g_update()))
@@ -856,7 +925,8 @@ class GraphedIteration:
             raise ValueError("GraphedIteration's data-parallel form needs a dist.GradAverager-like hook (start/finish/world)")
         gs = eng.dp_grad_scale()
         eng._g_dirty, eng._d_dirty = True, True
-        self.first = capture(lambda: (eng.d_pre(pred, gt, refine_fn, 0, None, None), eng.d_main()))
+        self.first = capture(lambda: (eng.g_forward_all(pred, None) if eng.batch_g else None,
+                                      eng.d_pre(pred, gt, refine_fn, 0, None, None), eng.d_main()))
         self.pre, self.upd_main = [None], [None]
         for k in range(1, eng.c):
             eng._g_dirty = False
