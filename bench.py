@@ -166,11 +166,12 @@ def main():
     hbm_bound = by_dom / (HBM_PEAK_GBS * 1e9) > fl_dom / (peak * 1e12)
     ach_gbs = by_dom / (ms_dom * 1e-3) / 1e9
     # HBM bytes per launch of the dominant kernel: from the committed rocprofv3 --pmc passes (FETCH_SIZE x2-corrected +
-    # WRITE_SIZE, profiles/round1_pmc_G_up4_fwd_persistent.json) when this run is the configuration they were taken on, else null
+    # WRITE_SIZE, tools/pmc_traffic.sh) when this run is the configuration they were taken on, else null
     traffic = None
-    pmc = ROOT / "profiles" / "round1_pmc_G_up4_fwd_persistent.json"
-    if dom == "G.up4.fwd" and (B, S, args.dtype) == (256, 32, "bf16") and pmc.exists():
-        traffic = json.loads(pmc.read_text())["hbm_bytes_per_launch"]
+    pmc = {"G.up4.fwd": "round1_pmc_G_up4_fwd_persistent.json",          # one generator call (GCSSL_BATCH_G=0)
+           "G.up4.fwd[n=768]": "round1_pmc_G_up4_fwd_n768.json"}.get(dom)  # the batched forward of n_critic + 1 = 3 calls
+    if pmc and (B, S, c, args.dtype, args.generator) == (256, 32, 2, "bf16", "unet") and (ROOT / "profiles" / pmc).exists():
+        traffic = json.loads((ROOT / "profiles" / pmc).read_text())["hbm_bytes_per_launch"]
     roofline = dict(bound="hbm" if hbm_bound else "mfma", kernel=dom,
                     achieved=round(ach_gbs if hbm_bound else ach, 2), peak=HBM_PEAK_GBS if hbm_bound else peak,
                     unit="GB/s" if hbm_bound else "TFLOP/s", frac=round(ach_gbs / HBM_PEAK_GBS if hbm_bound else ach / peak, 4),

@@ -168,6 +168,7 @@ struct ConvParams {
     float inv_group_n;  // 1 / group_n (sample -> group index in the epilogues)
     int ldx, ldw, ldy;  // pixel strides (elements); ldw = lddy for wgrad
     int wk;             // 3x3 forms: elements per packed weight row (9*Cin rounded up to 64) = length of the K loop
+    int class_major;    // persistent dgrad form: 1 = walk the tiles class by class (A/B knob GCSSL_DGRAD_ORDER=1), 0 = class-interleaved
     int N, Hi, Wi, Cin, Cout;   // conv geometry: x is [N][Hi][Wi][Cin], y is [N][Hi/2][Wi/2][Cout]
     int lgWo, lgHoWo, lgCin, lgCout;
     int M;              // GEMM rows
@@ -752,8 +753,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
 
     struct Addr { int rowoff[NVA]; unsigned rowmask[NVA]; unsigned wrow[NVB]; int m0, n0, py, px; };
     auto setup = [&](int tile, Addr& a) {
-        const int mx = tile % tiles_m, rest = tile / tiles_m;
-        const int ny = rest % tiles_n, cls = MODE == 1 ? rest / tiles_n : 0;
+        int mx, ny, cls = 0;
+        if (MODE == 1 && p.class_major == 0) {
+            // The four output-parity classes of a (m, n) tile read the SAME input rows.  Tile t runs on XCD t % 8 (workgroups
+            // are dealt round-robin to the XCDs and the grid is a multiple of 8), so blocks of 32 consecutive tiles are
+            // 8 groups x 4 classes with a group's classes 8 apart: back to back on one XCD, sharing its L2.  In class-major
+            // order (all tiles of class 0, then class 1, ...) a 50 MB input was streamed from HBM once per class: PMC
+            // FETCH_SIZE 270 MB per launch of G.up4.fwd at 768 samples against 50 MB of input.
+            const int groups = tiles_m * tiles_n, full = (groups >> 3) << 5;
+            int g;
+            if (tile < full) { const int r = tile & 31; cls = r >> 3; g = ((tile >> 5) << 3) + (r & 7); }
+            else { const int r = tile - full; g = (groups & ~7) + (r >> 2); cls = r & 3; }
+            mx = g % tiles_m; ny = g / tiles_m;
+        } else {
+            mx = tile % tiles_m;
+            const int rest = tile / tiles_m;
+            ny = rest % tiles_n; cls = MODE == 1 ? rest / tiles_n : 0;
+        }
         a.m0 = mx * BM; a.n0 = ny * BN; a.py = cls >> 1; a.px = cls & 1;
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
@@ -1473,6 +1489,8 @@ int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, c
     const int kv = dtype == GCSSL_F32 ? 4 : 8;
     if (lddy % kv || !aligned16(dy) || !aligned16(wt)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = dy; p.w = wt; p.y = dx; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
+    static const int class_major = [] { const char* e = getenv("GCSSL_DGRAD_ORDER"); return (e && e[0] == '1') ? 1 : 0; }();
+    p.class_major = class_major;
     p.ldx = lddy; p.ldy = lddx; p.out_f32 = out_f32; p.split_stride = split_stride;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     if (!fill_bytes(p, (size_t)N * (Hi / 2) * (Wi / 2) * lddy, (size_t)Cin * 16 * Cout, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
