@@ -145,7 +145,7 @@ class StepEngine:
         self._zcap, self._zkeep, self._splits = {}, [], {}
         self.grad_slabs = os.environ.get("GCSSL_GRAD_SLABS", "1") != "0"
         # one batched generator forward per iteration (g_forward_all); GCSSL_BATCH_G=0: one forward per call, for A/B runs
-        self.batch_g = generator_type == "unet" and os.environ.get("GCSSL_BATCH_G", "1") != "0"
+        self.batch_g = os.environ.get("GCSSL_BATCH_G", "1") != "0"
         self._alloc()
         self.gen = SimpleGenerator(self) if generator_type == "simple" else None
         self._d_dirty = True
@@ -525,6 +525,10 @@ class StepEngine:
         or None (drawn on the device, one launch)."""
         B, fa = self.B, self.gfa
         self._prep_g()
+        if self.gen is not None:
+            self.gen.forward_all(pred, masks)
+            self._gall_valid = True
+            return
         ops.pack_pair(pred, None, fa.x8[:B])
         fa.x8.view(self.c + 1, -1)[1:].copy_(fa.x8.view(self.c + 1, -1)[0])       # the same input for every call
         if masks is None:

@@ -32,6 +32,21 @@ def conv3_flops(n: int, h: int, cin: int, cout: int) -> float:
     return 2.0 * n * h * h * cout * 9 * cin
 
 
+class SFwd:
+    """Forward-pass buffers of the simple generator for a batch of n samples."""
+    LISTS = ("z", "a", "mean", "rstd", "p", "masks")
+    FIELDS = ("feat", "h1", "h2", "x8", "traw", "delta")
+
+    def group(self, g: int, b: int) -> "SFwd":
+        sl, v = slice(g * b, (g + 1) * b), SFwd()
+        v.n = b
+        for f in self.FIELDS:
+            setattr(v, f, getattr(self, f)[sl])
+        for f in self.LISTS:
+            setattr(v, f, [t[sl] for t in getattr(self, f)])
+        return v
+
+
 class SimpleGenerator:
     def __init__(self, eng):
         self.eng = eng
@@ -39,31 +54,46 @@ class SimpleGenerator:
         f32 = dict(device=dev, dtype=torch.float32)
         self.res = [S >> (j // 2) for j in range(8)]
         self.cinp = [max(8, cin) for cin, _ in GS_CONV]
-        self.wf, self.wt, self.z, self.a, self.mean, self.rstd, self.dz, self.da, self.slab, self.ns = ([] for _ in range(10))
+        # forward buffers: ONE set for all n_critic + 1 generator calls of an iteration (forward_all runs them as one
+        # batch, StepEngine.g_forward_all); the generator step's group is what backward and the stand-alone calls use
+        NG = getattr(eng, "c", 0) + 1
+        n = NG * B
+        fa = SFwd()
+        fa.n = n
+        fa.z, fa.a, fa.mean, fa.rstd = [], [], [], []
+        self.wf, self.wt, self.dz, self.da, self.slab, self.ns = ([] for _ in range(6))
         for j, ((cin, cout), r) in enumerate(zip(GS_CONV, self.res)):
             cp = self.cinp[j]
             self.wf.append(torch.empty(cout, ops.conv3_wk(cp), device=dev, dtype=T))
             self.wt.append(torch.empty(cin, ops.conv3_wk(cout), device=dev, dtype=T) if j > 0 else None)
-            self.z.append(torch.empty(B, r, r, cout, **f32))
-            self.a.append(torch.empty(B, r, r, cout, device=dev, dtype=T))
-            self.mean.append(torch.empty(B, cout, **f32))
-            self.rstd.append(torch.empty(B, cout, **f32))
+            fa.z.append(torch.empty(n, r, r, cout, **f32))
+            fa.a.append(torch.empty(n, r, r, cout, device=dev, dtype=T))
+            fa.mean.append(torch.empty(n, cout, **f32))
+            fa.rstd.append(torch.empty(n, cout, **f32))
             self.dz.append(torch.empty(B, r, r, cout, device=dev, dtype=T))
             self.da.append(torch.empty(B, r, r, cout, **f32))
             ns = ops.conv3_wgrad_splits(B, r, cp, cout)
             self.ns.append(ns)
             self.slab.append(torch.empty(ns, cout, 16, cp, **f32))
         # pooled outputs of the four blocks and the gradients that arrive at them (blocks 0..2: from the next conv's dgrad)
-        self.p = [torch.empty(B, self.res[2 * b + 1] // 2, self.res[2 * b + 1] // 2, GS_CONV[2 * b + 1][1], device=dev, dtype=T)
-                  for b in range(4)]
+        fa.p = [torch.empty(n, self.res[2 * b + 1] // 2, self.res[2 * b + 1] // 2, GS_CONV[2 * b + 1][1], device=dev, dtype=T)
+                for b in range(4)]
         self.dp = [torch.empty(B, self.res[2 * b + 1] // 2, self.res[2 * b + 1] // 2, GS_CONV[2 * b + 1][1], **f32)
                    for b in range(3)]
-        self.feat = torch.empty(B, 512, **f32)
-        self.h1, self.h2 = torch.empty(B, 256, **f32), torch.empty(B, 64, **f32)
+        fa.feat = torch.empty(n, 512, **f32)
+        fa.h1, fa.h2 = torch.empty(n, 256, **f32), torch.empty(n, 64, **f32)
         self.dp1, self.dp2, self.dp3 = torch.empty(B, 256, **f32), torch.empty(B, 64, **f32), torch.empty(B, 4, **f32)
         self.dfeat = torch.empty(B, 512, **f32)
-        self.maskbuf = torch.empty(B * (256 + 64), device=dev, dtype=torch.uint8)       # one launch draws both
-        self.masks = [self.maskbuf[:B * 256].view(B, 256), self.maskbuf[B * 256:].view(B, 64)]
+        self.maskbuf = torch.empty(n * (256 + 64), device=dev, dtype=torch.uint8)       # one launch draws both, for every call
+        fa.masks = [self.maskbuf[:n * 256].view(n, 256), self.maskbuf[n * 256:].view(n, 64)]
+        fa.x8 = torch.empty(n, S, S, 8, device=dev, dtype=T)
+        ga = getattr(eng, "gfa", None)                                # the engine's (n, 4) head outputs, shared with the U-Net path
+        fa.traw = ga.traw if ga is not None else eng.g_traw
+        fa.delta = ga.delta if ga is not None else eng.g_delta
+        self.fa = fa
+        self.f = f = fa.group(NG - 1, B)
+        self.z, self.a, self.mean, self.rstd, self.p, self.masks = f.z, f.a, f.mean, f.rstd, f.p, f.masks
+        self.feat, self.h1, self.h2 = f.feat, f.h1, f.h2
         self.w1t, self.w2t = torch.empty(512, 256, **f32), torch.empty(256, 64, **f32)   # transposed head weights (forward)
         self._prep = self._red = None
 
@@ -86,32 +116,53 @@ class SimpleGenerator:
         """The two Dropout(0.5) keep-masks (models.py:205,208): given (fixture / parity mode) or drawn on the device with
         the engine's counter-based generator (same keying as the U-Net's masks: StepEngine._set_masks)."""
         if masks is None:
-            ops.dropout_mask_gen(self.maskbuf, self.eng.seed * 131 + phase, self.eng.G.state)
+            for j, m in enumerate(self.masks):                         # (views into the all-calls buffer: one launch each)
+                ops.dropout_mask_gen(m, self.eng.seed * 131 + phase + 7919 * j, self.eng.G.state)
         else:
             for m, src in zip(self.masks, masks):
                 m.copy_(src)
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, x8: torch.Tensor, train: bool = True) -> torch.Tensor:
-        """models.py:213-216 on an NHWC8 input whose first 3 channels are pred."""
-        eng, B, V = self.eng, self.eng.B, self.eng.G.views
-        src = self.x8 = x8                         # (kept: the first conv's weight gradient contracts against it)
+        """models.py:213-216 on an NHWC8 input whose first 3 channels are pred (the generator step's group)."""
+        self.x8 = x8                                   # (kept: the first conv's weight gradient contracts against it)
+        return self._forward(x8, train, self.f)
+
+    def forward_all(self, pred: torch.Tensor, masks=None) -> None:
+        """All n_critic + 1 generator calls of an iteration as one batch (see StepEngine.g_forward_all)."""
+        eng, fa, B = self.eng, self.fa, self.eng.B
+        ng = fa.n // B
+        ops.pack_pair(pred, None, fa.x8[:B])
+        fa.x8.view(ng, -1)[1:].copy_(fa.x8.view(ng, -1)[0])
+        if masks is None:
+            ops.dropout_mask_gen(self.maskbuf, eng.seed * 131 + 20, eng.G.state)
+        else:
+            for g, pair in enumerate(masks):
+                for m, src in zip(fa.masks, pair):
+                    m[g * B:(g + 1) * B].copy_(src)
+        self.x8 = fa.x8[(ng - 1) * B:]
+        self._forward(fa.x8, True, fa)
+
+    def _forward(self, x8: torch.Tensor, train: bool, f: SFwd) -> torch.Tensor:
+        eng, n, V = self.eng, f.n, self.eng.G.views
+        tag = "" if n == eng.B else f"[n={n}]"
+        src = x8
         for j, (cin, cout) in enumerate(GS_CONV):
             wk, bk = self._w(j)
-            eng._conv(f"GS.c{j + 1}.fwd", conv3_flops(B, self.res[j], cin, cout), ops.conv3_fwd, src, self.wf[j], self.z[j],
+            eng._conv(f"GS.c{j + 1}.fwd{tag}", conv3_flops(n, self.res[j], cin, cout), ops.conv3_fwd, src, self.wf[j], f.z[j],
                       self.cinp[j], cout, bias=V[bk])
-            ops.in_act_fwd(self.z[j], self.a[j], self.mean[j], self.rstd[j], cout, RELU)
+            ops.in_act_fwd(f.z[j], f.a[j], f.mean[j], f.rstd[j], cout, RELU)
             if j & 1:
-                ops.maxpool2_fwd(self.a[j], self.p[j // 2], cout)
-                src = self.p[j // 2]
+                ops.maxpool2_fwd(f.a[j], f.p[j // 2], cout)
+                src = f.p[j // 2]
             else:
-                src = self.a[j]
-        ops.avgpool_fwd(self.p[3], self.feat, 512)
-        m1, m2 = self.masks if train else (None, None)
-        ops.mlp_head_fwd(self.feat, self.w1t, V["regressor.2.bias"], self.w2t,
+                src = f.a[j]
+        ops.avgpool_fwd(f.p[3], f.feat, 512)
+        m1, m2 = f.masks if train else (None, None)
+        ops.mlp_head_fwd(f.feat, self.w1t, V["regressor.2.bias"], self.w2t,
                          V["regressor.5.bias"], V["regressor.8.weight"], V["regressor.8.bias"], eng.delta_scale,
-                         self.h1, self.h2, eng.g_traw, eng.g_delta, m1=m1, m2=m2)
-        return eng.g_delta
+                         f.h1, f.h2, f.traw, f.delta, m1=m1, m2=m2)
+        return f.delta
 
     # ---------------------------------------------------------------------------------------------- backward
     def backward(self, gdelta: torch.Tensor):
