@@ -261,12 +261,13 @@ class StepEngine:
             self.d_wf.append(torch.empty(cout, 16, cp, device=dev, dtype=T))
             self.d_wt.append(torch.empty(cp, 16, cout, device=dev, dtype=T))
         self.d_w5p = torch.empty(16, 512, **f32)
+        unet = self.generator_type == "unet"                      # (the simple generator owns its buffers: gen_simple.py)
         self.gd_wf, self.gd_wt, self.gu_wf, self.gu_wt = [], [], [], []
-        for cin, cout in G_DOWN:
+        for cin, cout in (G_DOWN if unet else ()):
             cp = _pad8(cin)
             self.gd_wf.append(torch.empty(cout, 16, cp, device=dev, dtype=T))
             self.gd_wt.append(torch.empty(cp, 16, cout, device=dev, dtype=T))
-        for cint, coutt in G_UP:        # as a conv: Cout = CinT, Cin = CoutT
+        for cint, coutt in (G_UP if unet else ()):        # as a conv: Cout = CinT, Cin = CoutT
             self.gu_wf.append(torch.empty(cint, 16, coutt, device=dev, dtype=T))
             self.gu_wt.append(torch.empty(coutt, 16, cint, device=dev, dtype=T))
         # ---- critic, 3B batch
@@ -336,6 +337,16 @@ class StepEngine:
         n = NG * B
         ga = GFwd()
         ga.n = n
+        ga.traw = torch.empty(n, 4, **f32)
+        ga.delta = torch.empty(n, 4, **f32)
+        self.gfa = ga
+        self.g_traw, self.g_delta = ga.traw[self.c * B:], ga.delta[self.c * B:]
+        self._gall_valid = False
+        self.ws = torch.empty(2 * N3 * 512, **f32)                 # scratch of the large-map InstanceNorm backward
+        self.g_gdelta = torch.empty(B, 4, **f32)
+        self.g_cal = torch.empty(B, 4, **f32)
+        if not unet:
+            return
         ga.cat3 = act(n, S // 2, 128)          # [up3 out (64) | d1 (64)]
         ga.cat2 = act(n, S // 4, 256)          # [up2 out (128) | d2 (128)]
         ga.cat1 = act(n, S // 8, 512)          # [up1 out (256) | d3 (256)]
@@ -355,19 +366,12 @@ class StepEngine:
         ga.masks = [ga.maskbuf[sum(sizes[:j]):sum(sizes[:j + 1])].view(sh) for j, sh in enumerate(shapes)]
         ga.pooled = torch.empty(n, 64, **f32)
         ga.poolsum = torch.zeros(n, 64, **f32)                     # sum over H*W of u4 (up4's IN apply pass adds, the head consumes and clears)
-        ga.traw = torch.empty(n, 4, **f32)
-        ga.delta = torch.empty(n, 4, **f32)
         ga.x8 = act(n, S, 8)                                       # NHWC8 input of the batched forward (pred, replicated per call)
-        self.gfa = ga
         self.gf = gf = ga.group(self.c, B)
         self.g_cat3, self.g_cat2, self.g_cat1, self.g_d4, self.g_u4 = gf.cat3, gf.cat2, gf.cat1, gf.d4, gf.u4
         self.g_zd, self.g_zu, self.g_dmean, self.g_drstd = gf.zd, gf.zu, gf.dmean, gf.drstd
         self.g_umean, self.g_urstd, self.g_masks = gf.umean, gf.urstd, gf.masks
-        self.g_pooled, self.g_poolsum, self.g_traw, self.g_delta = gf.pooled, gf.poolsum, gf.traw, gf.delta
-        self._gall_valid = False
-        self.ws = torch.empty(2 * N3 * 512, **f32)                 # scratch of the large-map InstanceNorm backward
-        self.g_gdelta = torch.empty(B, 4, **f32)
-        self.g_cal = torch.empty(B, 4, **f32)
+        self.g_pooled, self.g_poolsum = gf.pooled, gf.poolsum
         self.g_dab = torch.empty(B, 64, **f32)
         # generator backward
         self.g_dzu = [act(B, S // 8, 256), act(B, S // 4, 128), act(B, S // 2, 64), act(B, S, 64)]
