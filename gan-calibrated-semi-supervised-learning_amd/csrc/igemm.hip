@@ -168,6 +168,7 @@ struct ConvParams {
     float inv_group_n;  // 1 / group_n (sample -> group index in the epilogues)
     int ldx, ldw, ldy;  // pixel strides (elements); ldw = lddy for wgrad
     int wk;             // 3x3 forms: elements per packed weight row (9*Cin rounded up to 64) = length of the K loop
+    int xcd_remap;      // wgrad: deal the workgroups of a K split to one XCD (A/B knob GCSSL_WGRAD_XCD=0 turns it off)
     int class_major;    // persistent dgrad form: 1 = walk the tiles class by class (A/B knob GCSSL_DGRAD_ORDER=1), 0 = class-interleaved
     int N, Hi, Wi, Cin, Cout;   // conv geometry: x is [N][Hi][Wi][Cin], y is [N][Hi/2][Wi/2][Cout]
     int lgWo, lgHoWo, lgCin, lgCout;
@@ -639,16 +640,30 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
     __shared__ MMajor<T, BM> As[2];
     __shared__ MMajor<T, BN> Bs[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int co0 = blockIdx.x * BM;
+    // All (co-tile, tap, ci-tile) workgroups of one K split read the same dy rows and overlapping x rows.  In dispatch order
+    // (x, then y, then z) they are consecutive and therefore spread over the 8 XCDs, each of which fetches its own copy:
+    // PMC FETCH_SIZE 197 MB per launch of D.c2.wgrad against 50 MB of operands, at 5 TB/s the launch was HBM-bound.
+    // Re-deal the linear workgroup index so that a split's workgroups are consecutive on ONE XCD (index = 8*(per*q + t) + xcd
+    // is split 8q + xcd, tile t of per), sharing its L2.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const int gx = gridDim.x, per = gx * gridDim.y, ns = gridDim.z;      // per: workgroups of one K split
+        const int L = bx + gx * (by + (int)gridDim.y * bz), full = (ns >> 3) * 8 * per;
+        int t;
+        if (L < full) { const int j = L >> 3; bz = (j / per) * 8 + (L & 7); t = j % per; }
+        else { const int r = L - full; bz = (ns & ~7) + r / per; t = r % per; }
+        bx = t % gx; by = t / gx;
+    }
+    const int co0 = bx * BM;
     const int ntile_ci = SMALLC ? 1 : p.Cin / BN;
-    const int tap = SMALLC ? 0 : blockIdx.y / ntile_ci, ci0 = SMALLC ? 0 : (blockIdx.y % ntile_ci) * BN;
+    const int tap = SMALLC ? 0 : by / ntile_ci, ci0 = SMALLC ? 0 : (by % ntile_ci) * BN;
     const int ky = G::ky(tap), kx = G::kx(tap);
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
     const T* x = static_cast<const T*>(p.x);
     const T* dy = static_cast<const T*>(p.w);
     const int Wo = p.Wi / G::ST;
     const int Ktot = p.M;                                      // N*Ho*Wo
-    const int kt_beg = blockIdx.z * p.ktiles_per_split;
+    const int kt_beg = bz * p.ktiles_per_split;
     int kt_end = kt_beg + p.ktiles_per_split;
     const int nkt = (Ktot + BK - 1) / BK;
     if (kt_end > nkt) kt_end = nkt;
@@ -699,7 +714,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
             __syncthreads();
         }
     }
-    float* slab = static_cast<float*>(p.y) + (size_t)blockIdx.z * p.Cout * 16 * p.Cin;
+    float* slab = static_cast<float*>(p.y) + (size_t)bz * p.Cout * 16 * p.Cin;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1317,6 +1332,10 @@ int ksplit_max() {
     static int v = [] { const char* e = getenv("GCSSL_KSPLIT_MAX"); return e ? atoi(e) : 8; }();
     return v;
 }
+int wgrad_xcd() {
+    static int v = [] { const char* e = getenv("GCSSL_WGRAD_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
 int pick_ksplit(long tiles, int nk, bool allowed) {
     if (!allowed || tiles >= 384 || nk < 16 || ksplit_max() <= 1) return 1;
     int ks = (int)((512 + tiles - 1) / tiles);
@@ -1535,6 +1554,7 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
     const int nsplit = gcssl_conv4x4s2_wgrad_splits(N, Hi, Wi, Cin, Cout);
     if (nsplit <= 0) return GCSSL_EBADSHAPE;
     ConvParams p{}; p.x = x; p.w = dy; p.y = slab; p.ldx = ldx; p.ldw = lddy;
+    p.xcd_remap = wgrad_xcd();
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)N * (Hi / 2) * (Wi / 2) * lddy, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
     const int nkt = (p.M + 63) / 64;
@@ -1704,6 +1724,7 @@ int gcssl_conv3x3_wgrad(int dtype, const void* x, int ldx, const void* dy, int l
     const int kv = dtype == GCSSL_F32 ? 4 : 8;
     if (ldx % kv || lddy % kv || !aligned16(x) || !aligned16(dy)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = x; p.w = dy; p.y = slab; p.ldx = ldx; p.ldw = lddy;
+    p.xcd_remap = wgrad_xcd();
     p.N = N; p.Hi = H; p.Wi = W; p.Cin = Cin; p.Cout = Cout;
     p.lgWo = ilog2(W); p.lgHoWo = ilog2(H * W); p.lgCin = ilog2(Cin); p.lgCout = ilog2(Cout);
     p.M = N * H * W;

@@ -16,7 +16,7 @@ import csv, glob, json
 out = {}
 for i, name in ((1, "FETCH_SIZE"), (2, "WRITE_SIZE")):
     f = glob.glob("$OUT/p%d/**/*counter_collection.csv" % i, recursive=True)[0]
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == name and "conv_dma" in r["Kernel_Name"]]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == name and "conv_" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"]]
     vals = vals[len(vals) // 2:]                       # the timed launches (warm)
     out[name] = sum(vals) / len(vals)
     out[name + "_launches"] = len(vals)
