@@ -319,7 +319,7 @@ class StepEngine:
         self.rep_bias_off = [0, 64, 192, 448]                      # c1..c4 bias (64, 128, 256, 512 floats); cdot at 960
         self.cdot = self.scal[0:12].view(4, 3)
         self.gp_sum = self.scal[12:13]
-        self.eiou_acc = self.scal[13:14]
+        self.eiou_acc = torch.zeros(1, **f32)      # (its own tensor: the generator step's first half may run between two critic steps, whose d_main clears zero_blk)
         self.means = self.scal[14:17]
         self.wgan_mean = self.scal[17:18]
         # wgrad slabs: per D layer [chain splits + forward splits]
@@ -740,6 +740,7 @@ class StepEngine:
                       write_clipped=1 if self.keep_clipped_grads else 2, grad_scale=gs)  # :368-369
         self.G.grads_zero = not self.keep_clipped_grads
         self._g_dirty = True
+        self._gall_valid = False                                  # the iteration's batched generator forward is consumed
 
     def g_compute(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
         """The generator step's launches (:345-366).  g_main (forward, EIoU, backward: the gradient) and g_critic (the
@@ -758,11 +759,17 @@ class StepEngine:
         ops.group_mean(self.d_out[:B], 1, self.wgan_mean)                              # loss_WGAN_G = -mean (:362)
 
     def g_main(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
+        """The generator step's forward, loss and backward (:345-366, without the value-only critic forward).  Two halves so
+        that a data-parallel schedule can put one under each critic all-reduce: neither depends on the critic."""
+        self.g_main_a(pred, delta_true, pred_box, refine_fn, masks)
+        self.g_main_b()
+
+    def g_main_a(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
+        """forward (unless the iteration's batched forward already ran), EIoU + its gradient, the re-crop for the critic's
+        value forward, and the backward through the head and the up path"""
         B, S = self.B, self.S
-        self.scal[13:].zero_()
-        if self._gall_valid:               # forward done with the iteration's batch (group n_critic = these very buffers)
-            self._gall_valid = False
-        else:
+        self.eiou_acc.zero_()
+        if not self._gall_valid:           # (else: forward done with the iteration's batch; group n_critic = these very buffers)
             self._prep_g()
             ops.pack_pair(pred, None, self.x0[:B])
             self._set_masks(masks, 1)
@@ -775,8 +782,7 @@ class StepEngine:
         if not self.G.grads_zero:
             self.G.g.zero_()
         self.G.grads_zero = False
-        if self.gen is not None:
-            self.gen.backward(self.g_gdelta)
+        if self.gen is not None:           # (the simple generator's backward is one piece: g_main_b)
             return
         gW = self.G.gviews
         ops.head_bwd(self.g_gdelta, self.g_traw, self.g_pooled, self.G.views["fc_delta.1.weight"], self.delta_scale,
@@ -801,6 +807,16 @@ class StepEngine:
             ns4, st4 = self._split("fwd", self.g_dd4, B, S >> 3, coutt, cint, grad=True) if k == 0 else (1, 0)
             self._conv(f"G.up{k + 1}.dgrad", fl, ops.conv_fwd, self.g_dzu[k], self.gu_wf[k], dcat[k], coutt, cint,
                        split_stride=st4)
+        self._g_dd4_slabs = (ns4, st4)
+        self._join_side()
+
+    def g_main_b(self) -> None:
+        """backward through the down path, then all eight weight gradients reduced in one launch"""
+        if self.gen is not None:
+            self.gen.backward(self.g_gdelta)
+            return
+        B, S = self.B, self.S
+        ns4, st4 = self._g_dd4_slabs
         d_act = [self.g_cat3[..., 64:], self.g_cat2[..., 128:], self.g_cat1[..., 256:]]            # d1, d2, d3
         dskip = [self.g_dcat3[..., 64:], self.g_dcat2[..., 128:], self.g_dcat1[..., 256:]]
         for k in (3, 2, 1, 0):
@@ -935,13 +951,17 @@ class GraphedIteration:
         eng._g_dirty, eng._d_dirty = True, True
         self.first = capture(lambda: (eng.g_forward_all(pred, None) if eng.batch_g else None,
                                       eng.d_pre(pred, gt, refine_fn, 0, None, None), eng.d_main()))
+        # the generator step's own work (forward already done, EIoU, backward) does not depend on the critic: with two or
+        # more critic steps its first half rides with pre[1] under the first critic all-reduce, its second half under the last
         self.pre, self.upd_main = [None], [None]
+        split_g = eng.c >= 2 and eng.batch_g       # (one forward per call would re-pack x0[:B] between two critic steps)
         for k in range(1, eng.c):
             eng._g_dirty = False
-            self.pre.append(capture(lambda k=k: eng.d_pre(pred, gt, refine_fn, k, None, None)))
+            self.pre.append(capture(lambda k=k: (eng.d_pre(pred, gt, refine_fn, k, None, None),
+                                                 eng.g_main_a(pred, delta_true, pred_box, refine_fn, None) if (k == 1 and split_g) else None)))
             self.upd_main.append(capture(lambda: (eng.d_update(gs), eng.d_main())))
         eng._g_dirty = False
-        self.g_main = capture(lambda: eng.g_main(pred, delta_true, pred_box, refine_fn, None))
+        self.g_main = capture(eng.g_main_b if split_g else (lambda: eng.g_main(pred, delta_true, pred_box, refine_fn, None)))
         self.upd_crit = capture(lambda: (eng.d_update(gs), eng.g_critic(pred)))
         self.upd_g = capture(lambda: eng.g_update(gs))
 
