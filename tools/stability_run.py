@@ -1,0 +1,23 @@
+"""3000 graph replays of the bench iteration on a fixed synthetic batch, both generator types: every weight and Adam moment
+must stay finite and the generator must fit its targets (EIoU -> ~0.01).  Experiment tool; run on the GPU box."""
+import importlib, sys, torch
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+PKG = "gan-calibrated-semi-supervised-learning_amd"
+synth = importlib.import_module(PKG + ".synth"); engine = importlib.import_module(PKG + ".engine")
+T = torch.from_numpy
+for gtype in ("unet", "simple"):
+    gsd = synth.simple_generator_state(42) if gtype == "simple" else synth.generator_state(42)
+    g = {k: T(v) for k, v in gsd.items()}; d = {k: T(v) for k, v in synth.discriminator_state(42).items()}
+    B, S, c = 256, 32, 2
+    eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype="bf16", device="cuda:0", keep_clipped_grads=False, generator_type=gtype)
+    inp = synth.step_inputs(42, B, S, c, tag="stab", generator_type=gtype)
+    refined = [T(r).cuda() for r in inp["refined"]]
+    call = (T(inp["pred"]).cuda(), T(inp["gt"]).cuda(), T(inp["delta_true"]).cuda(), T(inp["pred_box"]).cuda(), lambda dl, k: refined[k])
+    for _ in range(3): eng.run_iteration(*call)
+    gi = engine.GraphedIteration(eng, *call)
+    for i in range(3000): gi.replay()
+    torch.cuda.synchronize()
+    ok = bool(torch.isfinite(eng.D.p).all() and torch.isfinite(eng.G.p).all() and torch.isfinite(eng.D.m).all() and torch.isfinite(eng.G.v).all())
+    print(gtype, "finite:", ok, "steps D/G:", float(eng.D.state[0]), float(eng.G.state[0]), "gp", float(eng.gp_sum), "means", eng.means.tolist(), "eiou", 1 + float(eng.eiou_acc),
+          "|D|", float(eng.D.p.norm()), "|G|", float(eng.G.p.norm()))
