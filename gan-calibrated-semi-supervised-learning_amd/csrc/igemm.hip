@@ -1337,8 +1337,10 @@ int wgrad_xcd() {
     return v;
 }
 int pick_ksplit(long tiles, int nk, bool allowed) {
-    if (!allowed || tiles >= 384 || nk < 16 || ksplit_max() <= 1) return 1;
-    int ks = (int)((512 + tiles - 1) / tiles);
+    static const long nosplit = [] { const char* e = getenv("GCSSL_SPLIT_TILES"); return e ? atol(e) : 384L; }();
+    static const long target = [] { const char* e = getenv("GCSSL_SPLIT_TARGET"); return e ? atol(e) : 512L; }();
+    if (!allowed || tiles >= nosplit || nk < 16 || ksplit_max() <= 1) return 1;
+    int ks = (int)((target + tiles - 1) / tiles);
     if (ks > ksplit_max()) ks = ksplit_max();
     while (ks > 1 && nk / ks < 8) --ks;
     return ks;
