@@ -57,7 +57,14 @@ def _worker(rank, world, port, out_dir):
                                     dist_mod.shard(T(inp["delta_true"]), rank, world))
     gkeys = sorted(gg)
     gflat = torch.cat([gg[k].reshape(-1) for k in gkeys])
-    dist_mod.GradAverager()(gflat)
+    # the split form the graphed engine uses: start, (other work), finish without scaling -- the 1/world then rides in the
+    # fused clip+Adam launch (gcssl_clip_adam's grad_scale) -- must leave the SUM, i.e. world * the average
+    avg, summed = gflat.clone(), gflat.clone()
+    dist_mod.GradAverager()(avg)
+    ga = dist_mod.GradAverager()
+    ga.finish(ga.start(summed), summed, scale=False)
+    assert torch.allclose(summed, avg * world, rtol=1e-6, atol=1e-9)
+    gflat = avg
     # spectral-norm buffers stay identical across ranks without any exchange
     u = dl["model.5.weight_u"].clone()
     gathered = [torch.zeros_like(u) for _ in range(world)]
