@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import math
 import os
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, Optional, Sequence
 
 import torch
 
@@ -925,7 +925,6 @@ class GraphedIteration:
         if self.fused_update:
             # single GPU: the whole iteration (critic steps, generator step, all three updates) is ONE graph
             # (GCSSL_ONE_GRAPH=0: one graph per step, for A/B runs)
-            import os
             steps = []
             for k in range(eng.c):
                 steps.append(lambda k=k: (setattr(eng, "_d_dirty", True), setattr(eng, "_g_dirty", k == 0),
