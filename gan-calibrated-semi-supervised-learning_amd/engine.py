@@ -621,10 +621,12 @@ class StepEngine:
         (cgan/losses.py:199) and the packed fake / interpolated groups."""
         B = self.B
         I = slice(2 * B, 3 * B)
-        ops.pack_pair(pred, gt, self.x0[:B])                       # real group; channels 0-2 = pred are G's input too
         if self._gall_valid:                                       # this call was part of the iteration's batched forward
+            if k == 0:                                             # (pred and gt are the iteration's: the real group is packed once)
+                ops.pack_pair(pred, gt, self.x0[:B])
             delta_det = self.gfa.delta[k * B:(k + 1) * B]
         else:
+            ops.pack_pair(pred, gt, self.x0[:B])                   # real group; channels 0-2 = pred are G's input too
             self._prep_g()
             self._set_masks(masks, 10 + k)                         # keyed by (seed, step index, critic step count)
             delta_det = self._g_forward(self.x0[:B], True)
