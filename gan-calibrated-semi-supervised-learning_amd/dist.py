@@ -11,7 +11,10 @@ exactly like single-process semantics (:331,:368), so the norm itself needs no c
 from __future__ import annotations
 
 import os
-from typing import Optional
+import socket
+import subprocess
+import sys
+from typing import Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -88,3 +91,37 @@ def broadcast_state(tensors, src: int = 0, group=None) -> None:
         return
     for t in tensors:
         dist.broadcast(t, src=src, group=group)
+
+
+def launch_local_ranks(argv: Sequence[str], nproc: int, extra_env: Optional[dict] = None, timeout: Optional[float] = None):
+    """Start `nproc` fresh child processes of `argv` (one rank each: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set, rendezvous on 127.0.0.1) and wait for them.  The caller must not have touched the GPU: the children
+    are new processes (never an exec of this one).  Rank 0's stdout is captured and returned; the other ranks' stdout goes
+    to this process's stderr.  -> (exit codes, rank 0's stdout).  If a rank fails the others are terminated."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(nproc):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), **(extra_env or {}))
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    out0, codes = "", [None] * nproc
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+        codes[0] = procs[0].returncode
+        for r in range(1, nproc):
+            codes[r] = procs[r].wait(timeout=60 if codes[0] == 0 else 5)
+    except subprocess.TimeoutExpired:
+        pass
+    finally:
+        for r, pr in enumerate(procs):
+            if pr.poll() is None:                     # a rank that outlives a failed/timed-out peer would hang in a collective
+                pr.terminate()
+                try:
+                    pr.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+                    pr.wait()
+            codes[r] = pr.returncode
+    return codes, out0 or ""

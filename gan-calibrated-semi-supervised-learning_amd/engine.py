@@ -38,17 +38,27 @@ def _pad8(c: int) -> int:
     return max(8, c)
 
 
-def _algorithmic_bytes(label: str, args) -> int:
-    """Bytes a conv launch must move at least once: each operand tensor read once, the result written once (for a wgrad
-    ONE fp32 weight-gradient slab, not one per K split).  Tensors are taken from the launch's own arguments."""
+def _algorithmic_bytes(label: str, args, es: int):
+    """-> (algorithmic, stored) bytes of one conv launch.  Algorithmic is SURVEY.md 8(d)'s definition: the input read once
+    + the result written once + the weights read once, every element at the compute dtype's size `es` (a wgrad's result is
+    ONE weight-gradient tensor, not one slab per K split).  Stored is what the launch's own tensors occupy (fp32 pre-norm
+    outputs, fp32 slabs): stored - algorithmic is traffic the design adds.  Tensors are taken from the launch's arguments."""
     ts = [a for a in args if isinstance(a, torch.Tensor)]
-    total = 0
+    algo = stored = 0
     for i, t in enumerate(ts):
-        n = t.numel() * t.element_size()
+        n = t.numel()
         if label.endswith("wgrad") and t.dim() == 4 and t.dtype == torch.float32 and i == 2:
             n //= t.shape[0]                                          # slab [nsplit][Cout][16][Cin]
-        total += n
-    return total
+        algo += n * es
+        stored += n * t.element_size()
+    return algo, stored
+
+
+def roofline_bound(label: str) -> str:
+    """Which roof bounds a conv launch, per SURVEY.md 8(d): MFMA for every layer with >= 64 input channels (D.c2-c4,
+    G.down2-4, G.up1-4: 334-910 FLOP/B in a 16-bit dtype against a ridge of 312), HBM for the 8-channel first layers."""
+    layer = label.split(".")[1] if "." in label else label
+    return "hbm" if layer in ("c1", "down1") else "mfma"
 
 
 class FlatParams:
@@ -197,11 +207,15 @@ class StepEngine:
         e0.record()
         fn(*args, **kw)
         e1.record()
-        rec = self.probe.setdefault(label, {"events": [], "flops": flops, "bytes": _algorithmic_bytes(label, args)})
+        rec = self.probe.get(label)
+        if rec is None:
+            algo, stored = _algorithmic_bytes(label, args, 4 if self.code == _lib.F32 else 2)
+            rec = self.probe[label] = {"events": [], "flops": flops, "bytes": algo, "stored": stored}
         rec["events"].append((e0, e1))
 
     def probe_summary(self):
-        """-> {label: (n_launches, mean_ms, flops_per_launch, algorithmic_bytes_per_launch)} (synchronises)."""
+        """-> {label: (n_launches, mean_ms, flops_per_launch, algorithmic_bytes_per_launch, stored_bytes_per_launch)}
+        (synchronises)."""
         torch.cuda.synchronize()
         out = {}
         for k, rec in (self.probe or {}).items():
@@ -210,7 +224,7 @@ class StepEngine:
             # its two events: average the samples within 3x the median (all of them, when nothing stalled)
             med = ts[len(ts) // 2] if ts else 0.0
             keep = [t for t in ts if t <= 3.0 * med] or ts
-            out[k] = (len(ts), sum(keep) / max(len(keep), 1), rec["flops"], rec["bytes"])
+            out[k] = (len(ts), sum(keep) / max(len(keep), 1), rec["flops"], rec["bytes"], rec["stored"])
         return out
 
     # ------------------------------------------------------------------------------------------ split-K slabs
@@ -911,6 +925,13 @@ class GraphedIteration:
     def __init__(self, eng: "StepEngine", pred, gt, delta_true, pred_box, refine_fn):
         self.eng = eng
         self.fused_update = eng.allreduce is None
+        # A capture must not depend on host-side state that differs between capture time and replay time.  With
+        # keep_clipped_grads the updates leave the CLIPPED gradient in the bucket (clip_grad_norm_ semantics), so every
+        # backward has to start with its zero fill -- also the first one of a fresh engine, whose buckets happen to be zero:
+        # mark them dirty so that the fill is part of the graph.  (Without keep_clipped_grads the update re-zeroes the bucket
+        # it consumed, on the device, in every replay: the flag is then true at capture time and at every replay.)
+        if eng.keep_clipped_grads:
+            eng.D.grads_zero = eng.G.grads_zero = False
         self.d_graphs, self.g_graph = [], None
         pool = None
 

@@ -204,3 +204,36 @@ def test_infer_script_end_to_end(tmp_path):
     vals = np.array([[float(v) for v in r[1:5]] for r in rows])
     assert np.all(vals[:, :2] >= 0.05) and np.all(vals[:, :2] <= 0.95) and np.all(vals[:, 2:] >= 0.01) and np.all(vals[:, 2:] <= 0.9)
     assert np.abs(vals - np.array([[0.30, 0.35, 0.30, 0.30], [0.70, 0.60, 0.25, 0.40], [0.5, 0.5, 0.2, 0.2]])).max() < 0.2
+
+
+REF_DATA = Path("/root/reference/datasets/500_100_100/cgan")
+
+
+@pytest.mark.skipif(not REF_DATA.exists(), reason="the reference's data directory only exists in the dev container")
+def test_reference_dataset_record():
+    """Row f2 pinned to the reference's own record: its committed W&B run logged dataset/total_samples 18523, train 16671,
+    val 1852 for datasets/500_100_100/cgan at val_split 0.1; our CalibratorDataset + train.split_lengths must reproduce the
+    three numbers, and the sample table must match the committed checksums (tests/golden/make_dataset_golden.py)."""
+    import json
+    sys.path.insert(0, str(ROOT / "tests" / "golden"))
+    mk = importlib.import_module("make_dataset_golden")
+    fix = json.loads((ROOT / "tests" / "golden" / "dataset_500.json").read_text())
+    logged = fix["source"]["reference_logged"]
+    assert logged == dict(total_samples=18523, train_samples=16671, val_samples=1852)
+    ds = DS.CalibratorDataset(REF_DATA)
+    train = importlib.import_module("train")
+    assert len(ds) == logged["total_samples"]
+    assert train.split_lengths(len(ds), fix["source"]["val_split"]) == (logged["train_samples"], logged["val_samples"])
+    rec = mk.dataset_record(ds)
+    for k in ("total_samples", "images", "sha256_names", "sha256_pred_box", "sha256_gt_box"):
+        assert rec[k] == fix[k], k
+    for k in ("delta_sum", "delta_abs_sum"):
+        assert np.allclose(rec[k], fix[k], rtol=1e-9, atol=1e-9), k
+    assert np.allclose(rec["delta_sample"], fix["delta_sample"], rtol=1e-6, atol=1e-7)
+
+
+def test_split_lengths_reference_arithmetic():
+    train = importlib.import_module("train")
+    assert train.split_lengths(18523, 0.1) == (16671, 1852)          # the reference run's logged split
+    assert train.split_lengths(18523, 0.2) == (14819, 3704)          # config.yaml default
+    assert train.split_lengths(3, 0.1) == (2, 1)                     # max(1, ...) keeps one validation sample

@@ -49,7 +49,7 @@ def build_parser(config: dict) -> argparse.ArgumentParser:
     p.add_argument("--lambda_gp", type=float, default=config.get("lambda_gp", 10.0))
     p.add_argument("--n_critic", type=int, default=config.get("n_critic", 5))
     # MI355X-specific
-    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     p.add_argument("--iters_per_epoch", type=int, default=20, help="synthetic source: iterations per epoch")
     p.add_argument("--source", default="synthetic", choices=["synthetic", "dataset"])
     return p
@@ -58,6 +58,32 @@ def build_parser(config: dict) -> argparse.ArgumentParser:
 def load_config() -> dict:
     with open(ROOT / PKG / "config.yaml", "r", encoding="utf-8") as f:
         return yaml.safe_load(f)
+
+
+def split_lengths(n: int, val_split: float):
+    """(train_len, val_len) exactly as cgan/cgan_train_enhanced.py:220-221 computes them (`train_split` is parsed there and
+    never used): 18 523 pairs at val_split 0.1 -> 16 671 / 1 852, the numbers the reference's own run logged."""
+    val_len = max(1, int(val_split * n))
+    return n - val_len, val_len
+
+
+def shard_indices(indices, rank: int, world: int, batch: int):
+    """Rank `rank`'s share of `indices` for data-parallel training: strided, then cut to the number of WHOLE batches the
+    shortest shard holds, so every rank runs the same number of iterations (each iteration all-reduces: one rank with an
+    extra batch would wait for ever)."""
+    per_rank = len(indices) // world                       # the shortest strided shard
+    keep = (per_rank // batch) * batch
+    return list(indices[rank::world][:keep])
+
+
+def allreduce_mean(values, device):
+    """mean over the ranks of a list of python floats (identity without a process group)"""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return list(values)
+    backend = torch.distributed.get_backend()
+    t = torch.tensor(list(values), dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    torch.distributed.all_reduce(t)
+    return (t / torch.distributed.get_world_size()).tolist()
 
 
 def synthetic_source(synth, seed, batch, size, n_critic, device, iters):
@@ -123,9 +149,9 @@ def main(argv=None):
         ds = dataset_mod.CalibratorDataset(args.data_dir, img_size=args.img_size)
         g = torch.Generator().manual_seed(args.seed)
         perm = torch.randperm(len(ds), generator=g).tolist()
-        n_train = int(args.train_split * len(ds))
-        train_idx = perm[:n_train][rank::world]                                      # :219-231 (train part), sharded by rank
-        val_idx = perm[n_train:]                                                     # the validation part (rank 0 evaluates it)
+        n_train, _ = split_lengths(len(ds), args.val_split)
+        train_idx = shard_indices(perm[:n_train], rank, world, args.batch_size // world)   # :219-231 (train part), sharded by rank
+        val_idx = perm[n_train:]                                                     # the validation part (every rank evaluates it: same LR decisions)
         if rank == 0:
             print(f"dataset: {len(ds)} (pred, gt) pairs, {len(train_idx)} for training on this rank, {ds.atlas(device).n} images")
         if len(train_idx) < args.batch_size // world:
@@ -136,7 +162,7 @@ def main(argv=None):
                                                         mode="max", factor=0.5, patience=5) for _ in range(2)]
     out_root = Path(args.save_dir); out_root.mkdir(parents=True, exist_ok=True)
     ckpt_best = out_root / "G_best.pth"
-    best, history = -1.0, []
+    best, history, epochs_no_improve = -1.0, [], 0
     for epoch in range(1, args.n_epochs + 1):
         stats = dict(loss_G=0.0, loss_D=0.0, loss_iou=0.0, loss_wgan=0.0, loss_gp=0.0, wasserstein_distance=0.0)
         n = 0
@@ -160,6 +186,12 @@ def main(argv=None):
         for k in stats:
             stats[k] /= max(n, 1)
         delta_iou = (iou_a - iou_b) / max(n, 1)
+        if world > 1:
+            # every rank must take the same scheduler / early-stop / NaN decisions: a rank-local metric would give the replicas
+            # different learning rates for the same averaged gradient, a rank-local `break` would leave the others in a collective
+            keys = sorted(stats)
+            red = allreduce_mean([stats[k] for k in keys] + [delta_iou], device)
+            stats = dict(zip(keys, red[:-1])); delta_iou = red[-1]
         Bv = args.batch_size // world
         if train_idx is not None and len(val_idx) >= Bv:
             # validation of :395-420 on the held-out pairs: eval-mode G (dropout off), eval-mode box transform, plain IoU
@@ -182,14 +214,21 @@ def main(argv=None):
                   f"dIoU: {delta_iou:.4f}")
         if not all(map(lambda v: v == v and abs(v) != float("inf"), (stats["loss_G"], stats["loss_D"]))):
             print("Warning: NaN or Inf detected in losses! Stopping."); break          # :473-478
-        if rank == 0 and delta_iou > best + args.min_delta:
-            best = delta_iou
-            gsd, dsd = eng.state_dicts()
-            torch.save({"generator": {k: v.cpu() for k, v in gsd.items()},
-                        "discriminator": {k: v.cpu() for k, v in dsd.items()},
-                        "epoch": epoch, "delta_iou": delta_iou,
-                        "config": dict(config, generator_type=args.generator_type, delta_scale=args.delta_scale)},
-                       ckpt_best)                                                       # :481-489 (config as built at :194-214)
+        if delta_iou > best + args.min_delta:                        # (delta_iou is identical on every rank)
+            best, epochs_no_improve = delta_iou, 0
+            if rank == 0:
+                gsd, dsd = eng.state_dicts()
+                torch.save({"generator": {k: v.cpu() for k, v in gsd.items()},
+                            "discriminator": {k: v.cpu() for k, v in dsd.items()},
+                            "epoch": epoch, "delta_iou": delta_iou,
+                            "config": dict(config, generator_type=args.generator_type, delta_scale=args.delta_scale)},
+                           ckpt_best)                                                   # :481-489 (config as built at :194-214)
+        else:
+            epochs_no_improve += 1                                   # :497-500
+            if epochs_no_improve >= args.patience:
+                if rank == 0:
+                    print("Early stopping triggered.")
+                break
     if rank == 0:
         with open(out_root / "training_history.json", "w") as f:
             json.dump(history, f, indent=2)
