@@ -21,7 +21,7 @@ CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libgcssl_hip.so"
 SOURCES = ["igemm.hip", "norm.hip", "misc.hip", "recrop.hip", "simple_gen.hip"]
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ERRORS = {-1: "GCSSL_EBADSHAPE", -2: "GCSSL_EBADDTYPE", -3: "GCSSL_EALIGN", -4: "GCSSL_ENULL"}
 
 _CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
@@ -48,19 +48,37 @@ def parse_header(path: Path = HEADER):
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile the HIP sources for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP sources for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU).
+    One object per source, compiled in parallel (igemm.hip alone is most of the time), then linked."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [CSRC / s for s in SOURCES]
-    deps = srcs + [CSRC / "common.h"]
-    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
-        return LIB_PATH
+    hdr = CSRC / "common.h"
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", str(LIB_PATH)] + [str(s) for s in srcs]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{r.stderr}")
+    objdir = PKG_DIR / "build"
+    objdir.mkdir(exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+    def compile_one(src: Path):
+        obj = objdir / (src.stem + ".o")
+        if not force and obj.exists() and obj.stat().st_mtime >= max(src.stat().st_mtime, hdr.stat().st_mtime):
+            return obj, False
+        cmd = [hipcc] + flags + ["-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stderr}")
+        return obj, True
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+        res = list(ex.map(compile_one, srcs))
+    objs = [o for o, _ in res]
+    if force or any(c for _, c in res) or not LIB_PATH.exists() or any(LIB_PATH.stat().st_mtime < o.stat().st_mtime for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH)] + [str(o) for o in objs]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
     return LIB_PATH
 
 
@@ -121,8 +139,14 @@ def dtype_code(dt) -> int:
         return F32
     if dt in (BF16, "bf16", torch.bfloat16):
         return BF16
+    if dt in (F16, "fp16", "f16", torch.float16):
+        return F16
     raise ValueError(f"unsupported compute dtype {dt!r}")
 
 
 def torch_dtype(code: int):
-    return torch.float32 if code == F32 else torch.bfloat16
+    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[code]
+
+
+def dtype_name(code: int) -> str:
+    return {F32: "fp32", BF16: "bf16", F16: "fp16"}[code]

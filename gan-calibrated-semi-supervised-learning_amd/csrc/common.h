@@ -12,10 +12,22 @@
 
 #define GCSSL_F32 0
 #define GCSSL_BF16 1
+#define GCSSL_F16 2      // IEEE half operands (v_mfma_f32_32x32x16_f16: the bf16 rate, 3 more mantissa bits), fp32 accumulate
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// Run `...` with T bound to the element type of compute dtype `dt` (float / bf16_t / f16_t); the caller has validated dt.
+#define GCSSL_DISPATCH(dt, ...)                                              \
+    do {                                                                     \
+        if ((dt) == GCSSL_F32) { typedef float T; __VA_ARGS__; }             \
+        else if ((dt) == GCSSL_F16) { typedef f16_t T; __VA_ARGS__; }        \
+        else { typedef bf16_t T; __VA_ARGS__; }                              \
+    } while (0)
+static inline bool gcssl_bad_dtype(int dt) { return dt != GCSSL_F32 && dt != GCSSL_BF16 && dt != GCSSL_F16; }
 
 static inline int gcssl_launch_status() {
     hipError_t e = hipGetLastError();
@@ -37,12 +49,28 @@ template <> struct Elem<bf16_t> {
     __device__ static float ld(const bf16_t* p) { return (float)*p; }
     __device__ static void st(bf16_t* p, float v) { *p = (bf16_t)v; }
 };
+template <> struct Elem<f16_t> {
+    static constexpr int KV = 8;
+    __device__ static float ld(const f16_t* p) { return (float)*p; }
+    __device__ static void st(f16_t* p, float v) { *p = (f16_t)v; }     // RNE; beyond 65504 -> inf (visible, not clamped)
+};
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
     bf16_t h = (bf16_t)f;                              // v_cvt_pk_bf16_f32: RNE, NaN-preserving
     return (uint32_t)__builtin_bit_cast(uint16_t, h);
 }
+// 16-bit element <-> its bit pattern in the low half of a word, for either 16-bit operand type
+template <typename T> struct Bits16;
+template <> struct Bits16<bf16_t> {
+    __device__ static __forceinline__ uint32_t enc(float f) { return f32_to_bf16_bits(f); }
+    __device__ static __forceinline__ float dec(uint32_t b) { return bf16_bits_to_f32(b & 0xFFFFu); }
+};
+template <> struct Bits16<f16_t> {
+    __device__ static __forceinline__ uint32_t enc(float f) { return (uint32_t)__builtin_bit_cast(uint16_t, (f16_t)f); }
+    __device__ static __forceinline__ float dec(uint32_t b) { return (float)__builtin_bit_cast(f16_t, (uint16_t)(b & 0xFFFFu)); }
+};
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return Bits16<T>::enc(lo) | (Bits16<T>::enc(hi) << 16); }
 
 // 16-byte vector of elements <-> floats
 template <typename T> struct Vec16;
@@ -54,17 +82,21 @@ template <> struct Vec16<float> {
     __device__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
     __device__ void set(int i, float f) { if (i == 0) v.x = f; else if (i == 1) v.y = f; else if (i == 2) v.z = f; else v.w = f; }
 };
-template <> struct Vec16<bf16_t> {
-    uint4 v;
-    __device__ static Vec16 zero() { Vec16 r; r.v = make_uint4(0, 0, 0, 0); return r; }
-    __device__ static Vec16 load(const bf16_t* p) { Vec16 r; r.v = *reinterpret_cast<const uint4*>(p); return r; }
-    __device__ void store(bf16_t* p) const { *reinterpret_cast<uint4*>(p) = v; }
-    __device__ uint32_t word(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
-    __device__ uint32_t bits(int i) const { uint32_t w = word(i >> 1); return (i & 1) ? (w >> 16) : (w & 0xFFFFu); }
-    __device__ float get(int i) const { return bf16_bits_to_f32(bits(i)); }
-    __device__ void setword(int i, uint32_t w) { if (i == 0) v.x = w; else if (i == 1) v.y = w; else if (i == 2) v.z = w; else v.w = w; }
-    __device__ void set2(int pair, float lo, float hi) { setword(pair, f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16)); }
+#define GCSSL_VEC16_16BIT(TT)                                                                                         \
+template <> struct Vec16<TT> {                                                                                        \
+    uint4 v;                                                                                                          \
+    __device__ static Vec16 zero() { Vec16 r; r.v = make_uint4(0, 0, 0, 0); return r; }                               \
+    __device__ static Vec16 load(const TT* p) { Vec16 r; r.v = *reinterpret_cast<const uint4*>(p); return r; }        \
+    __device__ void store(TT* p) const { *reinterpret_cast<uint4*>(p) = v; }                                          \
+    __device__ uint32_t word(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }                \
+    __device__ uint32_t bits(int i) const { uint32_t w = word(i >> 1); return (i & 1) ? (w >> 16) : (w & 0xFFFFu); }  \
+    __device__ float get(int i) const { return Bits16<TT>::dec(bits(i)); }                                            \
+    __device__ void setword(int i, uint32_t w) { if (i == 0) v.x = w; else if (i == 1) v.y = w; else if (i == 2) v.z = w; else v.w = w; } \
+    __device__ void set2(int pair, float lo, float hi) { setword(pair, pack2<TT>(lo, hi)); }                          \
 };
+GCSSL_VEC16_16BIT(bf16_t)
+GCSSL_VEC16_16BIT(f16_t)
+#undef GCSSL_VEC16_16BIT
 
 // ---- wave / block reductions (wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -24,6 +24,13 @@ namespace {
 // gathers measured at the per-CU L2 gather ceiling, MI355X_MICROARCH.md "Indexed rows: gather into LDS").
 template <typename T> struct BKOf { static constexpr int v = 32; };       // fp32: 32 x 4 B
 template <> struct BKOf<bf16_t> { static constexpr int v = 64; };          // bf16: 64 x 2 B
+template <> struct BKOf<f16_t> { static constexpr int v = 64; };           // fp16: 64 x 2 B
+template <typename T> struct Is16 { static constexpr bool v = !std::is_same<T, float>::value; };   // a 16-bit MFMA operand type
+template <typename T> struct Op16 { typedef T type; };                     // (float -> bf16_t: lets never-taken 16-bit branches of
+template <> struct Op16<float> { typedef bf16_t type; };                   //  the float instantiations compile)
+template <typename T> struct Frag16;                                       // the 32x32x16 MFMA operand of a 16-bit type
+template <> struct Frag16<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag16<f16_t> { typedef f16x8 type; };
 constexpr int NT = 256;      // threads per workgroup: 4 waves as 2 (M) x 2 (N)
 
 // ------------------------------------------------------------------------------------------
@@ -47,19 +54,21 @@ template <int ROWS> struct KMajor<float, ROWS> {
         return d[(row0 + (lane & 31)) * STRIDE + ks * 2 + (lane >> 5)];
     }
 };
-template <int ROWS> struct KMajor<bf16_t, ROWS> {
-    static constexpr int BK = BKOf<bf16_t>::v;
+template <typename T, int ROWS> struct KMajor16 {
+    static constexpr int BK = 64;
     static constexpr int KSTEPS = BK / 16;
-    typedef bf16x8 Frag;
+    typedef typename Frag16<T>::type Frag;
     uint4 d[ROWS * 8];                                        // 128-byte rows of 8 16-byte chunks, XOR-swizzled:
     // a ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) reads one logical chunk of 16 rows; with
     // chunk' = chunk ^ ((row>>1)&7) those land on 16 distinct 16-B slots of the 256-B bank row -> conflict-free.
     __device__ static int swz(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
-    __device__ void store_vec(int row, int chunk, const Vec16<bf16_t>& v) { d[swz(row, chunk)] = v.v; }
+    __device__ void store_vec(int row, int chunk, const Vec16<T>& v) { d[swz(row, chunk)] = v.v; }
     __device__ Frag frag(int row0, int ks, int lane) const {
-        return __builtin_bit_cast(bf16x8, d[swz(row0 + (lane & 31), ks * 2 + (lane >> 5))]);
+        return __builtin_bit_cast(Frag, d[swz(row0 + (lane & 31), ks * 2 + (lane >> 5))]);
     }
 };
+template <int ROWS> struct KMajor<bf16_t, ROWS> : KMajor16<bf16_t, ROWS> {};
+template <int ROWS> struct KMajor<f16_t, ROWS> : KMajor16<f16_t, ROWS> {};
 
 template <typename T, int ROWS> struct MMajor;
 template <int ROWS> struct MMajor<float, ROWS> {
@@ -74,13 +83,13 @@ template <int ROWS> struct MMajor<float, ROWS> {
         return d[(ks * 2 + (lane >> 5)) * ROWS + row0 + (lane & 31)];
     }
 };
-template <int ROWS> struct MMajor<bf16_t, ROWS> {
-    static constexpr int BK = BKOf<bf16_t>::v;
+template <typename T, int ROWS> struct MMajor16 {
+    static constexpr int BK = 64;
     static constexpr int KSTEPS = BK / 16;
     static constexpr int STRIDE = ROWS * 2 + 64;              // bytes; +64 B keeps the 4 rows of a tr block on distinct banks
-    typedef bf16x8 Frag;
+    typedef typename Frag16<T>::type Frag;
     __attribute__((aligned(16))) unsigned char d[BK * STRIDE];
-    __device__ void store_vec(int k, int chunk, const Vec16<bf16_t>& v) {
+    __device__ void store_vec(int k, int chunk, const Vec16<T>& v) {
         *reinterpret_cast<uint4*>(d + k * STRIDE + chunk * 16) = v.v;
     }
     // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(row) block is delivered column-major:
@@ -95,9 +104,11 @@ template <int ROWS> struct MMajor<bf16_t, ROWS> {
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0 + 4 * STRIDE));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8, r);
+        return __builtin_bit_cast(Frag, r);
     }
 };
+template <int ROWS> struct MMajor<bf16_t, ROWS> : MMajor16<bf16_t, ROWS> {};
+template <int ROWS> struct MMajor<f16_t, ROWS> : MMajor16<f16_t, ROWS> {};
 
 // Branch-free gather loads.  hipcc turns `ok ? load(p) : 0` into an exec-mask branch per load (each with its own
 // vmcnt drain), which serialises the whole tile fetch; a raw buffer load with an out-of-range offset returns 0 in
@@ -114,12 +125,18 @@ template <> __device__ __forceinline__ Vec16<float> bload<float>(__amdgpu_buffer
 template <> __device__ __forceinline__ Vec16<bf16_t> bload<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned off) {
     Vec16<bf16_t> v; v.v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); return v;
 }
+template <> __device__ __forceinline__ Vec16<f16_t> bload<f16_t>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    Vec16<f16_t> v; v.v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); return v;
+}
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
 // one BK slab: acc[i][j] += A(rows wm0+32i..) x B(rows wn0+32j..)^T
@@ -431,12 +448,12 @@ typedef __attribute__((address_space(3))) void* lds_void_p;
 
 // WM x WN waves per workgroup (4 or 8 waves); SMALLK: the K-tile spans several taps (first layer, Cin padded to 8),
 // otherwise the tap of a K-tile is wave-uniform and its address arithmetic runs on the scalar unit.
-template <int BM, int BN, int MODE, int WM, int WN, bool SMALLK>
+template <typename T, int BM, int BN, int MODE, int WM, int WN, bool SMALLK>
 __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     // The host pass only needs the launch stub; it silently marks this body invalid (device-only LDS-DMA builtin and
     // inline asm with template-dependent operands) and then emits NO stub, so the body is device-pass only.
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef bf16_t T;
+    typedef typename Frag16<T>::type FragT;
     constexpr int NTH = WM * WN * 64;
     constexpr int BK = 64, ES = 2, KV = 8, CH = 8, RPT = NTH / CH;        // tile rows per pass of the workgroup
     constexpr int NVA = BM / RPT, NVB = BN / RPT, NL = NVA + NVB;          // DMA instructions per wave per K-tile
@@ -534,9 +551,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    auto frag = [&](const unsigned char* tile, int row0, int kstep) -> bf16x8 {
+    auto frag = [&](const unsigned char* tile, int row0, int kstep) -> FragT {
         const int row = row0 + (lane & 31), c = kstep * 2 + (lane >> 5);
-        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)));
+        return __builtin_bit_cast(FragT, *reinterpret_cast<const uint4*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)));
     };
     const int nk_all = K / BK;
     const int t_beg = p.ksplit > 1 ? ks * p.ktiles_per_split : 0;
@@ -556,7 +573,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
             const unsigned char* Bt = At + A_BYTES;
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
-                bf16x8 a[TM], b[TN];
+                FragT a[TM], b[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[i] = frag(At, wm0 + 32 * i, kk);
 #pragma unroll
@@ -742,10 +759,10 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
 // which needs a FIXED number of store instructions per tile: the epilogue is branch-free buffer stores whose
 // out-of-range lanes carry an out-of-bounds offset (dropped by the hardware, still counted).  No split-K here.
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int MODE, int WM, int WN, bool SMALLK = false>
+template <typename T, int BM, int BN, int MODE, int WM, int WN, bool SMALLK = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvParams p, int tiles_m, int tiles_n, int total_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef bf16_t T;
+    typedef typename Frag16<T>::type FragT;
     constexpr int NTH = WM * WN * 64;
     constexpr int BK = 64, ES = 2, KV = 8, CH = 8, RPT = NTH / CH;
     constexpr int NVA = BM / RPT, NVB = BN / RPT, NL = NVA + NVB;
@@ -849,9 +866,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
         for (int j = 0; j < NVB; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_p)(base + a_bytes + j * vstride), 16, a.wrow[j] + woff, 0, 0, 0);
     };
-    auto frag = [&](const unsigned char* tile, int row0, int kstep) -> bf16x8 {
+    auto frag = [&](const unsigned char* tile, int row0, int kstep) -> FragT {
         const int row = row0 + (lane & 31), c = kstep * 2 + (lane >> 5);
-        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)));
+        return __builtin_bit_cast(FragT, *reinterpret_cast<const uint4*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)));
     };
 
     int tile = blockIdx.x;
@@ -887,7 +904,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
             const unsigned char* Bt = At + A_BYTES;
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
-                bf16x8 a[TM], b[TN];
+                FragT a[TM], b[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[i] = frag(At, wm0 + 32 * i, kk);
 #pragma unroll
@@ -937,7 +954,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
                     if (MODE == 0 && p.act == 1) v = lrelu_f(v);
                     const unsigned e = pix * (unsigned)p.ldy + (unsigned)col;
                     if (p.out_f32) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ok ? e * 4u : OOB, 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_bf16_bits(v), yr, ok ? e * 2u : OOB, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b16((unsigned short)Bits16<T>::enc(v), yr, ok ? e * 2u : OOB, 0, 0);
                 }
             }
         if (!has_next) break;
@@ -1117,18 +1134,18 @@ int dma_waves() {
     static int v = [] { const char* e = getenv("GCSSL_DMA_WAVES"); return e ? atoi(e) : 8; }();
     return v;
 }
-template <int BM, int BN, int MODE> struct Dma8 {            // 8-wave form exists only for the 128-row tiles
+template <typename T, int BM, int BN, int MODE> struct Dma8 {            // 8-wave form exists only for the 128-row tiles
     static bool launch(const ConvParams&, dim3, hipStream_t) { return false; }
 };
-template <int MODE> struct Dma8<128, 128, MODE> {
+template <typename T, int MODE> struct Dma8<T, 128, 128, MODE> {
     static bool launch(const ConvParams& p, dim3 grid, hipStream_t st) {
-        hipLaunchKernelGGL((conv_dma_kernel<128, 128, MODE, 2, 4, false>), grid, dim3(512), 0, st, p);
+        hipLaunchKernelGGL((conv_dma_kernel<T, 128, 128, MODE, 2, 4, false>), grid, dim3(512), 0, st, p);
         return true;
     }
 };
-template <int MODE> struct Dma8<128, 64, MODE> {
+template <typename T, int MODE> struct Dma8<T, 128, 64, MODE> {
     static bool launch(const ConvParams& p, dim3 grid, hipStream_t st) {
-        hipLaunchKernelGGL((conv_dma_kernel<128, 64, MODE, 4, 2, false>), grid, dim3(512), 0, st, p);
+        hipLaunchKernelGGL((conv_dma_kernel<T, 128, 64, MODE, 4, 2, false>), grid, dim3(512), 0, st, p);
         return true;
     }
 };
@@ -1141,46 +1158,46 @@ int cu_count() {
     static int v = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
     return v;
 }
-template <int BM, int BN, int MODE> struct Persist {
+template <typename T, int BM, int BN, int MODE> struct Persist {
     static bool launch(const ConvParams&, int, int, int, int, hipStream_t) { return false; }
 };
-template <int MODE> struct Persist<128, 64, MODE> {
+template <typename T, int MODE> struct Persist<T, 128, 64, MODE> {
     static bool launch(const ConvParams& p, int g, int tm, int tn, int total, hipStream_t st) {
-        hipLaunchKernelGGL((conv_dma_persist_kernel<128, 64, MODE, 4, 2>), dim3(g), dim3(512), 0, st, p, tm, tn, total);
+        hipLaunchKernelGGL((conv_dma_persist_kernel<T, 128, 64, MODE, 4, 2>), dim3(g), dim3(512), 0, st, p, tm, tn, total);
         return true;
     }
 };
-template <int MODE> struct Persist<64, 64, MODE> {
+template <typename T, int MODE> struct Persist<T, 64, 64, MODE> {
     static bool launch(const ConvParams& p, int g, int tm, int tn, int total, hipStream_t st) {
-        hipLaunchKernelGGL((conv_dma_persist_kernel<64, 64, MODE, 2, 2>), dim3(g), dim3(256), 0, st, p, tm, tn, total);
+        hipLaunchKernelGGL((conv_dma_persist_kernel<T, 64, 64, MODE, 2, 2>), dim3(g), dim3(256), 0, st, p, tm, tn, total);
         return true;
     }
 };
-template <int BM, int BN, int MODE> struct PersistSmallK {     // 8-channel first layers (K = 128: two K steps per tile)
+template <typename T, int BM, int BN, int MODE> struct PersistSmallK {     // 8-channel first layers (K = 128: two K steps per tile)
     static bool launch(const ConvParams&, int, int, int, int, hipStream_t) { return false; }
 };
-template <> struct PersistSmallK<128, 64, 0> {
+template <typename T> struct PersistSmallK<T, 128, 64, 0> {
     static bool launch(const ConvParams& p, int g, int tm, int tn, int total, hipStream_t st) {
-        hipLaunchKernelGGL((conv_dma_persist_kernel<128, 64, 0, 2, 2, true>), dim3(g), dim3(256), 0, st, p, tm, tn, total);
+        hipLaunchKernelGGL((conv_dma_persist_kernel<T, 128, 64, 0, 2, 2, true>), dim3(g), dim3(256), 0, st, p, tm, tn, total);
         return true;
     }
 };
-template <int BM, int BN, int MODE>
+template <typename T, int BM, int BN, int MODE>
 void launch_dma(const ConvParams& p, dim3 grid, bool smallk, hipStream_t st) {
     if (persist_mode() && p.ksplit <= 1 && p.y_bytes && dma_waves() == 8) {
         const int nk = (MODE == 0 ? 16 * p.Cin : 4 * p.Cout) / 64;
         const int resident = (160 * 1024) / (3 * (BM + BN) * 128);
         const int slots = cu_count() * resident, total = (int)(grid.x * grid.y * grid.z);
         if (nk >= 2 && total > slots + slots / 4) {
-            if (!smallk && Persist<BM, BN, MODE>::launch(p, slots, (int)grid.x, (int)grid.y, total, st)) return;
-            if (smallk && (persist_mode() & 2) && PersistSmallK<BM, BN, MODE>::launch(p, slots, (int)grid.x, (int)grid.y, total, st)) return;
+            if (!smallk && Persist<T, BM, BN, MODE>::launch(p, slots, (int)grid.x, (int)grid.y, total, st)) return;
+            if (smallk && (persist_mode() & 2) && PersistSmallK<T, BM, BN, MODE>::launch(p, slots, (int)grid.x, (int)grid.y, total, st)) return;
         }
     }
-    if (dma_waves() == 8 && !smallk && Dma8<BM, BN, MODE>::launch(p, grid, st)) return;
+    if (dma_waves() == 8 && !smallk && Dma8<T, BM, BN, MODE>::launch(p, grid, st)) return;
     if (smallk) {
-        hipLaunchKernelGGL((conv_dma_kernel<BM, BN, MODE, 2, 2, true>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, MODE, 2, 2, true>), grid, dim3(256), 0, st, p);
     } else {
-        hipLaunchKernelGGL((conv_dma_kernel<BM, BN, MODE, 2, 2, false>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, MODE, 2, 2, false>), grid, dim3(256), 0, st, p);
     }
 }
 
@@ -1194,17 +1211,19 @@ template <> __device__ __forceinline__ void store16<float>(float* dst, const flo
     for (int j = 0; j < 4; ++j)
         reinterpret_cast<float4*>(dst)[j] = make_float4(src[4 * j], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]);
 }
-template <> __device__ __forceinline__ void store16<bf16_t>(bf16_t* dst, const float* src) {
+template <typename T> __device__ __forceinline__ void store16_16(T* dst, const float* src) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         uint4 w;
-        w.x = f32_to_bf16_bits(src[8 * j + 0]) | (f32_to_bf16_bits(src[8 * j + 1]) << 16);
-        w.y = f32_to_bf16_bits(src[8 * j + 2]) | (f32_to_bf16_bits(src[8 * j + 3]) << 16);
-        w.z = f32_to_bf16_bits(src[8 * j + 4]) | (f32_to_bf16_bits(src[8 * j + 5]) << 16);
-        w.w = f32_to_bf16_bits(src[8 * j + 6]) | (f32_to_bf16_bits(src[8 * j + 7]) << 16);
+        w.x = pack2<T>(src[8 * j + 0], src[8 * j + 1]);
+        w.y = pack2<T>(src[8 * j + 2], src[8 * j + 3]);
+        w.z = pack2<T>(src[8 * j + 4], src[8 * j + 5]);
+        w.w = pack2<T>(src[8 * j + 6], src[8 * j + 7]);
         reinterpret_cast<uint4*>(dst)[j] = w;
     }
 }
+template <> __device__ __forceinline__ void store16<bf16_t>(bf16_t* dst, const float* src) { store16_16<bf16_t>(dst, src); }
+template <> __device__ __forceinline__ void store16<f16_t>(f16_t* dst, const float* src) { store16_16<f16_t>(dst, src); }
 
 // The re-pack is a pair of transposes of w[co][ci][tap]: Wf[co][tap][ci] makes ci the fast axis, Wt[ci][tap][co] makes
 // co the fast axis.  Each goes through an LDS tile shaped so that BOTH the fp32 reads and the packed writes are full
@@ -1271,7 +1290,7 @@ template <typename T, int BM, int BN>
 int launch_fwd(const ConvParams& p, hipStream_t st) {
     if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
-    if (std::is_same<T, bf16_t>::value && use_dma()) launch_dma<BM, BN, 0>(p, grid, p.Cin < 64, st);
+    if (Is16<T>::v && use_dma()) launch_dma<typename Op16<T>::type, BM, BN, 0>(p, grid, p.Cin < 64, st);
     else hipLaunchKernelGGL((conv_fwd_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
 }
@@ -1279,7 +1298,7 @@ template <typename T, int BM, int BN>
 int launch_dgrad(const ConvParams& p, hipStream_t st) {
     if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cin + BN - 1) / BN, 4 * (p.ksplit > 1 ? p.ksplit : 1));
-    if (std::is_same<T, bf16_t>::value && use_dma()) launch_dma<BM, BN, 1>(p, grid, false, st);
+    if (Is16<T>::v && use_dma()) launch_dma<typename Op16<T>::type, BM, BN, 1>(p, grid, false, st);
     else hipLaunchKernelGGL((conv_dgrad_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
 }
@@ -1360,33 +1379,33 @@ const char* forced_tile() {
     static const char* v = getenv("GCSSL_FORCE_TILE");       // "256x128", "256x64", "128x128", "128x64", "64x64": experiments
     return v;
 }
-template <int BM, int BN, int MODE> struct PersistBig {       // 256x128 has 64 epilogue stores per wave: beyond the 6-bit vmcnt
+template <typename T, int BM, int BN, int MODE> struct PersistBig {       // 256x128 has 64 epilogue stores per wave: beyond the 6-bit vmcnt
     static bool launch(const ConvParams&, int, int, int, int, hipStream_t) { return false; }
 };
-template <int MODE> struct PersistBig<256, 64, MODE> {
+template <typename T, int MODE> struct PersistBig<T, 256, 64, MODE> {
     static bool launch(const ConvParams& p, int g, int tm, int tn, int total, hipStream_t st) {
-        hipLaunchKernelGGL((conv_dma_persist_kernel<256, 64, MODE, 4, 2>), dim3(g), dim3(512), 0, st, p, tm, tn, total);
+        hipLaunchKernelGGL((conv_dma_persist_kernel<T, 256, 64, MODE, 4, 2>), dim3(g), dim3(512), 0, st, p, tm, tn, total);
         return true;
     }
 };
-template <int BM, int BN, int MODE>
+template <typename T, int BM, int BN, int MODE>
 int launch_big(const ConvParams& p, hipStream_t st) {
     if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     const int ncols = MODE == 0 ? p.Cout : p.Cin;
     dim3 grid((p.M + BM - 1) / BM, (ncols + BN - 1) / BN, (MODE == 1 ? 4 : 1) * (p.ksplit > 1 ? p.ksplit : 1));
     const int total = (int)(grid.x * grid.y * grid.z), slots = cu_count();          // 120-144 KB of LDS: one per CU
     if (persist_mode() && p.ksplit <= 1 && p.y_bytes && total > slots + slots / 4 &&
-        PersistBig<BM, BN, MODE>::launch(p, slots, (int)grid.x, (int)grid.y, total, st)) return gcssl_launch_status();
-    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, MODE, 4, 2, false>), grid, dim3(512), 0, st, p);
+        PersistBig<T, BM, BN, MODE>::launch(p, slots, (int)grid.x, (int)grid.y, total, st)) return gcssl_launch_status();
+    hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, MODE, 4, 2, false>), grid, dim3(512), 0, st, p);
     return gcssl_launch_status();
 }
 
 template <typename T>
 int dispatch_fwd(ConvParams p, hipStream_t st) {
-    if (std::is_same<T, bf16_t>::value && use_dma() && p.Cin >= 64) {
+    if (Is16<T>::v && use_dma() && p.Cin >= 64) {
         const char* f = forced_tile();
-        if (f && !strcmp(f, "256x128") && p.Cout >= 128) return launch_big<256, 128, 0>(p, st);
-        if (f && !strcmp(f, "256x64")) return launch_big<256, 64, 0>(p, st);
+        if (f && !strcmp(f, "256x128") && p.Cout >= 128) return launch_big<typename Op16<T>::type, 256, 128, 0>(p, st);
+        if (f && !strcmp(f, "256x64")) return launch_big<typename Op16<T>::type, 256, 64, 0>(p, st);
         if (f && !strcmp(f, "128x128") && p.Cout >= 128) return launch_fwd<T, 128, 128>(p, st);
         if (f && !strcmp(f, "128x64")) return launch_fwd<T, 128, 64>(p, st);
     }
@@ -1399,7 +1418,7 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
     const bool split_ok = f32out && p.act == 0;
     // small-M layers: split K.  With the LDS-DMA kernels a K step costs about the same for a 128x64 tile (8 waves) as
     // for a 64x64 one (4 waves), so prefer half as many, twice as deep... twice as WIDE workgroups with twice the split
-    if (split_tile() == 128 && std::is_same<T, bf16_t>::value && use_dma() && p.Cin >= 64 && p.Cout >= 64 && p.M >= 128) {
+    if (split_tile() == 128 && Is16<T>::v && use_dma() && p.Cin >= 64 && p.Cout >= 64 && p.M >= 128) {
         const long t = (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
         p.ksplit = pick_ksplit(t, nk, split_ok);
         if (p.ksplit > 1) {
@@ -1419,10 +1438,10 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
 }
 template <typename T>
 int dispatch_dgrad(ConvParams p, hipStream_t st) {
-    if (std::is_same<T, bf16_t>::value && use_dma() && p.Cin >= 64) {
+    if (Is16<T>::v && use_dma() && p.Cin >= 64) {
         const char* f = forced_tile();
-        if (f && !strcmp(f, "256x128") && p.Cin >= 128) return launch_big<256, 128, 1>(p, st);
-        if (f && !strcmp(f, "256x64")) return launch_big<256, 64, 1>(p, st);
+        if (f && !strcmp(f, "256x128") && p.Cin >= 128) return launch_big<typename Op16<T>::type, 256, 128, 1>(p, st);
+        if (f && !strcmp(f, "256x64")) return launch_big<typename Op16<T>::type, 256, 64, 1>(p, st);
         if (f && !strcmp(f, "128x128") && p.Cin >= 128) return launch_dgrad<T, 128, 128>(p, st);
         if (f && !strcmp(f, "128x64")) return launch_dgrad<T, 128, 64>(p, st);
     }
@@ -1432,7 +1451,7 @@ int dispatch_dgrad(ConvParams p, hipStream_t st) {
     const long t64 = 4L * ((p.M + 63) / 64) * ((p.Cin + 63) / 64);
     const int nk = 4 * p.Cout / BKOf<T>::v;
     const bool f32out = p.out_f32 || std::is_same<T, float>::value;
-    if (split_tile() == 128 && std::is_same<T, bf16_t>::value && use_dma() && p.Cin >= 64 && p.Cout >= 64 && p.M >= 128) {
+    if (split_tile() == 128 && Is16<T>::v && use_dma() && p.Cin >= 64 && p.Cout >= 64 && p.M >= 128) {
         const long t = 4L * ((p.M + 127) / 128) * ((p.Cin + 63) / 64);
         p.ksplit = pick_ksplit(t, nk, f32out);
         if (p.ksplit > 1) {
@@ -1462,7 +1481,8 @@ int gcssl_conv4x4s2_fwd_splits(int dtype, int N, int Hi, int Wi, int Cin, int Co
     int ks = 1;
     ConvParams p{}; p.act = act; p.out_f32 = out_f32; p.plan_out = &ks; p.ldx = Cin; p.ldy = Cout; p.y_bytes = 1;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
-    rc = dtype == GCSSL_F32 ? dispatch_fwd<float>(p, nullptr) : (dtype == GCSSL_BF16 ? dispatch_fwd<bf16_t>(p, nullptr) : GCSSL_EBADDTYPE);
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH(dtype, rc = dispatch_fwd<T>(p, nullptr));
     return rc ? rc : ks;
 }
 int gcssl_conv4x4s2_dgrad_splits(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int out_f32) {
@@ -1471,7 +1491,8 @@ int gcssl_conv4x4s2_dgrad_splits(int dtype, int N, int Hi, int Wi, int Cin, int 
     int ks = 1;
     ConvParams p{}; p.out_f32 = out_f32; p.plan_out = &ks; p.ldx = Cout; p.ldy = Cin; p.y_bytes = 1;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
-    rc = dtype == GCSSL_F32 ? dispatch_dgrad<float>(p, nullptr) : (dtype == GCSSL_BF16 ? dispatch_dgrad<bf16_t>(p, nullptr) : GCSSL_EBADDTYPE);
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH(dtype, rc = dispatch_dgrad<T>(p, nullptr));
     return rc ? rc : ks;
 }
 
@@ -1494,8 +1515,8 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
         p.y_bytes = yb < 0x7FFFFFFFull ? (unsigned)yb : 0u;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == GCSSL_F32) return dispatch_fwd<float>(p, st);
-    if (dtype == GCSSL_BF16) return dispatch_fwd<bf16_t>(p, st);
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH(dtype, return dispatch_fwd<T>(p, st));
     return GCSSL_EBADDTYPE;
 }
 
@@ -1520,8 +1541,8 @@ int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, c
         p.y_bytes = yb < 0x7FFFFFFFull ? (unsigned)yb : 0u;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == GCSSL_F32) return dispatch_dgrad<float>(p, st);
-    if (dtype == GCSSL_BF16) return dispatch_dgrad<bf16_t>(p, st);
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH(dtype, return dispatch_dgrad<T>(p, st));
     return GCSSL_EBADDTYPE;
 }
 
@@ -1569,15 +1590,11 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
     const bool smallc = Cin == 8;
     dim3 grid(Cout / bm, smallc ? 1 : 16 * (Cin / bn), nsplit);
 #define WG(T, A, B, S) hipLaunchKernelGGL((conv_wgrad_kernel<T, A, B, S>), grid, dim3(NT), 0, st, p)
-    if (dtype == GCSSL_F32) {
-        if (smallc) { if (bm == 128) WG(float, 128, 128, true); else WG(float, 64, 128, true); }
-        else if (bm == 128 && bn == 128) WG(float, 128, 128, false); else if (bm == 128) WG(float, 128, 64, false);
-        else if (bn == 128) WG(float, 64, 128, false); else WG(float, 64, 64, false);
-    } else if (dtype == GCSSL_BF16) {
-        if (smallc) { if (bm == 128) WG(bf16_t, 128, 128, true); else WG(bf16_t, 64, 128, true); }
-        else if (bm == 128 && bn == 128) WG(bf16_t, 128, 128, false); else if (bm == 128) WG(bf16_t, 128, 64, false);
-        else if (bn == 128) WG(bf16_t, 64, 128, false); else WG(bf16_t, 64, 64, false);
-    } else return GCSSL_EBADDTYPE;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH(dtype,
+        if (smallc) { if (bm == 128) WG(T, 128, 128, true); else WG(T, 64, 128, true); }
+        else if (bm == 128 && bn == 128) WG(T, 128, 128, false); else if (bm == 128) WG(T, 128, 64, false);
+        else if (bn == 128) WG(T, 64, 128, false); else WG(T, 64, 64, false));
 #undef WG
     return gcssl_launch_status();
 }
@@ -1633,9 +1650,8 @@ int gcssl_prep_conv_weights(int dtype, int nl, const float* const* w, void* cons
     }
     unsigned gx = (unsigned)((mx + 4095) / 4096); if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;     // one 4096-element tile per pass
     dim3 grid(gx, nl, 2);
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(prep_weight_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, b);
-    else if (dtype == GCSSL_BF16) hipLaunchKernelGGL(prep_weight_batch_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, b);
-    else return GCSSL_EBADDTYPE;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(prep_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b));
     return gcssl_launch_status();
 }
 
@@ -1645,13 +1661,8 @@ int gcssl_prep_conv_weight(int dtype, const float* w, void* wf, void* wt, int Co
     if (Cout <= 0 || Cin <= 0 || CinP < Cin) return GCSSL_EBADSHAPE;
     const size_t total = (size_t)Cout * 16 * CinP;
     dim3 grid((unsigned)((total + 255) / 256));
-    if (dtype == GCSSL_F32)
-        hipLaunchKernelGGL(prep_weight_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, w,
-                           (float*)wf, (float*)wt, Cout, Cin, CinP);
-    else if (dtype == GCSSL_BF16)
-        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, w,
-                           (bf16_t*)wf, (bf16_t*)wt, Cout, Cin, CinP);
-    else return GCSSL_EBADDTYPE;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(prep_weight_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, w, (T*)wf, (T*)wt, Cout, Cin, CinP));
     return gcssl_launch_status();
 }
 
@@ -1667,7 +1678,7 @@ int gcssl_conv3x3_fwd(int dtype, const void* x, int ldx, const void* w, const fl
     if (rc) return rc;
     if (Cout < 64 || ldx < Cin || ldy < Cout) return GCSSL_EBADSHAPE;
     const int kv = dtype == GCSSL_F32 ? 4 : 8;
-    if (dtype != GCSSL_F32 && dtype != GCSSL_BF16) return GCSSL_EBADDTYPE;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (ldx % kv || !aligned16(x) || !aligned16(w)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = x; p.w = w; p.y = y; p.bias = bias; p.ldx = ldx; p.ldy = ldy; p.out_f32 = out_f32;
     p.N = N; p.Hi = H; p.Wi = W; p.Cin = Cin; p.Cout = Cout; p.wk = wk3(Cin);
@@ -1682,24 +1693,25 @@ int gcssl_conv3x3_fwd(int dtype, const void* x, int ldx, const void* w, const fl
     const bool big = (long)((p.M + 127) / 128) * (Cout / 64) >= 256;
     dim3 grid((p.M + (big ? 127 : 63)) / (big ? 128 : 64), Cout / 64, 1);
     static const bool dma3 = [] { const char* e = getenv("GCSSL_CONV3_DMA"); return !(e && e[0] == '0'); }();   // A/B knob
-    if (dtype == GCSSL_BF16 && use_dma() && dma3) {            // LDS-DMA pipeline (MODE 2 of conv_dma_kernel)
-        if (Cin < 64) {                                        // 8-channel first layer: a K tile spans several taps
-            if (big) hipLaunchKernelGGL((conv_dma_kernel<128, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((conv_dma_kernel<64, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p);
-        } else if (big) {
-            // more tiles than resident workgroups: the persistent form (the DMA ring never drains between tiles)
-            const int slots = cu_count() * ((160 * 1024) / (3 * (128 + 64) * 128)), total = (int)(grid.x * grid.y);
-            if ((persist_mode() & 1) && p.y_bytes && total > slots + slots / 4)
-                hipLaunchKernelGGL((conv_dma_persist_kernel<128, 64, 2, 4, 2>), dim3(slots), dim3(512), 0, st, p, (int)grid.x, (int)grid.y, total);
-            else hipLaunchKernelGGL((conv_dma_kernel<128, 64, 2, 4, 2, false>), grid, dim3(512), 0, st, p);
-        }
-        else hipLaunchKernelGGL((conv_dma_kernel<64, 64, 2, 2, 2, false>), grid, dim3(256), 0, st, p);
+    if (dtype != GCSSL_F32 && use_dma() && dma3) {             // LDS-DMA pipeline (MODE 2 of conv_dma_kernel)
+#define DMA3(T) do { \
+        if (Cin < 64) {                                        /* 8-channel first layer: a K tile spans several taps */ \
+            if (big) hipLaunchKernelGGL((conv_dma_kernel<T, 128, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p); \
+            else hipLaunchKernelGGL((conv_dma_kernel<T, 64, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p); \
+        } else if (big) { \
+            /* more tiles than resident workgroups: the persistent form (the DMA ring never drains between tiles) */ \
+            const int slots = cu_count() * ((160 * 1024) / (3 * (128 + 64) * 128)), total = (int)(grid.x * grid.y); \
+            if ((persist_mode() & 1) && p.y_bytes && total > slots + slots / 4) \
+                hipLaunchKernelGGL((conv_dma_persist_kernel<T, 128, 64, 2, 4, 2>), dim3(slots), dim3(512), 0, st, p, (int)grid.x, (int)grid.y, total); \
+            else hipLaunchKernelGGL((conv_dma_kernel<T, 128, 64, 2, 4, 2, false>), grid, dim3(512), 0, st, p); \
+        } \
+        else hipLaunchKernelGGL((conv_dma_kernel<T, 64, 64, 2, 2, 2, false>), grid, dim3(256), 0, st, p); } while (0)
+        if (dtype == GCSSL_F16) DMA3(f16_t); else DMA3(bf16_t);
+#undef DMA3
         return gcssl_launch_status();
     }
-#define C3(T, BM) hipLaunchKernelGGL((conv_fwd_kernel<T, BM, 64, 3>), grid, dim3(NT), 0, st, p)
-    if (dtype == GCSSL_F32) { if (big) C3(float, 128); else C3(float, 64); }
-    else { if (big) C3(bf16_t, 128); else C3(bf16_t, 64); }
-#undef C3
+    GCSSL_DISPATCH(dtype, if (big) hipLaunchKernelGGL((conv_fwd_kernel<T, 128, 64, 3>), grid, dim3(NT), 0, st, p);
+                          else hipLaunchKernelGGL((conv_fwd_kernel<T, 64, 64, 3>), grid, dim3(NT), 0, st, p));
     return gcssl_launch_status();
 }
 
@@ -1725,7 +1737,7 @@ int gcssl_conv3x3_wgrad(int dtype, const void* x, int ldx, const void* dy, int l
     const int nsplit = gcssl_conv3x3_wgrad_splits(N, H, W, Cin, Cout);
     if (nsplit <= 0) return GCSSL_EBADSHAPE;
     if (ldx < Cin || lddy < Cout) return GCSSL_EBADSHAPE;
-    if (dtype != GCSSL_F32 && dtype != GCSSL_BF16) return GCSSL_EBADDTYPE;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     const int kv = dtype == GCSSL_F32 ? 4 : 8;
     if (ldx % kv || lddy % kv || !aligned16(x) || !aligned16(dy)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = x; p.w = dy; p.y = slab; p.ldx = ldx; p.ldw = lddy;
@@ -1741,15 +1753,10 @@ int gcssl_conv3x3_wgrad(int dtype, const void* x, int ldx, const void* dy, int l
     const bool smallc = Cin == 8;
     dim3 grid(Cout / bm, smallc ? 1 : 9 * (Cin / bn), nsplit);
 #define WG(T, A, B, S) hipLaunchKernelGGL((conv_wgrad_kernel<T, A, B, S, 3>), grid, dim3(NT), 0, st, p)
-    if (dtype == GCSSL_F32) {
-        if (smallc) { if (bm == 128) WG(float, 128, 128, true); else WG(float, 64, 128, true); }
-        else if (bm == 128 && bn == 128) WG(float, 128, 128, false); else if (bm == 128) WG(float, 128, 64, false);
-        else if (bn == 128) WG(float, 64, 128, false); else WG(float, 64, 64, false);
-    } else {
-        if (smallc) { if (bm == 128) WG(bf16_t, 128, 128, true); else WG(bf16_t, 64, 128, true); }
-        else if (bm == 128 && bn == 128) WG(bf16_t, 128, 128, false); else if (bm == 128) WG(bf16_t, 128, 64, false);
-        else if (bn == 128) WG(bf16_t, 64, 128, false); else WG(bf16_t, 64, 64, false);
-    }
+    GCSSL_DISPATCH(dtype,
+        if (smallc) { if (bm == 128) WG(T, 128, 128, true); else WG(T, 64, 128, true); }
+        else if (bm == 128 && bn == 128) WG(T, 128, 128, false); else if (bm == 128) WG(T, 128, 64, false);
+        else if (bn == 128) WG(T, 64, 128, false); else WG(T, 64, 64, false));
 #undef WG
     return gcssl_launch_status();
 }
@@ -1787,9 +1794,8 @@ int gcssl_conv3x3_prep_weights(int dtype, int nl, const float* const* w, void* c
     }
     unsigned gx = (unsigned)((mx + 1023) / 1024); if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
     dim3 grid(gx, nl);
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(prep3_weight_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, b);
-    else if (dtype == GCSSL_BF16) hipLaunchKernelGGL(prep3_weight_batch_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, b);
-    else return GCSSL_EBADDTYPE;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(prep3_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b));
     return gcssl_launch_status();
 }
 

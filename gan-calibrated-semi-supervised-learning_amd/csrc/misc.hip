@@ -8,7 +8,7 @@
 
 namespace {
 
-bool bad_dtype(int dt) { return dt != GCSSL_F32 && dt != GCSSL_BF16; }
+bool bad_dtype(int dt) { return gcssl_bad_dtype(dt); }
 
 // =========================================================================================
 // boundary: NCHW fp32 (B,3,S,S) pairs -> NHWC [B][S*S][8] (channels 0-2 = a, 3-5 = b, 6-7 = 0)
@@ -641,8 +641,7 @@ int gcssl_pack_pair(int dtype, const float* a, const float* b, void* out, int B,
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (B <= 0 || S <= 0) return GCSSL_EBADSHAPE;
     const size_t n = (size_t)B * S * S;
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(pack_pair_kernel<float>, GRID1(n), a, b, nullptr, nullptr, (float*)out, B, S * S);
-    else hipLaunchKernelGGL(pack_pair_kernel<bf16_t>, GRID1(n), a, b, nullptr, nullptr, (bf16_t*)out, B, S * S);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(pack_pair_kernel<T>, GRID1(n), a, b, nullptr, nullptr, (T*)out, B, S * S));
     return gcssl_launch_status();
 }
 
@@ -652,8 +651,7 @@ int gcssl_pack_interp(int dtype, const float* pred, const float* gt, const float
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (B <= 0 || S <= 0) return GCSSL_EBADSHAPE;
     const size_t n = (size_t)B * S * S;
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(pack_pair_kernel<float>, GRID1(n), pred, gt, refined, alpha, (float*)out, B, S * S);
-    else hipLaunchKernelGGL(pack_pair_kernel<bf16_t>, GRID1(n), pred, gt, refined, alpha, (bf16_t*)out, B, S * S);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(pack_pair_kernel<T>, GRID1(n), pred, gt, refined, alpha, (T*)out, B, S * S));
     return gcssl_launch_status();
 }
 
@@ -664,8 +662,7 @@ int gcssl_pack_fake_interp(int dtype, const float* pred, const float* gt, const 
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (B <= 0 || S <= 0) return GCSSL_EBADSHAPE;
     const size_t n = (size_t)B * S * S;
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(pack_fake_interp_kernel<float>, GRID1(n), pred, gt, refined, alpha, (uint64_t)seed, counter, (float*)out_fake, (float*)out_interp, B, S * S);
-    else hipLaunchKernelGGL(pack_fake_interp_kernel<bf16_t>, GRID1(n), pred, gt, refined, alpha, (uint64_t)seed, counter, (bf16_t*)out_fake, (bf16_t*)out_interp, B, S * S);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(pack_fake_interp_kernel<T>, GRID1(n), pred, gt, refined, alpha, (uint64_t)seed, counter, (T*)out_fake, (T*)out_interp, B, S * S));
     return gcssl_launch_status();
 }
 
@@ -689,8 +686,7 @@ int gcssl_conv4x4s1_c1_fwd(int dtype, const void* x, int ldx, const float* wp, f
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || ldx < C) return GCSSL_EBADSHAPE;
     const size_t threads = (size_t)N * (Hi - 1) * (Wi - 1) * 64;
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(c5_fwd_kernel<float>, GRID1(threads), (const float*)x, ldx, wp, out, N, Hi, Wi, C);
-    else hipLaunchKernelGGL(c5_fwd_kernel<bf16_t>, GRID1(threads), (const bf16_t*)x, ldx, wp, out, N, Hi, Wi, C);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(c5_fwd_kernel<T>, GRID1(threads), (const T*)x, ldx, wp, out, N, Hi, Wi, C));
     return gcssl_launch_status();
 }
 
@@ -700,8 +696,7 @@ int gcssl_conv4x4s1_c1_dgrad(int dtype, const float* dout, float g0, float g1, f
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || lddx < C || (!dout && group_n <= 0)) return GCSSL_EBADSHAPE;
     const size_t n = (size_t)N * Hi * Wi * C;
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(c5_dgrad_kernel<float>, GRID1(n), dout, g0, g1, g2, group_n, wp, (float*)dx, lddx, N, Hi, Wi, C);
-    else hipLaunchKernelGGL(c5_dgrad_kernel<bf16_t>, GRID1(n), dout, g0, g1, g2, group_n, wp, (bf16_t*)dx, lddx, N, Hi, Wi, C);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(c5_dgrad_kernel<T>, GRID1(n), dout, g0, g1, g2, group_n, wp, (T*)dx, lddx, N, Hi, Wi, C));
     return gcssl_launch_status();
 }
 
@@ -714,8 +709,7 @@ int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dou
     int zs = N * zcap / 768; if (zs < 1) zs = 1; if (zs > zcap) zs = zcap;
     const int per = (N + zs - 1) / zs;
     dim3 grid((C + 63) / 64, zs);
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(c5_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C, per);
-    else hipLaunchKernelGGL(c5_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C, per);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(c5_wgrad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C, per));
     return gcssl_launch_status();
 }
 
@@ -754,10 +748,8 @@ int gcssl_gp_norm(const float* g, long per_sample, int B, float lambda_gp, float
     if (!g || !nrm || !coef || !gp_sum) return GCSSL_ENULL;
     if (per_sample <= 0 || B <= 0) return GCSSL_EBADSHAPE;
     if (scaled && bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    if (scaled && dtype == GCSSL_BF16)
-        hipLaunchKernelGGL(gp_norm_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, g, (size_t)per_sample, B, lambda_gp, nrm, coef, gp_sum, (bf16_t*)scaled);
-    else
-        hipLaunchKernelGGL(gp_norm_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, g, (size_t)per_sample, B, lambda_gp, nrm, coef, gp_sum, (float*)scaled);
+    if (!scaled) dtype = GCSSL_F32;
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(gp_norm_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, g, (size_t)per_sample, B, lambda_gp, nrm, coef, gp_sum, (T*)scaled));
     return gcssl_launch_status();
 }
 
@@ -766,8 +758,7 @@ int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (per_sample <= 0 || B <= 0) return GCSSL_EBADSHAPE;
     const size_t total = (size_t)per_sample * B;
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(scale_rows_kernel<float>, GRID1(total), x, coef, (float*)y, (size_t)per_sample, total);
-    else hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, GRID1(total), x, coef, (bf16_t*)y, (size_t)per_sample, total);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(scale_rows_kernel<T>, GRID1(total), x, coef, (T*)y, (size_t)per_sample, total));
     return gcssl_launch_status();
 }
 
@@ -792,8 +783,7 @@ int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, float* pool_sum, c
     if ((!x && !pool_sum) || !w || !bias || !pooled || !traw || !delta) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (B <= 0 || HW <= 0 || C != 64 || ldx < C) return GCSSL_EBADSHAPE;
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(pool_fc_tanh_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, pool_sum, w, bias, scale, pooled, traw, delta, HW);
-    else hipLaunchKernelGGL(pool_fc_tanh_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, pool_sum, w, bias, scale, pooled, traw, delta, HW);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(pool_fc_tanh_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, pool_sum, w, bias, scale, pooled, traw, delta, HW));
     return gcssl_launch_status();
 }
 
@@ -866,8 +856,7 @@ int gcssl_cast(int dtype, const float* x, void* y, long n, void* stream) {
     if (!x || !y) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (n <= 0) return GCSSL_EBADSHAPE;
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(cast_kernel<float>, GRID1(n), x, (float*)y, (size_t)n);
-    else hipLaunchKernelGGL(cast_kernel<bf16_t>, GRID1(n), x, (bf16_t*)y, (size_t)n);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(cast_kernel<T>, GRID1(n), x, (T*)y, (size_t)n));
     return gcssl_launch_status();
 }
 
@@ -875,8 +864,7 @@ int gcssl_uncast(int dtype, const void* x, float* y, long n, void* stream) {
     if (!x || !y) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (n <= 0) return GCSSL_EBADSHAPE;
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(uncast_kernel<float>, GRID1(n), (const float*)x, y, (size_t)n);
-    else hipLaunchKernelGGL(uncast_kernel<bf16_t>, GRID1(n), (const bf16_t*)x, y, (size_t)n);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(uncast_kernel<T>, GRID1(n), (const T*)x, y, (size_t)n));
     return gcssl_launch_status();
 }
 

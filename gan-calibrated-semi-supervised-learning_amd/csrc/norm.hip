@@ -106,19 +106,23 @@ template <typename T> __device__ __forceinline__ void st4(T* p, const float (&v)
 template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v)[VC]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
-template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&v)[VC]) {
+template <typename T> __device__ __forceinline__ void st4_16(T* p, const float (&v)[VC]) {
     uint2 w;
-    w.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
-    w.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+    w.x = pack2<T>(v[0], v[1]);
+    w.y = pack2<T>(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = w;
 }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&v)[VC]) { st4_16<bf16_t>(p, v); }
+template <> __device__ __forceinline__ void st4<f16_t>(f16_t* p, const float (&v)[VC]) { st4_16<f16_t>(p, v); }
 template <typename T> __device__ __forceinline__ void ldT4(const T* p, float (&o)[VC]);
 template <> __device__ __forceinline__ void ldT4<float>(const float* p, float (&o)[VC]) { ld4(p, o); }
-template <> __device__ __forceinline__ void ldT4<bf16_t>(const bf16_t* p, float (&o)[VC]) {
+template <typename T> __device__ __forceinline__ void ldT4_16(const T* p, float (&o)[VC]) {
     const uint2 w = *reinterpret_cast<const uint2*>(p);
-    o[0] = bf16_bits_to_f32(w.x & 0xFFFFu); o[1] = bf16_bits_to_f32(w.x >> 16);
-    o[2] = bf16_bits_to_f32(w.y & 0xFFFFu); o[3] = bf16_bits_to_f32(w.y >> 16);
+    o[0] = Bits16<T>::dec(w.x); o[1] = Bits16<T>::dec(w.x >> 16);
+    o[2] = Bits16<T>::dec(w.y); o[3] = Bits16<T>::dec(w.y >> 16);
 }
+template <> __device__ __forceinline__ void ldT4<bf16_t>(const bf16_t* p, float (&o)[VC]) { ldT4_16<bf16_t>(p, o); }
+template <> __device__ __forceinline__ void ldT4<f16_t>(const f16_t* p, float (&o)[VC]) { ldT4_16<f16_t>(p, o); }
 __device__ __forceinline__ void keep4(const uint8_t* mp, float (&k)[VC]) {
     const uint32_t w = *reinterpret_cast<const uint32_t*>(mp);
 #pragma unroll
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(256) void dot_accum_kernel(const T* __restrict__ x,
 // Same-address float atomics serialise (~12 ns each, and a 256-byte bias vector shares a few memory-side lines): 768
 // workgroups adding 64 bias sums each cost 70 us on a 17-us pass (tools/actbwd_bench.py).  The sums therefore go to one of
 // nrep replicas chosen by workgroup index; gcssl_sum_replicas folds them afterwards.
-bool bad_dtype(int dt) { return dt != GCSSL_F32 && dt != GCSSL_BF16; }
+bool bad_dtype(int dt) { return gcssl_bad_dtype(dt); }
 
 // row-group lanes per sample for a small map, and samples per workgroup (a multiple of the samples per pass that keeps
 // >= ~256 workgroups and, when per-group sums are accumulated, never straddles a sample group)
@@ -802,10 +806,12 @@ extern "C" {
 // the LDS-resident forward needs the 128-KB dynamic-LDS opt-in; done once, outside any stream capture (gcssl_init)
 int gcssl_init_norm() {
     const int bytes = (int)(LDS_HW_MAX * 32 * sizeof(float));
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<bf16_t, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<float, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<bf16_t, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes / 2);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<float, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes / 2);
+    hipError_t e = hipSuccess;
+#define OPT_IN(T) do { \
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<T, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(in_fwd_lds_kernel<T, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes / 2); } while (0)
+    OPT_IN(bf16_t); OPT_IN(f16_t); OPT_IN(float);
+#undef OPT_IN
     return e == hipSuccess ? GCSSL_OK : (int)e;
 }
 
@@ -822,13 +828,9 @@ int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean
         dim3 grid(C / CW, (N + spb - 1) / spb);
 #define FWD_SMALL(T, RG, MR) do { if (nslab > 1) hipLaunchKernelGGL((in_fwd_small_kernel<T, RG, MR, true>), grid, dim3(CGN * RGN), 0, st, z, ldz, (T*)a, lda, mean, rstd, mask, N, HW, C, act, spb, nslab, slab_stride); \
                                   else hipLaunchKernelGGL((in_fwd_small_kernel<T, RG, MR, false>), grid, dim3(CGN * RGN), 0, st, z, ldz, (T*)a, lda, mean, rstd, mask, N, HW, C, act, spb, nslab, slab_stride); } while (0)
-        if (dtype == GCSSL_F32) {
-            if (rg == 1) FWD_SMALL(float, 1, MAXR); else if (rg == 4) FWD_SMALL(float, 4, MAXR);
-            else if (HW <= SMALL_HW) FWD_SMALL(float, 16, MAXR); else FWD_SMALL(float, 16, BIGR);
-        } else {
-            if (rg == 1) FWD_SMALL(bf16_t, 1, MAXR); else if (rg == 4) FWD_SMALL(bf16_t, 4, MAXR);
-            else if (HW <= SMALL_HW) FWD_SMALL(bf16_t, 16, MAXR); else FWD_SMALL(bf16_t, 16, BIGR);
-        }
+        GCSSL_DISPATCH(dtype,
+            if (rg == 1) FWD_SMALL(T, 1, MAXR); else if (rg == 4) FWD_SMALL(T, 4, MAXR);
+            else if (HW <= SMALL_HW) FWD_SMALL(T, 16, MAXR); else FWD_SMALL(T, 16, BIGR));
 #undef FWD_SMALL
         return gcssl_launch_status();
     }
@@ -839,8 +841,7 @@ int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean
         if (!inited) { int rc = gcssl_init_norm(); if (rc) return rc; inited = true; }
         dim3 g2(C / lds_ch, N);
 #define LDS_FWD(T, CHN) hipLaunchKernelGGL((in_fwd_lds_kernel<T, CHN>), g2, dim3(256), lds, st, z, ldz, (T*)a, lda, mean, rstd, mask, pool, HW, C, act)
-        if (dtype == GCSSL_F32) { if (lds_ch == 16) LDS_FWD(float, 16); else LDS_FWD(float, 32); }
-        else { if (lds_ch == 16) LDS_FWD(bf16_t, 16); else LDS_FWD(bf16_t, 32); }
+        GCSSL_DISPATCH(dtype, if (lds_ch == 16) LDS_FWD(T, 16); else LDS_FWD(T, 32));
 #undef LDS_FWD
         return gcssl_launch_status();
     }
@@ -853,8 +854,7 @@ int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean
     }
     hipLaunchKernelGGL(in_stats_kernel, grid, dim3(CGN * RGN), 0, st, z, ldz, mean, rstd, HW, C);
     hipLaunchKernelGGL(in_finalize_kernel, dim3((unsigned)(((size_t)N * C + 255) / 256)), dim3(256), 0, st, z, ldz, mean, rstd, N, HW, C);
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(CGN * RGN), 0, st, z, ldz, (float*)a, lda, mean, rstd, mask, pool, HW, C, act);
-    else hipLaunchKernelGGL(in_apply_kernel<bf16_t>, grid, dim3(CGN * RGN), 0, st, z, ldz, (bf16_t*)a, lda, mean, rstd, mask, pool, HW, C, act);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(in_apply_kernel<T>, grid, dim3(CGN * RGN), 0, st, z, ldz, (T*)a, lda, mean, rstd, mask, pool, HW, C, act));
     return gcssl_launch_status();
 }
 
@@ -880,25 +880,17 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
         dim3 grid(C / CW, (N + spb - 1) / spb);
 #define BWD_SMALL(T, RG, MR) do { if (da_nslab > 1) hipLaunchKernelGGL((in_bwd_small_kernel<T, RG, MR, true>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed); \
                                   else hipLaunchKernelGGL((in_bwd_small_kernel<T, RG, MR, false>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed); } while (0)
-        if (dtype == GCSSL_F32) {
-            if (rg == 1) BWD_SMALL(float, 1, MAXR); else if (rg == 4) BWD_SMALL(float, 4, MAXR);
-            else if (HW <= SMALL_HW) BWD_SMALL(float, 16, MAXR); else BWD_SMALL(float, 16, BIGR);
-        } else {
-            if (rg == 1) BWD_SMALL(bf16_t, 1, MAXR); else if (rg == 4) BWD_SMALL(bf16_t, 4, MAXR);
-            else if (HW <= SMALL_HW) BWD_SMALL(bf16_t, 16, MAXR); else BWD_SMALL(bf16_t, 16, BIGR);
-        }
+        GCSSL_DISPATCH(dtype,
+            if (rg == 1) BWD_SMALL(T, 1, MAXR); else if (rg == 4) BWD_SMALL(T, 4, MAXR);
+            else if (HW <= SMALL_HW) BWD_SMALL(T, 16, MAXR); else BWD_SMALL(T, 16, BIGR));
 #undef BWD_SMALL
         return gcssl_launch_status();
     }
     dim3 grid(C / CW, N, (HW + SMALL_HW - 1) / SMALL_HW);
     hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)N * C, st);
-    if (dtype == GCSSL_F32) {
-        hipLaunchKernelGGL((in_bwd_kernel<float, 1>), grid, dim3(CGN * RGN), 0, st, q, ws);
-        hipLaunchKernelGGL((in_bwd_kernel<float, 2>), grid, dim3(CGN * RGN), 0, st, q, ws);
-    } else {
-        hipLaunchKernelGGL((in_bwd_kernel<bf16_t, 1>), grid, dim3(CGN * RGN), 0, st, q, ws);
-        hipLaunchKernelGGL((in_bwd_kernel<bf16_t, 2>), grid, dim3(CGN * RGN), 0, st, q, ws);
-    }
+    GCSSL_DISPATCH(dtype,
+        hipLaunchKernelGGL((in_bwd_kernel<T, 1>), grid, dim3(CGN * RGN), 0, st, q, ws);
+        hipLaunchKernelGGL((in_bwd_kernel<T, 2>), grid, dim3(CGN * RGN), 0, st, q, ws));
     return gcssl_launch_status();
 }
 
@@ -918,14 +910,12 @@ int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, in
         hipStream_t st = (hipStream_t)stream;
 #define DBL_SMALL(T, RG) do { if (q_nslab > 1) hipLaunchKernelGGL((in_dbl_small_kernel<T, RG, true>), sgrid, dim3(CGN * RGN), 0, st, q, N, spb); \
                               else hipLaunchKernelGGL((in_dbl_small_kernel<T, RG, false>), sgrid, dim3(CGN * RGN), 0, st, q, N, spb); } while (0)
-        if (dtype == GCSSL_F32) { if (rg == 1) DBL_SMALL(float, 1); else if (rg == 4) DBL_SMALL(float, 4); else DBL_SMALL(float, 16); }
-        else { if (rg == 1) DBL_SMALL(bf16_t, 1); else if (rg == 4) DBL_SMALL(bf16_t, 4); else DBL_SMALL(bf16_t, 16); }
+        GCSSL_DISPATCH(dtype, if (rg == 1) DBL_SMALL(T, 1); else if (rg == 4) DBL_SMALL(T, 4); else DBL_SMALL(T, 16));
 #undef DBL_SMALL
         return gcssl_launch_status();
     }
     dim3 grid(C / CW, N);
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(in_dbl_bwd_kernel<float>, grid, dim3(CW * RG), 0, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL(in_dbl_bwd_kernel<bf16_t>, grid, dim3(CW * RG), 0, (hipStream_t)stream, q);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(in_dbl_bwd_kernel<T>, grid, dim3(CW * RG), 0, (hipStream_t)stream, q));
     return gcssl_launch_status();
 }
 
@@ -948,8 +938,7 @@ int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ld
            (!cdot || q.group_n % (spb * 2) == 0)) spb *= 2;
     const int mixed = (cdot && q.group_n % spb) ? 1 : 0;
     dim3 grid(C / CW, (N + spb - 1) / spb, zc);
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, grid, dim3(CGN * RGN), 0, (hipStream_t)stream, q, N, spb, rows, mixed);
-    else hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, grid, dim3(CGN * RGN), 0, (hipStream_t)stream, q, N, spb, rows, mixed);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, grid, dim3(CGN * RGN), 0, (hipStream_t)stream, q, N, spb, rows, mixed));
     return gcssl_launch_status();
 }
 
@@ -961,12 +950,8 @@ int gcssl_dot_accum(int dtype, const void* x, int ldx, const float* y, int ldy, 
     const size_t total = (size_t)pixels * C;
     if (C % 4 || ldx % 4 || ldy % 4) return GCSSL_EBADSHAPE;
     int blocks = (int)((total / 4 + 255) / 256); if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
-    if (dtype == GCSSL_F32)
-        hipLaunchKernelGGL(dot_accum_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx,
-                           y, ldy, (size_t)pixels, C, out);
-    else
-        hipLaunchKernelGGL(dot_accum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                           y, ldy, (size_t)pixels, C, out);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(dot_accum_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx,
+                                             y, ldy, (size_t)pixels, C, out));
     return gcssl_launch_status();
 }
 

@@ -276,32 +276,26 @@ extern "C" {
 
 int gcssl_maxpool2_fwd(int dtype, const void* a, int lda, void* o, int ldo, int N, int H, int W, int C, void* stream) {
     if (!a || !o) return GCSSL_ENULL;
-    if (dtype != GCSSL_F32 && dtype != GCSSL_BF16) return GCSSL_EBADDTYPE;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     const int kv = dtype == GCSSL_F32 ? 4 : 8;
     if (N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C <= 0 || C % kv || lda < C || ldo < C) return GCSSL_EBADSHAPE;
     if (lda % kv || ldo % kv || !aligned16(a) || !aligned16(o)) return GCSSL_EALIGN;
     const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / kv);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == GCSSL_F32)
-        hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)a, lda, (float*)o, ldo, N, H, W, C);
-    else
-        hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)a, lda, (bf16_t*)o, ldo, N, H, W, C);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)a, lda, (T*)o, ldo, N, H, W, C));
     return gcssl_launch_status();
 }
 
 int gcssl_maxpool2_bwd(int dtype, const void* a, int lda, const float* dpool, int ldd, int bcast, float bscale, float* da,
                        int ldda, int N, int H, int W, int C, void* stream) {
     if (!a || !dpool || !da) return GCSSL_ENULL;
-    if (dtype != GCSSL_F32 && dtype != GCSSL_BF16) return GCSSL_EBADDTYPE;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     const int kv = dtype == GCSSL_F32 ? 4 : 8;
     if (N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C <= 0 || C % kv || lda < C || ldd < C || ldda < C) return GCSSL_EBADSHAPE;
     if (lda % kv || !aligned16(a)) return GCSSL_EALIGN;
     const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / kv);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == GCSSL_F32)
-        hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)a, lda, dpool, ldd, bcast, bscale, da, ldda, N, H, W, C);
-    else
-        hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)a, lda, dpool, ldd, bcast, bscale, da, ldda, N, H, W, C);
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)a, lda, dpool, ldd, bcast, bscale, da, ldda, N, H, W, C));
     return gcssl_launch_status();
 }
 
@@ -310,9 +304,8 @@ int gcssl_avgpool_fwd(int dtype, const void* x, int ldx, float* feat, int N, int
     if (N <= 0 || HW <= 0 || C <= 0 || ldx < C) return GCSSL_EBADSHAPE;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(((size_t)N * C + 255) / 256));
-    if (dtype == GCSSL_F32) hipLaunchKernelGGL(avgpool_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, feat, N, HW, C);
-    else if (dtype == GCSSL_BF16) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, feat, N, HW, C);
-    else return GCSSL_EBADDTYPE;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(avgpool_kernel<T>, grid, dim3(256), 0, st, (const T*)x, ldx, feat, N, HW, C));
     return gcssl_launch_status();
 }
 

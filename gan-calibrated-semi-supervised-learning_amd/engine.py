@@ -116,7 +116,11 @@ def conv_flops(n: int, hi: int, cin: int, cout: int) -> float:
 class StepEngine:
     """Holds G and D (weights, Adam state, spectral-norm u/v) on one GPU and runs reference-ordered iterations.
 
-    dtype: "fp32" (exact fp32 MFMA; the parity mode) or "bf16" (bf16 operands, fp32 accumulate; throughput mode).
+    dtype: "fp32" (exact fp32 MFMA; the parity mode), "bf16" or "fp16" (16-bit MFMA operands, fp32 accumulate: the
+    throughput modes).  fp16 has 3 more mantissa bits than bf16 and 5 exponent bits: the backward passes run on gradients
+    multiplied by a static loss scale (loss_scale_d / loss_scale_g, powers of two: every backward quantity is linear in its
+    seed) and the fused clip+Adam launch divides it out again, so small gradients stay in fp16's normal range; losses,
+    statistics, weight gradients and optimiser state are fp32 (BASELINE configs[3]: "fp16 with fp32 loss accum").
     ``allreduce(flat_grad)`` (optional) is called on the flat D / G gradient right before clip+Adam: the data-parallel
     hook (dist.py).  ``refine_fn(delta, k)`` stands in for the host re-crop stage ``get_refined_patch_batch``
     (cgan/cgan_train_enhanced.py:37-137): it must return a (B,3,S,S) fp32 NCHW tensor with no dependence path
@@ -141,6 +145,12 @@ class StepEngine:
         self.delta_scale, self.lambda_gp, self.lambda_iou = delta_scale, lambda_gp, lambda_iou
         self.seed = seed
         self.allreduce = allreduce
+        # static loss scales of the fp16 mode (1 elsewhere: bf16 and fp32 have fp32's exponent range).  Unscaled, the critic's
+        # backward runs at ~1e-4 and the generator's at ~1e-6 per element (seeds 1/(B hw) and 1/(B S^2)): at and below fp16's
+        # smallest normal 6e-5.  x1024 / x4096 puts both near 1e-1..1e-3, five orders of magnitude under the 65504 ceiling.
+        f16 = self.code == _lib.F16
+        self.loss_scale_d = float(os.environ.get("GCSSL_LOSS_SCALE_D", 1024.0 if f16 else 1.0))
+        self.loss_scale_g = float(os.environ.get("GCSSL_LOSS_SCALE_G", 4096.0 if f16 else 1.0))
         self.keep_clipped_grads = keep_clipped_grads     # write g*clip_coef back like clip_grad_norm_ does (not needed to step)
         _lib.lib()                                                  # fail loudly now if the HIP library is missing
         _lib.call_nostream("gcssl_init")                            # dynamic-LDS opt-ins, before any graph capture
@@ -614,7 +624,7 @@ class StepEngine:
         elif self.allreduce is not None:
             self.allreduce(self.D.g)
         ops.clip_adam(self.D.p, self.D.g, self.D.m, self.D.v, self.D.state, self.lr, self.betas[0], self.betas[1],
-                      write_clipped=1 if self.keep_clipped_grads else 2, grad_scale=gs)   # 2: the update also re-zeroes the bucket
+                      write_clipped=1 if self.keep_clipped_grads else 2, grad_scale=gs / self.loss_scale_d)   # 2: the update also re-zeroes the bucket
         self.D.grads_zero = not self.keep_clipped_grads
         self._d_dirty = True
 
@@ -681,7 +691,8 @@ class StepEngine:
         ops.act_bwd(self.gb_a[0], self.d_a[0][I], self.gb_zs[0], 64, gscale=isig[0, 2:3], group_n=B)
         self._conv("D.c1.gp_dgrad", conv_flops(B, S, 6, 64), ops.conv_dgrad, self.gb_zs[0], self.d_wt[0], self.gb_x0, 8, 64)
         # :223-231, and the seed of the reverse pass (gb_x0 * coef, the create_graph=True part of d_loss.backward(), :330)
-        ops.gp_norm(self.gb_x0, B, self.lambda_gp, self.gp_nrm, self.gp_coef, self.gp_sum, scaled=self.gt_x)
+        # (lambda_gp only enters the adjoint seed coef/scaled, not gp_sum: the critic's loss scale rides on it)
+        ops.gp_norm(self.gb_x0, B, self.lambda_gp * self.loss_scale_d, self.gp_nrm, self.gp_coef, self.gp_sum, scaled=self.gt_x)
         src = self.gt_x
         for l, (cin, cout) in enumerate(D_CH):
             cp = _pad8(cin)
@@ -702,7 +713,8 @@ class StepEngine:
         ops.c5_wgrad(self.gt_a[3], gw5, 512, consts=(1.0, 1.0, 1.0), group_n=B)
         # ---- backward of the three forwards, batched: seeds -1/(B hw), +1/(B hw), 0  (:327-330)
         hw = self.h5 * self.h5
-        seeds = (-1.0 / (B * hw), 1.0 / (B * hw), 0.0)
+        ls = self.loss_scale_d
+        seeds = (-ls / (B * hw), ls / (B * hw), 0.0)
         ops.c5_wgrad(self.d_a[3], gw5, 512, consts=seeds, group_n=B)
         ops.c5_dgrad(self.d_da[3], self.d_w5p, consts=seeds, group_n=B)
         for l in (3, 2, 1, 0):
@@ -753,7 +765,7 @@ class StepEngine:
         elif self.allreduce is not None:
             self.allreduce(self.G.g)
         ops.clip_adam(self.G.p, self.G.g, self.G.m, self.G.v, self.G.state, self.lr, self.betas[0], self.betas[1],
-                      write_clipped=1 if self.keep_clipped_grads else 2, grad_scale=gs)  # :368-369
+                      write_clipped=1 if self.keep_clipped_grads else 2, grad_scale=gs / self.loss_scale_g)  # :368-369
         self.G.grads_zero = not self.keep_clipped_grads
         self._g_dirty = True
         self._gall_valid = False                                  # the iteration's batched generator forward is consumed
@@ -790,7 +802,8 @@ class StepEngine:
             ops.pack_pair(pred, None, self.x0[:B])
             self._set_masks(masks, 1)
             self._g_forward(self.x0[:B], True)                                         # :348
-        ops.eiou_fwd_bwd(pred_box, self.g_delta, delta_true, self.lambda_iou, self.g_gdelta, self.g_cal,
+        # (lambda_iou only scales the gradient g_gdelta, not the accumulated loss: the generator's loss scale rides on it)
+        ops.eiou_fwd_bwd(pred_box, self.g_delta, delta_true, self.lambda_iou * self.loss_scale_g, self.g_gdelta, self.g_cal,
                          self.eiou_acc)                                                # :351-355
         self.delta_pred = self.g_delta                  # (alias: valid until the next generator forward; iteration() clones it)
         self._refined_g = refine_fn(self.delta_pred, self.c)                           # :358-360

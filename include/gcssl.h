@@ -8,8 +8,10 @@
  *     (including all workspaces); the library keeps no device state.
  *   - `stream` is a hipStream_t; kernels are only enqueued on it, never synchronised (graph-capture safe).
  *   - return value: 0 ok; <0 argument error (GCSSL_E*); >0 a hipError_t from the launch.  Never throws.
- *   - dtype: element type of activations/operands (GCSSL_F32 exact-fp32 MFMA, GCSSL_BF16 bf16 MFMA with fp32
- *     accumulation).  Statistics, losses, weight gradients, master weights and optimiser state are always fp32.
+ *   - dtype: element type of activations/operands (GCSSL_F32 exact-fp32 MFMA; GCSSL_BF16 / GCSSL_F16 bf16 / IEEE-half
+ *     MFMA operands with fp32 accumulation -- the same kernels and rate, fp16 trades exponent range for 3 more mantissa
+ *     bits: BASELINE configs[3] "fp16 with fp32 loss accum").  Statistics, losses, weight gradients, master weights and
+ *     optimiser state are always fp32.
  *   - activations are NHWC: tensor[n][y][x][c] with an explicit pixel stride `ld*` (elements) so a kernel can
  *     read/write a channel slice of a concat buffer in place; spatial sizes and channel counts are powers of 2.
  */
@@ -27,6 +29,7 @@ extern "C" {
 #define GCSSL_ENULL (-4)
 #define GCSSL_F32 0
 #define GCSSL_BF16 1
+#define GCSSL_F16 2
 
 const char* gcssl_version(void);
 /* One-time device-side set-up (dynamic-LDS opt-ins of the kernels that use > 64 KB).  Call once per process with a GPU

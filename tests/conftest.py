@@ -54,14 +54,16 @@ def check_pinned(fix: dict, name: str, t, rtol: float, synth_mod) -> float:
     return max(e1, e2)
 
 
-def check_grad(fix: dict, name: str, t, synth_mod, rtol: float, frac_ok: float = 0.95, norm_rtol: float = 5e-3) -> float:
-    """Gradient comparison that tolerates activation-kink flips.
+def check_grad(fix: dict, name: str, t, synth_mod, rtol: float, frac_ok: float = 0.98, norm_rtol: float = 5e-3,
+               outlier_rtol: float = 5e-2) -> float:
+    """Gradient comparison that tolerates activation-kink flips -- and nothing else.
 
     A weight gradient is a sum over >1e5 positions of (upstream grad x ReLU/LeakyReLU mask x input).  When a
     pre-activation sits within fp32 rounding of 0 (measured: 2 of 524288 elements of G.up4 at S=64 have |xhat| < 1e-6)
     the two implementations may take different branches; that one element moves every weight-gradient entry of its
-    channel by ~1e-2 of the tensor's max although everything upstream agrees to 1e-6.  A flip is localised (one channel),
-    a real bug is not, so: at least `frac_ok` of the pinned elements must agree within `rtol` of the tensor scale, and
+    channel by ~1e-2 of the tensor's max although everything upstream agrees to 1e-6.  A flip is localised (one channel: at
+    most 1.6 % of a tensor's entries) and small, a real bug is neither, so: at least `frac_ok` of the pinned elements must
+    agree within `rtol` of the tensor scale, EVERY element within `outlier_rtol` (no entry may be arbitrarily wrong), and
     the full-tensor L2 norm within `norm_rtol`."""
     a = np.asarray(t, dtype=np.float64).reshape(-1)
     if name in fix:
@@ -72,7 +74,9 @@ def check_grad(fix: dict, name: str, t, synth_mod, rtol: float, frac_ok: float =
         b = np.asarray(fix[name + "@sample"], dtype=np.float64)
         nrm_ref = float(fix[name + "@norm"])
     scale = max(np.abs(b).max(), 1e-30)
-    good = float((np.abs(sel - b) <= rtol * scale).mean())
+    err = np.abs(sel - b) / scale
+    good = float((err <= rtol).mean())
     e_n = abs(float(np.sqrt((a ** 2).sum())) - nrm_ref) / max(nrm_ref, 1e-30)
-    assert good >= frac_ok and e_n <= norm_rtol, f"{name}: {good:.3f} of elements within {rtol}, norm err {e_n:.2e}"
+    assert good >= frac_ok and e_n <= norm_rtol and float(err.max()) <= outlier_rtol, \
+        f"{name}: {good:.3f} of elements within {rtol}, worst {float(err.max()):.2e}, norm err {e_n:.2e}"
     return 1.0 - good

@@ -3,7 +3,8 @@
 
 Tolerances (relative to each tensor's scale):
   fp32 mode (exact-fp32 MFMA): 1e-3 is the north-star bound; we assert 2e-4 on first-iteration outputs.
-  bf16 mode (bf16 operands / activations, fp32 accumulation): 6e-2 on scores/losses -- reported, not the parity mode.
+  bf16 / fp16 modes (16-bit MFMA operands / activations, fp32 accumulation): the measured error per quantity, with 2x
+  headroom (test_16bit_mode_error_vs_oracle at the bench size; fp16 is the default throughput mode).
 """
 import numpy as np
 import pytest
@@ -145,35 +146,35 @@ def test_fp32_first_critic_step_gradients(synth, name):
     # reference's CPU run (every upstream tensor agrees to 2e-6; see tests/conftest.check_grad).  Those two elements
     # perturb ALL upstream-in-backward gradients by up to ~1e-2 of their scale, so that case gets 2e-2; S=32 has no
     # borderline element and is held to 5e-4.
-    rtol_g, frac = (5e-4, 0.95) if S == 32 else (2e-2, 0.90)
+    rtol_g, frac, worst = (5e-4, 0.98, 5e-2) if S == 32 else (2e-2, 0.90, 1e-1)
     for k in eng.G.keys:
         if k.startswith("features.") and k.endswith(".bias"):
             continue            # conv bias in front of InstanceNorm: exactly-zero gradient, rounding noise on both sides
         g = eng.G.gviews[k].cpu().numpy() / coef_g
-        check_grad(fix, f"it0.ggrad.{k}", g, synth, rtol_g, frac_ok=frac)
+        check_grad(fix, f"it0.ggrad.{k}", g, synth, rtol_g, frac_ok=frac, outlier_rtol=worst)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("name", ["step_B4_S32", "step_B2_S64", "step_simple_B4_S32"])
-def test_bf16_step_is_close(synth, name):
-    """bf16 throughput mode: same schedule, bf16 operands.  Error is reported and bounded, not the parity claim."""
-    fix, eng, (seed, B, S, n_critic, iters, gray) = make_engine(synth, name, "bf16")
+def test_16bit_step_is_close_to_reference_golden(synth, name, dtype):
+    """The 16-bit throughput modes on the small golden cases (the reference's own outputs): same schedule, 16-bit MFMA
+    operands.  Bounds are 2x what was measured on MI355X; the bench-size error table is test_16bit_mode_error_vs_oracle."""
+    fix, eng, (seed, B, S, n_critic, iters, gray) = make_engine(synth, name, dtype)
     inp = inputs_for(synth, name, seed, 0, B, S, n_critic, gray)
     log = run_iter(eng, inp)
     sc = fix["it0.c0.scalars"]
     got = np.array([log["d_loss"][0], log["gp"][0], log["wd"][0], log["d_grad_norm"][0]])
-    err = rel_err(got, sc)
     e_real = rel_err(log["real"][0].cpu().reshape(-1), fix["it0.c0.real_validity"].reshape(-1))
     e_delta = rel_err(log["delta_pred"].cpu(), fix["it0.delta_pred"])
-    print(f"\n[bf16 {name}] scalars rel err {err:.3e}, real-score rel err {e_real:.3e}, delta rel err {e_delta:.3e}")
-    print("   d_loss/gp/wd/gradnorm bf16:", got, " reference fp32:", sc)
-    # Measured on MI355X (round 1): S=64: scalars 3e-4, scores 1e-2, delta 1e-4.  S=32: scores 6e-3, delta 8e-4, GP 3e-2,
-    # but the un-clipped critic gradient norm is 10 % low: at 32x32 input D.c4 normalises over a 2x2 map (4 elements), whose
-    # backward/double-backward amplify the rounding of the bf16 MFMA operands (keeping z and all incoming gradients in
-    # fp32 -- norm.hip -- took the GP error from 18 % to 3 % but cannot remove operand rounding).  fp32 mode is the parity
-    # mode; these bounds only keep the bf16 path from regressing.
     e_loss = rel_err(got[:3], sc[:3])
     e_norm = abs(got[3] - sc[3]) / sc[3]
-    assert e_loss < 5e-2 and e_norm < 0.15 and e_real < 3e-2 and e_delta < 1e-2
+    print(f"\n[{dtype} {name}] d_loss/gp/wd rel err {e_loss:.3e}, grad-norm {e_norm:.3e}, real-score {e_real:.3e}, delta {e_delta:.3e}")
+    print(f"   d_loss/gp/wd/gradnorm {dtype}:", got, " reference fp32:", sc)
+    # bf16 at S=32 (round 1): scores 6e-3, delta 8e-4, GP 3e-2, critic gradient norm 10 % LOW -- bf16 operand rounding adds
+    # variance to D.c4's 2x2 InstanceNorm (4 strongly correlated elements), so rstd and every gradient through it shrink.
+    # fp16's 3 extra mantissa bits cut that variance 64x.
+    b_loss, b_norm, b_real, b_delta = (5e-2, 0.15, 3e-2, 1e-2) if dtype == "bf16" else (1e-2, 2e-2, 4e-3, 1.5e-3)
+    assert e_loss < b_loss and e_norm < b_norm and e_real < b_real and e_delta < b_delta
 
 
 def test_eval_mode_forward_matches_golden(synth):
@@ -358,3 +359,118 @@ def test_full_size_iteration_matches_oracle(synth, B, S):
     assert rel_err(log2["delta_pred"].cpu(), ref2["delta_pred"]) < 2e-4
     assert abs(log2["loss_iou"] - ref2["loss_iou"]) < 2e-4 * abs(ref2["loss_iou"])
     assert abs(log2["g_grad_norm"] - ref2["g_grad_norm"]) < 2e-3 * ref2["g_grad_norm"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The path bench.py times: B=256, 32x32, n_critic=2, a 16-bit compute mode, device-drawn alpha / dropout masks, ONE hipGraph
+# per iteration replayed K times.
+# ---------------------------------------------------------------------------------------------------------------------
+def _bench_like(synth, dtype, **kw):
+    engine = load_pkg("engine")
+    seed, B, S, c = 42, 256, 32, 2
+    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+    d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+    eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype=dtype, device="cuda:0", seed=seed, **kw)
+    inp = synth.step_inputs(seed, B, S, c, tag="bench")
+    refined = [T(r).cuda() for r in inp["refined"]]
+    call = (T(inp["pred"]).cuda(), T(inp["gt"]).cuda(), T(inp["delta_true"]).cuda(), T(inp["pred_box"]).cuda(),
+            lambda delta, k: refined[k])
+    return engine, eng, call
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("keep_clipped", [False, True])
+def test_graph_replay_matches_eager_at_bench_config(synth, dtype, keep_clipped):
+    """GraphedIteration (single-GPU, one graph per iteration: what bench.py replays) == run_iteration launched eagerly, on two
+    FRESH engines with the same seed.  Alpha and the dropout masks are drawn on the device keyed by (seed, phase, optimiser step
+    count), so both sides draw identical values; what remains is the order of float atomics.  keep_clipped=True is the
+    constructor default: there the captured graph must contain the gradient zero fills although a fresh engine's buckets are
+    zero at capture time (replays used to accumulate onto the previous iteration's clipped gradients)."""
+    n_it, lr = 3, 2e-4
+    engine, eng_e, call = _bench_like(synth, dtype, keep_clipped_grads=keep_clipped)
+    for _ in range(n_it):
+        eng_e.run_iteration(*call)
+    torch.cuda.synchronize()
+    _, eng_g, call_g = _bench_like(synth, dtype, keep_clipped_grads=keep_clipped)
+    gi = engine.GraphedIteration(eng_g, *call_g)                # captured on the fresh engine, nothing executed yet
+    assert float(eng_g.G.state[0]) == 0.0 and float(eng_g.D.state[0]) == 0.0
+    for _ in range(n_it):
+        gi.replay()
+    torch.cuda.synchronize()
+    assert float(eng_g.D.state[0]) == float(eng_e.D.state[0]) == n_it * 2        # optimiser step counts
+    assert float(eng_g.G.state[0]) == float(eng_e.G.state[0]) == n_it
+    for a, b, steps, name in ((eng_g.D.p, eng_e.D.p, 2 * n_it, "D"), (eng_g.G.p, eng_e.G.p, n_it, "G")):
+        assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+        diff = (a - b).abs()
+        # Adam's first steps are ~lr*sign(g): an element whose near-zero gradient changes sign with the summation order lands
+        # 2*lr away per step; everything else must agree to rounding
+        close = float((diff <= 2e-6).float().mean())
+        assert close >= 0.99, (name, close)
+        assert float(diff.max()) <= 2.2 * lr * steps, (name, float(diff.max()))
+    for l in range(4):                                            # spectral-norm state advanced the same number of times
+        assert rel_err(eng_g.u[l].cpu(), eng_e.u[l].cpu()) < 1e-3
+    # the last critic step's losses (device scalars the replays left behind)
+    me, mg = eng_e.means.tolist(), eng_g.means.tolist()
+    for x, y in ((me[0] - me[1], mg[0] - mg[1]), (float(eng_e.gp_sum), float(eng_g.gp_sum)), (float(eng_e.eiou_acc), float(eng_g.eiou_acc))):
+        assert np.isfinite(x) and np.isfinite(y) and abs(x - y) <= 2e-2 * max(abs(x), 1e-3), (x, y)
+
+
+# measured on MI355X (tools/mode_error.py -> profiles/round2_mode_error.json), asserted with 2x headroom
+MODE_BOUNDS = {
+    # dtype: scores, delta, wd, gp, |d_grad_norm|, loss_iou, |g_grad_norm|
+    "bf16": dict(scores=1.5e-2, delta=2e-3, wd=2e-2, gp=6e-2, d_grad_norm=0.2, loss_iou=1e-3, g_grad_norm=2e-2),
+    "fp16": dict(scores=2e-3, delta=4e-4, wd=4e-3, gp=1e-2, d_grad_norm=1e-2, loss_iou=2e-4, g_grad_norm=5e-3),
+}
+
+
+def test_16bit_mode_error_vs_oracle(synth):
+    """The throughput modes at the bench configuration itself (B=256, 32x32, n_critic=2) against the pinned oracle on fixture
+    alphas / masks: every quantity of SURVEY 0's parity contract, bounded at twice its measured error.  fp16 is the default
+    throughput mode because it meets <= 1e-3 on scores / delta and <= 1e-2 on GP / gradient norm; bf16 does not (its operand
+    rounding inflates the variance InstanceNorm sees on D.c4's 2x2 maps: rstd, and every gradient through it, comes out low)."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, str(ROOT / "tools"))
+    import mode_error as ME
+    state, ref, taps = ME.oracle_reference(synth)
+    for dtype, bounds in MODE_BOUNDS.items():
+        m = ME.measure(dtype, state, ref, taps)
+        print(f"\n[{dtype}] " + "  ".join(f"{k}={v:.2e}" if isinstance(v, float) else f"{k}={v}" for k, v in m.items()))
+        assert m["finite"]
+        for k, b in bounds.items():
+            assert abs(m[k]) <= b, (dtype, k, m[k], b)
+    m32 = ME.measure("fp32", state, ref, taps)
+    for k in ("scores", "delta", "wd", "gp", "loss_iou"):
+        assert abs(m32[k]) <= 2e-4, ("fp32", k, m32[k])
+    assert abs(m32["d_grad_norm"]) <= 5e-4 and abs(m32["g_grad_norm"]) <= 2e-3
+
+
+def test_svhn_config_fp16_batch512(synth):
+    """BASELINE configs[3]: 32x32x3, batch 512, fp16 operands with fp32 loss / GP / statistics accumulation.  One eager
+    iteration with device-drawn alpha and masks, then graph replays: finite, and the first critic step's scalars agree with
+    the fp32-MFMA parity mode on the same draws (same seed -> same device RNG)."""
+    engine = load_pkg("engine")
+    seed, B, S, c = 7, 512, 32, 2
+    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+    d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+    inp = synth.step_inputs(seed, B, S, c, tag="svhn")
+    refined = [T(r).cuda() for r in inp["refined"]]
+    call = (T(inp["pred"]).cuda(), T(inp["gt"]).cuda(), T(inp["delta_true"]).cuda(), T(inp["pred_box"]).cuda(),
+            lambda delta, k: refined[k])
+    logs = {}
+    for dtype in ("fp32", "fp16"):
+        eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype=dtype, device="cuda:0", seed=seed)
+        logs[dtype] = eng.iteration(*call)
+        if dtype == "fp16":
+            gi = engine.GraphedIteration(eng, *call)
+            for _ in range(3):
+                gi.replay()
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(eng.D.p).all()) and bool(torch.isfinite(eng.G.p).all())
+            assert np.isfinite(float(eng.gp_sum)) and float(eng.D.state[0]) == 2 * 4
+    a, b = logs["fp16"], logs["fp32"]
+    assert rel_err(a["real"][0].cpu().reshape(-1), b["real"][0].cpu().reshape(-1)) < 2e-3
+    assert rel_err(a["delta_pred"].cpu(), b["delta_pred"].cpu()) < 5e-4
+    assert abs(a["gp"][0] - b["gp"][0]) <= 1e-2 * abs(b["gp"][0])
+    assert abs(a["d_grad_norm"][0] - b["d_grad_norm"][0]) <= 1e-2 * b["d_grad_norm"][0]
+    assert abs(a["loss_iou"] - b["loss_iou"]) <= 2e-4 * abs(b["loss_iou"])

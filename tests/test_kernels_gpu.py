@@ -1,5 +1,11 @@
-"""Per-kernel parity of the HIP kernels (called through the C ABI) against torch CPU fp32 / the oracle formulas.
-Tolerances: exact-fp32 MFMA mode 2e-5 relative to the tensor scale; bf16 mode 2e-2 (bf16 operands, fp32 accumulate)."""
+"""Per-kernel parity of the HIP kernels (called through the C ABI) against torch CPU fp32/fp64 / the oracle formulas.
+
+Tolerances (relative to the tensor's largest entry).  Operands are pre-rounded to the compute dtype on BOTH sides (q()), so
+a 16-bit run differs from the reference only by (a) fp32 summation order and (b) the rounding of a 16-bit OUTPUT:
+  * `tol`     -- outputs stored in the compute dtype: fp32 2e-5, bf16 5e-3 (half an ulp is 2e-3), fp16 6e-4 (5e-4);
+  * `tol_acc` -- fp32 outputs of a 16-bit kernel (pre-norm tensors, slabs, gradients): 1e-4, i.e. summation order only.
+    This is what pins the LDS-DMA kernels' taps, zero-filled borders, persistent tile order and vmcnt bookkeeping: one
+    dropped boundary tap of a K = 1024..4096 contraction is ~1e-2."""
 import numpy as np
 import pytest
 import torch
@@ -10,7 +16,8 @@ from conftest import load_pkg, rel_err
 
 pytestmark = pytest.mark.gpu
 
-DTS = [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)]
+DTS = [(torch.float32, 2e-5), (torch.bfloat16, 5e-3), (torch.float16, 6e-4)]
+TOL_ACC = 1e-4
 
 
 @pytest.fixture(scope="module")
@@ -76,10 +83,27 @@ def test_conv_fwd(ops, dt, tol, N, Hi, Cin, CinP, Cout):
     y = torch.zeros(N, Hi // 2, Hi // 2, Cout, device="cuda", dtype=dt)
     ops.conv_fwd(xd, wf, y, CinP, Cout, bias=b.cuda(), gscale=gs.cuda(), group_n=group_n, act=1)
     torch.cuda.synchronize()
-    ref = F.conv2d(x, q(w, dt), None, 2, 1)
-    scale = gs[torch.arange(N) // group_n].view(-1, 1, 1, 1)
-    ref = F.leaky_relu(ref * scale + b.view(1, -1, 1, 1), 0.2)
+    lin = F.conv2d(x.double(), q(w, dt).double(), None, 2, 1)
+    scale = gs[torch.arange(N) // group_n].view(-1, 1, 1, 1).double()
+    lin = lin * scale + b.view(1, -1, 1, 1).double()
+    ref = F.leaky_relu(lin, 0.2)
     assert rel_err(nchw(y), ref) < tol
+    if dt != torch.float32:
+        # the same kernels with an fp32 output: summation order is all that is left.  With the activation (no K split) ...
+        y32 = torch.full((N, Hi // 2, Hi // 2, Cout), float("nan"), device="cuda")
+        ops.conv_fwd(xd, wf, y32, CinP, Cout, bias=b.cuda(), gscale=gs.cuda(), group_n=group_n, act=1)
+        assert rel_err(nchw(y32), ref) < TOL_ACC
+        # ... and the linear form the engine uses for pre-norm tensors: the dispatcher may split K (atomics into a zeroed
+        # output, or slabs behind the output that the consumer adds)
+        z32 = torch.full((N, Hi // 2, Hi // 2, Cout), float("nan"), device="cuda")
+        ops.conv_fwd(xd, wf, z32, CinP, Cout, bias=b.cuda(), gscale=gs.cuda(), group_n=group_n)
+        assert rel_err(nchw(z32), lin) < TOL_ACC
+        ks = ops.conv_splits("fwd", ops.code(xd), N, Hi, CinP, Cout)
+        if ks > 1:
+            slabs = torch.full((ks, N, Hi // 2, Hi // 2, Cout), float("nan"), device="cuda")
+            ops.conv_fwd(xd, wf, slabs[0], CinP, Cout, bias=b.cuda(), gscale=gs.cuda(), group_n=group_n,
+                         split_stride=slabs[0].numel())
+            assert rel_err(nchw(slabs.sum(0)), lin) < TOL_ACC
 
 
 @pytest.mark.parametrize("dt,tol", DTS)
@@ -95,9 +119,14 @@ def test_conv_dgrad(ops, dt, tol, N, Hi, Cin, CinP, Cout):
     dx32 = torch.zeros(N, Hi, Hi, CinP, device="cuda", dtype=torch.float32)
     ops.conv_dgrad(dyd, wt, dx32, CinP, Cout)
     torch.cuda.synchronize()
-    ref = F.conv_transpose2d(dy, q(w, dt), None, 2, 1)
+    ref = F.conv_transpose2d(dy.double(), q(w, dt).double(), None, 2, 1)
     assert rel_err(nchw(dx)[:, :Cin], ref * 0.9) < tol
-    assert rel_err(nchw(dx32)[:, :Cin], ref) < tol
+    assert rel_err(nchw(dx32)[:, :Cin], ref) < (tol if dt == torch.float32 else TOL_ACC)
+    ks = ops.conv_splits("dgrad", ops.code(dyd), N, Hi, CinP, Cout)
+    if dt != torch.float32 and ks > 1:                        # slab form of a K-split launch
+        slabs = torch.full((ks, N, Hi, Hi, CinP), float("nan"), device="cuda")
+        ops.conv_dgrad(dyd, wt, slabs[0], CinP, Cout, split_stride=slabs[0].numel())
+        assert rel_err(nchw(slabs.sum(0))[:, :Cin], ref) < TOL_ACC
     if CinP > Cin:
         assert float(dx32[..., Cin:].abs().max()) == 0.0
 
@@ -121,10 +150,11 @@ def test_conv_wgrad(ops, dt, tol, N, Hi, Cin, CinP, Cout):
     dw2 = torch.zeros((Cout, Cin, 4, 4), device="cuda")      # pre-zeroed, split-parallel atomic reduction
     ops.wgrad_reduce(slab, ns, dw2, Cout, CinP, Cin, coef=coef, cscale=torch.tensor([2.0, 0.5], device="cuda"), u=u, v=v, nrank=2,
                      accumulate="zeroed")
-    ref = conv2d_weight(x, (Cout, Cin, 4, 4), dy, 2, 1)
-    corr = sum(float(coef[k]) * (2.0, 0.5)[k] * torch.outer(u[k].cpu(), v[k].cpu()).view(Cout, Cin, 4, 4) for k in range(2))
-    assert rel_err(dw.cpu(), ref - corr) < tol
-    assert rel_err(dw2.cpu(), ref - corr) < tol
+    ref = conv2d_weight(x.double(), (Cout, Cin, 4, 4), dy.double(), 2, 1)
+    corr = sum(float(coef[k]) * (2.0, 0.5)[k] * torch.outer(u[k].cpu().double(), v[k].cpu().double()).view(Cout, Cin, 4, 4) for k in range(2))
+    tol_w = tol if dt == torch.float32 else TOL_ACC           # the gradient is fp32 in every mode: summation order only
+    assert rel_err(dw.cpu(), ref - corr) < tol_w
+    assert rel_err(dw2.cpu(), ref - corr) < tol_w
 
 
 @pytest.mark.parametrize("dt,tol", DTS)
@@ -228,7 +258,7 @@ def test_critic_head(ops, dt, tol, N, H):
     out = torch.empty(N, H - 1, H - 1, device="cuda")
     ops.c5_fwd(xd, wp, out)
     ref = F.conv2d(x, w, None, 1, 1)
-    assert rel_err(out.cpu().view_as(ref), ref) < max(tol * 0.5, 2e-5)
+    assert rel_err(out.cpu().view_as(ref), ref) < (2e-5 if dt == torch.float32 else TOL_ACC)   # fp32 output: summation order only
     dout = rnd(N, 1, H - 1, H - 1, seed=32)
     dx = torch.empty(N, H, H, C, device="cuda", dtype=dt)
     ops.c5_dgrad(dx, wp, dout=dout.cuda().contiguous())
@@ -277,7 +307,7 @@ def test_pack_interp_gp_norm_unpack(ops):
     B, S = 5, 32
     pred, gt, ref = rnd(B, 3, S, S, seed=70), rnd(B, 3, S, S, seed=71), rnd(B, 3, S, S, seed=72)
     alpha = torch.rand(B, generator=torch.Generator().manual_seed(3))
-    for dt in (torch.float32, torch.bfloat16):
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
         out = torch.empty(3 * B, S, S, 8, device="cuda", dtype=dt)
         ops.pack_pair(pred.cuda(), gt.cuda(), out[:B])
         ops.pack_pair(pred.cuda(), ref.cuda(), out[B:2 * B])
@@ -289,7 +319,7 @@ def test_pack_interp_gp_norm_unpack(ops):
         if dt == torch.float32:
             assert torch.equal(got[:, :6], exp)       # bit-exact: same op-by-op rounding as eager torch
         else:
-            assert rel_err(got[:, :6], exp) < 1e-2
+            assert rel_err(got[:, :6], exp) < (4e-3 if dt == torch.bfloat16 else 5e-4)
         assert float(got[:, 6:].abs().max()) == 0.0
     g = rnd(B, S, S, 8, seed=73).cuda()
     nrm = torch.empty(B, device="cuda"); coef = torch.empty(B, device="cuda"); gp = torch.zeros(1, device="cuda")
