@@ -19,7 +19,7 @@ ROOT = PKG_DIR.parent
 HEADER = ROOT / "include" / "gcssl.h"
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libgcssl_hip.so"
-SOURCES = ["igemm.hip", "norm.hip", "misc.hip", "recrop.hip", "simple_gen.hip"]
+SOURCES = ["igemm.hip", "norm.hip", "misc.hip", "recrop.hip", "simple_gen.hip", "convt_fused.hip"]
 
 F32, BF16, F16 = 0, 1, 2
 ERRORS = {-1: "GCSSL_EBADSHAPE", -2: "GCSSL_EBADDTYPE", -3: "GCSSL_EALIGN", -4: "GCSSL_ENULL"}

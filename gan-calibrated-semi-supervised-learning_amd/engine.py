@@ -145,12 +145,17 @@ class StepEngine:
         self.delta_scale, self.lambda_gp, self.lambda_iou = delta_scale, lambda_gp, lambda_iou
         self.seed = seed
         self.allreduce = allreduce
-        # static loss scales of the fp16 mode (1 elsewhere: bf16 and fp32 have fp32's exponent range).  Unscaled, the critic's
-        # backward runs at ~1e-4 and the generator's at ~1e-6 per element (seeds 1/(B hw) and 1/(B S^2)): at and below fp16's
-        # smallest normal 6e-5.  x1024 / x4096 puts both near 1e-1..1e-3, five orders of magnitude under the 65504 ceiling.
+        # Static loss scales of the fp16 mode (1 elsewhere: bf16 and fp32 have fp32's exponent range).  The backward seeds are
+        # 1/(B hw) for the critic (hw score positions per sample) and ~1/(B S^2) per element for the generator (EIoU mean over
+        # the batch, then the average pool): unscaled the 16-bit gradient tensors sit at 1e-4 / 1e-7 per element, at and
+        # far below fp16's smallest normal 6e-5.  Scaling by B hw / B S^2 (rounded to a power of two: exact) makes the seeds
+        # O(1) whatever the batch and image size.  Measured at B=256, 32x32 (tools/fp16_ranges.py): largest entry ~2e2 against the
+        # 65504 ceiling, <1 % of the non-zero entries below the normal range.
         f16 = self.code == _lib.F16
-        self.loss_scale_d = float(os.environ.get("GCSSL_LOSS_SCALE_D", 1024.0 if f16 else 1.0))
-        self.loss_scale_g = float(os.environ.get("GCSSL_LOSS_SCALE_G", 4096.0 if f16 else 1.0))
+        pow2 = lambda v: float(2 ** round(math.log2(max(v, 1.0))))
+        hw5 = (size // 16 - 1) ** 2
+        self.loss_scale_d = float(os.environ.get("GCSSL_LOSS_SCALE_D", pow2(batch * hw5) if f16 else 1.0))
+        self.loss_scale_g = float(os.environ.get("GCSSL_LOSS_SCALE_G", pow2(batch * size * size) if f16 else 1.0))
         self.keep_clipped_grads = keep_clipped_grads     # write g*clip_coef back like clip_grad_norm_ does (not needed to step)
         _lib.lib()                                                  # fail loudly now if the HIP library is missing
         _lib.call_nostream("gcssl_init")                            # dynamic-LDS opt-ins, before any graph capture
@@ -166,6 +171,9 @@ class StepEngine:
         self.grad_slabs = os.environ.get("GCSSL_GRAD_SLABS", "1") != "0"
         # one batched generator forward per iteration (g_forward_all); GCSSL_BATCH_G=0: one forward per call, for A/B runs
         self.batch_g = os.environ.get("GCSSL_BATCH_G", "1") != "0"
+        # the generator's up3 / up4 layers as ONE pixel-stationary launch each (transposed conv + InstanceNorm + ReLU + pool
+        # sums: csrc/convt_fused.hip) where the shapes allow; bit 0 = up4, bit 1 = up3 (GCSSL_FUSED_UP=0: the unfused pair)
+        self.fused_up = int(os.environ.get("GCSSL_FUSED_UP", "3"))
         self._alloc()
         self.gen = SimpleGenerator(self) if generator_type == "simple" else None
         self._d_dirty = True
@@ -210,7 +218,8 @@ class StepEngine:
         """Bracket every MFMA conv launch with HIP events on the launch stream (eager mode only)."""
         self.probe = {} if on else None
 
-    def _conv(self, label: str, flops: float, fn, *args, **kw):
+    def _conv(self, label: str, flops: float, fn, *args, _bytes=None, **kw):
+        """_bytes: (algorithmic, stored) bytes of the launch when its argument list does not show them (fused launches)"""
         if self.probe is None:
             return fn(*args, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -219,7 +228,7 @@ class StepEngine:
         e1.record()
         rec = self.probe.get(label)
         if rec is None:
-            algo, stored = _algorithmic_bytes(label, args, 4 if self.code == _lib.F32 else 2)
+            algo, stored = _bytes or _algorithmic_bytes(label, args, 4 if self.code == _lib.F32 else 2)
             rec = self.probe[label] = {"events": [], "flops": flops, "bytes": algo, "stored": stored}
         rec["events"].append((e0, e1))
 
@@ -534,6 +543,19 @@ class StepEngine:
         ins = [f.d4, f.cat1, f.cat2, f.cat3]
         outs = [f.cat1[..., :256], f.cat2[..., :128], f.cat3[..., :64], f.u4]
         for k, (cint, coutt) in enumerate(G_UP):
+            hin = S >> (4 - k)                                        # input map of the transposed conv
+            if k >= 2 and (self.fused_up >> (3 - k)) & 1 and ops.convt_fused_ok(self.code, n, hin, coutt):
+                # one launch: conv + statistics + ReLU (+ pool sums for up4, whose activation nobody reads: only its sums
+                # feed the head).  The fp32 pre-norm values are kept for the samples that have a backward pass: all of them in
+                # a single-call forward, the generator step's group in the iteration's batched forward.
+                es, hw_o = 2, 4 * hin * hin
+                algo = (ins[k].numel() + self.gu_wt[k].numel() + n * hw_o * coutt) * es
+                z_n0 = 0 if n == self.B else n - self.B
+                stored = (ins[k].numel() + self.gu_wt[k].numel() + (n * hw_o * coutt if k < 3 else 0)) * es + (n - z_n0) * hw_o * coutt * 4
+                self._conv(f"G.up{k + 1}.fwd{tag}", conv_flops(n, 2 * hin, coutt, cint), ops.convt_in_relu_fwd, ins[k],
+                           self.gu_wt[k], f.umean[k], f.urstd[k], cint, z32=f.zu[k], z_n0=z_n0, a=outs[k] if k < 3 else None,
+                           pool=f.poolsum if k == 3 else None, _bytes=(algo, stored))
+                continue
             ns, st = self._split("dgrad", f.zu[k], n, S >> (3 - k), coutt, cint) if k < 3 else (1, 0)
             self._conv(f"G.up{k + 1}.fwd{tag}", conv_flops(n, S >> (3 - k), coutt, cint), ops.conv_dgrad, ins[k],
                        self.gu_wt[k], f.zu[k], coutt, cint, split_stride=st)

@@ -95,6 +95,20 @@ def conv_dgrad(dy, wt, dx, cin, cout, gscale=None, group_n=0, split_stride=0):
          int(split_stride))
 
 
+def convt_in_relu_fwd(x, wt, mean, rstd, K, z32=None, z_n0=0, a=None, pool=None):
+    """ConvTranspose2d(K -> 64, k4 s2 p1) + InstanceNorm + ReLU in one launch (csrc/convt_fused.hip).  x: [N][H][H][>=K],
+    H in (8, 16), N*H*H a multiple of 256; wt: the dgrad pack [64][16][K].  Optional outputs: a (16-bit activation, may be a
+    channel slice of a concat buffer), z32 (fp32 pre-norm values, written for samples >= z_n0 only), pool ([N][64] sums)."""
+    N, H, _, _ = x.shape
+    call("gcssl_convT4x4s2_in_relu_fwd", code(x), x, _ld(x), wt, z32, _ld(z32) if z32 is not None else 0, int(z_n0), a,
+         _ld(a) if a is not None else 0, mean, rstd, pool, N, H, K, 64)
+
+
+def convt_fused_ok(dt: int, n: int, h: int, cout_t: int) -> bool:
+    """shapes the fused kernel takes: 16-bit dtype, 64 output channels, 8x8 or 16x16 inputs in whole 256-pixel blocks"""
+    return dt != _lib.F32 and cout_t == 64 and h in (8, 16) and (n * h * h) % 256 == 0
+
+
 def wgrad_splits(N, Hi, Wi, cin, cout) -> int:
     r = _lib.call_nostream("gcssl_conv4x4s2_wgrad_splits", N, Hi, Wi, cin, cout)
     if r <= 0:

@@ -158,6 +158,16 @@ int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* c
                         const int* rows, const int* cols, float* sigma, float* isig, float* u_hist, float* v_hist,
                         int hist_stride_u, int hist_stride_v, int slot, int nslots, int iterate, void* stream);
 
+/* ---- fused generator up-path layer (cgan/models.py:72-74,112-118) ---------------------------------------------------------
+ * ConvTranspose2d(K -> 64, k4 s2 p1, bias=False) + InstanceNorm2d + ReLU (+ the sums AdaptiveAvgPool2d(1) needs) as ONE
+ * launch: the pixel-stationary kernel of csrc/convt_fused.hip (inputs of 8x8 or 16x16 pixels; 16-bit dtypes only).
+ * x [N][H][H][ldx>=K]; wt = the dgrad pack Wt[64][16][K] of gcssl_prep_conv_weight.  Outputs, each nullable except
+ * mean/rstd [N][64]: a [N][2H][2H][lda] in `dtype`; z32 = the fp32 pre-norm values of samples >= z_n0 only (what
+ * gcssl_in_act_bwd reads for the samples that have a backward pass); pool [N][64] = sum over the output pixels of the
+ * activation (written, not accumulated). */
+int gcssl_convT4x4s2_in_relu_fwd(int dtype, const void* x, int ldx, const void* wt, float* z32, int ldz, int z_n0, void* a,
+                                 int lda, float* mean, float* rstd, float* pool, int N, int H, int K, int Cout, void* stream);
+
 /* ---- gradient penalty (cgan/losses.py:223-231) -------------------------------------------------------------------
  * nrm[b] = sqrt(sum g_b^2 + 1e-12); gp_sum += mean((nrm-1)^2); coef[b] = lambda_gp*2/B*(nrm-1)/nrm. */
 int gcssl_gp_norm(const float* g, long per_sample, int B, float lambda_gp, float* nrm, float* coef, float* gp_sum,

@@ -564,3 +564,39 @@ def test_pack_fake_interp_equals_the_two_separate_packs(ops):
     al = ((m - r) / (g - r)).reshape(B, -1)
     assert float(al.min()) >= -1e-3 and float(al.max()) <= 1 + 1e-3
     assert float((al - al.median(1, keepdim=True).values).abs().median()) < 1e-3
+
+
+@pytest.mark.parametrize("dt,tol", DTS[1:])
+@pytest.mark.parametrize("N,H,K,z_n0", [(3, 16, 128, 1),       # G.up4 at 32x32 images: one sample per pixel block
+                                        (8, 8, 256, 4),        # G.up3: four samples per pixel block
+                                        (12, 8, 64, 0),        # shortest K (two 32-channel chunks)
+                                        (520, 16, 128, 500)])  # more pixel blocks than CUs: the persistent loop, 2-3 blocks per workgroup
+def test_fused_convT_instnorm_relu(ops, dt, tol, N, H, K, z_n0):
+    """csrc/convt_fused.hip against ConvTranspose2d -> InstanceNorm2d -> ReLU (-> spatial sums) of torch CPU (fp64)."""
+    x = q(rnd(N, K, H, H, seed=101), dt)
+    w = rnd(K, 64, 4, 4, seed=102, scale=0.05)                  # ConvTranspose2d weight [Cin_T = K][Cout_T = 64][4][4]
+    # as a conv: Cout = K (its input is our output), Cin = 64; packed dgrad operand Wt[64][16][K]
+    _, wt = packed_weights(ops, w, dt)
+    xd = nhwc(x, dt)
+    wide = torch.zeros(N, 2 * H, 2 * H, 128, device="cuda", dtype=dt)       # activation goes into a concat slice
+    a = wide[..., :64]
+    z32 = torch.full((N, 2 * H, 2 * H, 64), float("nan"), device="cuda")
+    mean = torch.empty(N, 64, device="cuda"); rstd = torch.empty(N, 64, device="cuda")
+    pool = torch.full((N, 64), float("nan"), device="cuda")
+    ops.convt_in_relu_fwd(xd, wt, mean, rstd, K, z32=z32, z_n0=z_n0, a=a, pool=pool)
+    torch.cuda.synchronize()
+    z = F.conv_transpose2d(x.double(), q(w, dt).double(), None, 2, 1)
+    mu = z.mean(dim=(2, 3)); var = z.var(dim=(2, 3), unbiased=False)
+    r = 1.0 / torch.sqrt(var + 1e-5)
+    act = torch.relu((z - mu[:, :, None, None]) * r[:, :, None, None])
+    assert rel_err(mean.cpu(), mu) < 1e-4 and rel_err(rstd.cpu(), r) < 1e-4
+    assert rel_err(nchw(z32[z_n0:]), z[z_n0:]) < TOL_ACC
+    assert bool(torch.isnan(z32[:z_n0]).all())                   # samples without a backward pass: nothing written
+    assert rel_err(nchw(a), act) < tol
+    assert float(wide[..., 64:].abs().max()) == 0.0
+    assert rel_err(pool.cpu(), act.sum(dim=(2, 3))) < 1e-4
+    # outputs are optional: statistics + pool only (what G.up4 needs for the samples of the no-grad forwards)
+    mean2 = torch.empty_like(mean); rstd2 = torch.empty_like(rstd); pool2 = torch.empty_like(pool)
+    ops.convt_in_relu_fwd(xd, wt, mean2, rstd2, K, pool=pool2)
+    torch.cuda.synchronize()
+    assert torch.equal(mean2, mean) and torch.equal(rstd2, rstd) and torch.equal(pool2, pool)

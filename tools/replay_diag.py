@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""How far apart do two runs of the same seeded iterations drift?  eager vs eager (float-atomic order only) and eager vs
+graph replay, per iteration: share of weights within 2e-6, median and largest |difference|, last d_loss."""
+import importlib
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+PKG = "gan-calibrated-semi-supervised-learning_amd"
+T = torch.from_numpy
+synth = importlib.import_module(PKG + ".synth")
+engine = importlib.import_module(PKG + ".engine")
+dtype = sys.argv[1] if len(sys.argv) > 1 else "fp16"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+seed, S, c = 42, 32, 2
+g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+inp = synth.step_inputs(seed, B, S, c, tag="bench")
+refined = [T(r).cuda() for r in inp["refined"]]
+call = (T(inp["pred"]).cuda(), T(inp["gt"]).cuda(), T(inp["delta_true"]).cuda(), T(inp["pred_box"]).cuda(), lambda dl, k: refined[k])
+
+
+def fresh():
+    return engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype=dtype, device="cuda:0", seed=seed, keep_clipped_grads=False)
+
+
+def cmp(a, b, tag):
+    for name, x, y in (("D", a.D.p, b.D.p), ("G", a.G.p, b.G.p)):
+        diff = (x - y).abs()
+        print(f"  {tag} {name}: within 2e-6 {float((diff <= 2e-6).float().mean()):.4f}  median {float(diff.median()):.2e}  "
+              f"max {float(diff.max()):.2e}  |  gp {float(a.gp_sum):.5f} vs {float(b.gp_sum):.5f}  "
+              f"gnorm {float(a.D.state[2]):.4f} vs {float(b.D.state[2]):.4f}")
+
+
+e1, e2, eg = fresh(), fresh(), fresh()
+gi = engine.GraphedIteration(eg, *call)
+for it in range(3):
+    e1.run_iteration(*call); e2.run_iteration(*call); gi.replay()
+    torch.cuda.synchronize()
+    print(f"iteration {it + 1} ({dtype}, B={B})")
+    cmp(e1, e2, "eager vs eager")
+    cmp(e1, eg, "eager vs graph")
+# a single critic step twice on the same engine state: gradient reproducibility
+ea, eb = fresh(), fresh()
+for e in (ea, eb):
+    e.lr = 0.0
+    e.d_step(call[0], call[1], call[4], 0, None, None)
+torch.cuda.synchronize()
+ga, gb = ea.D.g.clone(), eb.D.g.clone()
+print("first critic step, two engines: grad rel diff", float((ga - gb).abs().max() / ga.abs().max()), " norms", float(ea.D.state[2]), float(eb.D.state[2]))
