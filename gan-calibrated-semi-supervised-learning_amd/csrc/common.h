@@ -49,10 +49,16 @@ template <> struct Elem<bf16_t> {
     __device__ static float ld(const bf16_t* p) { return (float)*p; }
     __device__ static void st(bf16_t* p, float v) { *p = (bf16_t)v; }
 };
+// fp16 stores SATURATE at +-65504 instead of overflowing to inf: the critic's loss-scaled gradient tensors have a heavy tail
+// (a 2x2 InstanceNorm with a tiny variance multiplies by rstd up to 316; measured peaks reach a quarter of the ceiling once
+// in a few thousand iterations), and one inf in a weight-gradient operand turns the whole update into NaN, while a clipped
+// outlier perturbs a gradient that is norm-clipped to 1 anyway.  NaN inputs are not preserved by the clamp (fmaxf returns
+// the other operand) -- the fp32 statistics, losses and scores next to every 16-bit tensor still carry them.
+__device__ __forceinline__ f16_t f32_to_f16_sat(float v) { return (f16_t)fminf(fmaxf(v, -65504.f), 65504.f); }
 template <> struct Elem<f16_t> {
     static constexpr int KV = 8;
     __device__ static float ld(const f16_t* p) { return (float)*p; }
-    __device__ static void st(f16_t* p, float v) { *p = (f16_t)v; }     // RNE; beyond 65504 -> inf (visible, not clamped)
+    __device__ static void st(f16_t* p, float v) { *p = f32_to_f16_sat(v); }
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
@@ -67,7 +73,7 @@ template <> struct Bits16<bf16_t> {
     __device__ static __forceinline__ float dec(uint32_t b) { return bf16_bits_to_f32(b & 0xFFFFu); }
 };
 template <> struct Bits16<f16_t> {
-    __device__ static __forceinline__ uint32_t enc(float f) { return (uint32_t)__builtin_bit_cast(uint16_t, (f16_t)f); }
+    __device__ static __forceinline__ uint32_t enc(float f) { return (uint32_t)__builtin_bit_cast(uint16_t, f32_to_f16_sat(f)); }
     __device__ static __forceinline__ float dec(uint32_t b) { return (float)__builtin_bit_cast(f16_t, (uint16_t)(b & 0xFFFFu)); }
 };
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return Bits16<T>::enc(lo) | (Bits16<T>::enc(hi) << 16); }
@@ -123,3 +129,34 @@ template <int NW> __device__ __forceinline__ float block_sum(float v, float* sm)
 }
 
 __device__ __forceinline__ float lrelu_f(float x) { return x > 0.f ? x : 0.2f * x; }
+
+// ---- zero fills as KERNELS.  hipMemsetAsync / hipMemset2DAsync must not be used on a path that may be stream-captured: on
+// ROCm 7.2 the memset node of the instantiated graph replays with a garbage fill pattern once the host memory the call's
+// parameters lived in has been reused (measured: the InstanceNorm backward's scratch came back filled with 0x61 / 0x6f
+// bytes = 2.6e20 / 7.4e28 on the second replay, depending on what Python had allocated in between; tools/replay_diag9.py).
+static __global__ __launch_bounds__(256) void gcssl_zero_kernel(float* __restrict__ p, size_t n) {
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = 0.f;
+}
+// rows x cols floats with a row pitch of ld floats
+static __global__ __launch_bounds__(256) void gcssl_zero2d_kernel(float* __restrict__ p, size_t ld, int cols, size_t rows) {
+    const size_t total = rows * (size_t)cols, stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride)
+        p[(i / cols) * ld + (i % cols)] = 0.f;
+}
+static inline void gcssl_zero_async(float* p, size_t n, hipStream_t st) {
+    if ((((uintptr_t)p) & 15) != 0) {                                            // float4 stores need 16-byte alignment
+        size_t b = (n + 255) / 256; if (b > 2048) b = 2048; if (b < 1) b = 1;
+        hipLaunchKernelGGL(gcssl_zero2d_kernel, dim3((unsigned)b), dim3(256), 0, st, p, n, (int)(n < 0x7fffffff ? n : 0x7fffffff), (size_t)1);
+        return;
+    }
+    size_t blocks = (n / 4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(gcssl_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n);
+}
+static inline void gcssl_zero2d_async(float* p, size_t ld, int cols, size_t rows, hipStream_t st) {
+    if (ld == (size_t)cols && (((uintptr_t)p) & 15) == 0) { gcssl_zero_async(p, rows * cols, st); return; }
+    size_t blocks = (rows * cols + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(gcssl_zero2d_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, ld, cols, rows);
+}

@@ -143,6 +143,27 @@ __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
 template <int TM, int TN, class TA, class TB>
 __device__ __forceinline__ void mma_slab(const TA& As, const TB& Bs, int wm0, int wn0, int lane,
                                          f32x16 (&acc)[TM][TN]) {
+    if constexpr (sizeof(typename TA::Frag) == 16 && TA::KSTEPS * (TM + TN) <= 16) {
+        // 16-bit operands: every fragment read of the slab goes out first, then the MFMAs run behind counted lgkmcnt waits
+        // (left to itself hipcc emits reads, lgkmcnt(0), MFMAs per k-step: each group paid a full LDS round trip)
+        typename TA::Frag a[TA::KSTEPS][TM];
+        typename TB::Frag b[TA::KSTEPS][TN];
+#pragma unroll
+        for (int ks = 0; ks < TA::KSTEPS; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[ks][i] = As.frag(wm0 + 32 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[ks][j] = Bs.frag(wn0 + 32 * j, ks, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < TA::KSTEPS; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma(a[ks][i], b[ks][j], acc[i][j]);
+        return;
+    }
 #pragma unroll
     for (int ks = 0; ks < TA::KSTEPS; ++ks) {
         typename TA::Frag a[TM];
@@ -568,21 +589,28 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // everyone's part of tile t landed; everyone is done reading tile t-1
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < t_end) issue(t + 2, slot == 0 ? 2 : slot - 1);     // slot of tile t-1 == (slot+2)%3
+            // All fragment reads of the step go out FIRST, the DMA of tile t+2 is issued under their latency, then the MFMAs run
+            // behind counted lgkmcnt waits.  (Left to itself hipcc emits read, read, lgkmcnt(0), MFMA four times over: every
+            // MFMA of the step paid a full LDS round trip, ~4 x 160 cycles per wave and step for 4 x 32 cycles of matrix work.)
             const unsigned char* At = lds + slot * STAGE;
             const unsigned char* Bt = At + A_BYTES;
+            FragT a[BK / 16][TM], b[BK / 16][TN];
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
-                FragT a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = frag(At, wm0 + 32 * i, kk);
+                for (int i = 0; i < TM; ++i) a[kk][i] = frag(At, wm0 + 32 * i, kk);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = frag(Bt, wn0 + 32 * j, kk);
+                for (int j = 0; j < TN; ++j) b[kk][j] = frag(Bt, wn0 + 32 * j, kk);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < t_end) issue(t + 2, slot == 0 ? 2 : slot - 1);     // slot of tile t-1 == (slot+2)%3
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
-            }
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma(a[kk][i], b[kk][j], acc[i][j]);
             slot = slot == 2 ? 0 : slot + 1;
         }
     }
@@ -897,23 +925,28 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            // (reads first, DMA issue under their latency, MFMAs behind counted lgkmcnt waits: see conv_dma_kernel)
+            const unsigned char* At = lds + slot * STAGE;
+            const unsigned char* Bt = At + A_BYTES;
+            FragT a[BK / 16][TM], b[BK / 16][TN];
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[kk][i] = frag(At, wm0 + 32 * i, kk);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[kk][j] = frag(Bt, wn0 + 32 * j, kk);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             const int s2 = slot == 0 ? 2 : slot - 1;                      // slot of step t+2 == slot of step t-1
             if (t + 2 < nk) issue(cur, t + 2, s2);
             else if (has_next) issue(nxt, t + 2 - nk, s2);
-            const unsigned char* At = lds + slot * STAGE;
-            const unsigned char* Bt = At + A_BYTES;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                FragT a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = frag(At, wm0 + 32 * i, kk);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = frag(Bt, wn0 + 32 * j, kk);
+            for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
-            }
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma(a[kk][i], b[kk][j], acc[i][j]);
             slot = slot == 2 ? 0 : slot + 1;
         }
         // step 0 of the next tile must have landed before this wave's stores enter the queue behind it
@@ -1367,8 +1400,8 @@ int pick_ksplit(long tiles, int nk, bool allowed) {
 
 int zero_output(const ConvParams& p, long rows, int cols, hipStream_t st) {
     if (p.split_stride || p.plan_out) return GCSSL_OK;                     // slab mode: every split owns its own slab, nothing to zero
-    hipError_t e = hipMemset2DAsync(p.y, (size_t)p.ldy * 4, 0, (size_t)cols * 4, (size_t)rows, st);
-    return e == hipSuccess ? GCSSL_OK : (int)e;
+    gcssl_zero2d_async(static_cast<float*>(p.y), (size_t)p.ldy, cols, (size_t)rows, st);   // (a kernel, not a memset node: common.h)
+    return gcssl_launch_status();
 }
 
 // 256-row tiles, bf16 LDS-DMA path only: 8 waves as 4 (M) x 2 (N), so a wave owns 64x64 (or 64x32) outputs and issues

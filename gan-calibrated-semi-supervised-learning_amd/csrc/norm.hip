@@ -847,10 +847,10 @@ int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean
     }
     dim3 grid(C / CW, N, (HW + SMALL_HW - 1) / SMALL_HW);
     if (rstd == mean + (size_t)N * C) {                      // back-to-back buffers (the engine's): one fill
-        hipMemsetAsync(mean, 0, sizeof(float) * 2 * (size_t)N * C, st);
+        gcssl_zero_async(mean, 2 * (size_t)N * C, st);        // (kernels, not memset nodes: common.h)
     } else {
-        hipMemsetAsync(mean, 0, sizeof(float) * (size_t)N * C, st);
-        hipMemsetAsync(rstd, 0, sizeof(float) * (size_t)N * C, st);
+        gcssl_zero_async(mean, (size_t)N * C, st);
+        gcssl_zero_async(rstd, (size_t)N * C, st);
     }
     hipLaunchKernelGGL(in_stats_kernel, grid, dim3(CGN * RGN), 0, st, z, ldz, mean, rstd, HW, C);
     hipLaunchKernelGGL(in_finalize_kernel, dim3((unsigned)(((size_t)N * C + 255) / 256)), dim3(256), 0, st, z, ldz, mean, rstd, N, HW, C);
@@ -887,7 +887,7 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
         return gcssl_launch_status();
     }
     dim3 grid(C / CW, N, (HW + SMALL_HW - 1) / SMALL_HW);
-    hipMemsetAsync(ws, 0, sizeof(float) * 2 * (size_t)N * C, st);
+    gcssl_zero_async(ws, 2 * (size_t)N * C, st);             // (a kernel, not a memset node: common.h)
     GCSSL_DISPATCH(dtype,
         hipLaunchKernelGGL((in_bwd_kernel<T, 1>), grid, dim3(CGN * RGN), 0, st, q, ws);
         hipLaunchKernelGGL((in_bwd_kernel<T, 2>), grid, dim3(CGN * RGN), 0, st, q, ws));

@@ -148,13 +148,15 @@ class StepEngine:
         # Static loss scales of the fp16 mode (1 elsewhere: bf16 and fp32 have fp32's exponent range).  The backward seeds are
         # 1/(B hw) for the critic (hw score positions per sample) and ~1/(B S^2) per element for the generator (EIoU mean over
         # the batch, then the average pool): unscaled the 16-bit gradient tensors sit at 1e-4 / 1e-7 per element, at and
-        # far below fp16's smallest normal 6e-5.  Scaling by B hw / B S^2 (rounded to a power of two: exact) makes the seeds
-        # O(1) whatever the batch and image size.  Measured at B=256, 32x32 (tools/fp16_ranges.py): largest entry ~2e2 against the
-        # 65504 ceiling, <1 % of the non-zero entries below the normal range.
+        # far below fp16's smallest normal 6e-5.  The generator's scale B S^2 makes its seeds O(1) (measured peak 2e2 over 1500
+        # iterations).  The critic's tensors have a heavy tail -- dzs is rstd (up to 316 on a 2x2 map) times the incoming
+        # gradient: un-scaled peaks of 10..125 in 18 000 iterations (tools/nan_hunt.py, bf16) against a median of 1e-4 -- so its
+        # scale is B hw / 8 (32 at B=256, 32x32: peak ~4e3 of the 65504 ceiling, a few % of the entries below the normal
+        # range), and fp16 stores saturate instead of producing inf (common.h).  Powers of two: exact.
         f16 = self.code == _lib.F16
         pow2 = lambda v: float(2 ** round(math.log2(max(v, 1.0))))
         hw5 = (size // 16 - 1) ** 2
-        self.loss_scale_d = float(os.environ.get("GCSSL_LOSS_SCALE_D", pow2(batch * hw5) if f16 else 1.0))
+        self.loss_scale_d = float(os.environ.get("GCSSL_LOSS_SCALE_D", pow2(batch * hw5 / 8.0) if f16 else 1.0))
         self.loss_scale_g = float(os.environ.get("GCSSL_LOSS_SCALE_G", pow2(batch * size * size) if f16 else 1.0))
         self.keep_clipped_grads = keep_clipped_grads     # write g*clip_coef back like clip_grad_norm_ does (not needed to step)
         _lib.lib()                                                  # fail loudly now if the HIP library is missing

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""fp16 mode over many training iterations on a fixed synthetic batch: largest magnitude of every 16-bit gradient tensor
+against the 65504 ceiling, critic gradient norm, and the first non-finite tensor if any.
+    python tools/fp16_stability.py [iters] [dtype]"""
+import importlib, os, sys, torch
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+PKG = "gan-calibrated-semi-supervised-learning_amd"
+synth = importlib.import_module(PKG + ".synth"); engine = importlib.import_module(PKG + ".engine")
+T = torch.from_numpy
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+dtype = sys.argv[2] if len(sys.argv) > 2 else "fp16"
+g = {k: T(v) for k, v in synth.generator_state(42).items()}; d = {k: T(v) for k, v in synth.discriminator_state(42).items()}
+B, S, c = 256, 32, 2
+eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype=dtype, device="cuda:0", keep_clipped_grads=False)
+inp = synth.step_inputs(42, B, S, c, tag="bench")
+refined = [T(r).cuda() for r in inp["refined"]]
+call = (T(inp["pred"]).cuda(), T(inp["gt"]).cuda(), T(inp["delta_true"]).cuda(), T(inp["pred_box"]).cuda(), lambda dl, k: refined[k])
+print(f"{dtype}: loss scales D {eng.loss_scale_d} G {eng.loss_scale_g}")
+names = {}
+for l in range(4):
+    names[f"D.dzs4[{l}]"] = eng.d_dzs4[l]; names[f"D.a4[{l}]"] = eng.d_a4[l]
+for k in range(4):
+    names[f"G.dzu[{k}]"] = eng.g_dzu[k]; names[f"G.dzd[{k}]"] = eng.g_dzd[k]
+names["gt_x"] = eng.gt_x
+peak = {k: 0.0 for k in names}
+gmax = 0.0
+for it in range(iters):
+    eng.run_iteration(*call)
+    if it % 10 == 0 or it < 20:
+        bad = [k for k, t in names.items() if not bool(torch.isfinite(t.float()).all())]
+        for k, t in names.items():
+            peak[k] = max(peak[k], float(t.float().abs().nan_to_num(posinf=1e9).max()))
+        gn = float(eng.D.state[2]); gmax = max(gmax, gn if gn == gn else 1e30)
+        fin = bool(torch.isfinite(eng.D.p).all() and torch.isfinite(eng.G.p).all())
+        if bad or not fin or it % 250 == 0:
+            top = sorted(peak.items(), key=lambda kv: -kv[1])[:4]
+            print(f"it {it:5d} D gnorm {gn:10.2f} (max {gmax:10.2f}) gp {float(eng.gp_sum):8.4f} weights finite {fin} nonfinite {bad} peaks {[(k, round(v, 1)) for k, v in top]}")
+        if bad or not fin:
+            break
+print("peaks:", {k: round(v, 2) for k, v in peak.items()})
