@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--size", type=int, default=32)
     ap.add_argument("--n_critic", type=int, default=2)
-    ap.add_argument("--dtype", default=os.environ.get("GCSSL_BENCH_DTYPE", "bf16"), choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default=os.environ.get("GCSSL_BENCH_DTYPE", "fp16"), choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--generator", default="unet", choices=["unet", "simple"],
                     help="generator_type (cgan/cgan_train_enhanced.py:26-31); the headline config is the default U-Net")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")

@@ -208,6 +208,8 @@ struct ConvParams {
     int wk;             // 3x3 forms: elements per packed weight row (9*Cin rounded up to 64) = length of the K loop
     int xcd_remap;      // wgrad: deal the workgroups of a K split to one XCD (A/B knob GCSSL_WGRAD_XCD=0 turns it off)
     int class_major;    // persistent dgrad form: 1 = walk the tiles class by class (A/B knob GCSSL_DGRAD_ORDER=1), 0 = class-interleaved
+    int sib_remap;      // fwd / dgrad: deal all tiles that read the SAME input rows (the N tiles and, for dgrad, the four parity
+                        // classes of one M tile) to one XCD back to back (A/B knob GCSSL_SIB_REMAP=0)
     int N, Hi, Wi, Cin, Cout;   // conv geometry: x is [N][Hi][Wi][Cin], y is [N][Hi/2][Wi/2][Cout]
     int lgWo, lgHoWo, lgCin, lgCout;
     int M;              // GEMM rows
@@ -467,6 +469,19 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_void_p;
 
+// Linear workgroup / tile index -> (M tile, N tile, parity class).  Workgroups are dealt round-robin to the 8 XCDs, so indices
+// L and L + 8 share an L2.  All SIB = tiles_n * ncls tiles of one M tile gather the same activation rows: blocks of 8 * SIB
+// consecutive indices hold 8 M tiles, one per XCD, each with its siblings 8 apart -- the first sibling pulls the rows from
+// HBM / Infinity Cache into the XCD's L2, the others hit there (the per-CU LDS-DMA rate is latency x bytes in flight: ~33 GB/s
+// from beyond L2, ~70 GB/s from L2, MI355X_MICROARCH.md "Indexed rows: gather into LDS").  Placement only, never correctness.
+__device__ __forceinline__ void tile_decode(int L, int tiles_m, int tiles_n, int ncls, int& mx, int& ny, int& cls) {
+    const int sib = tiles_n * ncls, full = (tiles_m >> 3) * 8 * sib;
+    int s;
+    if (L < full) { const int w = L % (8 * sib); mx = (L / (8 * sib)) * 8 + (w & 7); s = w >> 3; }
+    else { const int r = L - full; mx = (tiles_m & ~7) + r / sib; s = r % sib; }
+    ny = s % tiles_n; cls = s / tiles_n;
+}
+
 // WM x WN waves per workgroup (4 or 8 waves); SMALLK: the K-tile spans several taps (first layer, Cin padded to 8),
 // otherwise the tap of a K-tile is wave-uniform and its address arithmetic runs on the scalar unit.
 template <typename T, int BM, int BN, int MODE, int WM, int WN, bool SMALLK>
@@ -485,9 +500,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int cls = MODE == 1 ? (p.ksplit > 1 ? (int)blockIdx.z / p.ksplit : (int)blockIdx.z) : 0;
+    int mxi = blockIdx.x, nyi = blockIdx.y;
+    int cls = MODE == 1 ? (p.ksplit > 1 ? (int)blockIdx.z / p.ksplit : (int)blockIdx.z) : 0;
     const int ks = p.ksplit > 1 ? (MODE == 1 ? (int)blockIdx.z % p.ksplit : (int)blockIdx.z) : 0;
+    if (p.sib_remap && p.ksplit <= 1)
+        tile_decode((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), (int)gridDim.x, (int)gridDim.y,
+                    MODE == 1 ? 4 : 1, mxi, nyi, cls);
+    const int m0 = mxi * BM, n0 = nyi * BN;
     const int py = cls >> 1, px = cls & 1;
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
     const int Ho = MODE == 2 ? p.Hi : p.Hi >> 1, Wo = MODE == 2 ? p.Wi : p.Wi >> 1;
@@ -814,7 +833,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
     struct Addr { int rowoff[NVA]; unsigned rowmask[NVA]; unsigned wrow[NVB]; int m0, n0, py, px; };
     auto setup = [&](int tile, Addr& a) {
         int mx, ny, cls = 0;
-        if (MODE == 1 && p.class_major == 0) {
+        if (p.sib_remap) {
+            tile_decode(tile, tiles_m, tiles_n, MODE == 1 ? 4 : 1, mx, ny, cls);
+        } else if (MODE == 1 && p.class_major == 0) {
             // The four output-parity classes of a (m, n) tile read the SAME input rows.  Tile t runs on XCD t % 8 (workgroups
             // are dealt round-robin to the XCDs and the grid is a multiple of 8), so blocks of 32 consecutive tiles are
             // 8 groups x 4 classes with a group's classes 8 apart: back to back on one XCD, sharing its L2.  In class-major
@@ -993,6 +1014,155 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
         if (!has_next) break;
         cur = nxt; tile = next_tile; first = false;
     }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad on the LDS-DMA ring (16-bit types, Cin a multiple of 64, Cout a multiple of 128): the same contraction as
+// conv_wgrad_kernel, but a workgroup owns FOUR taps (one filter row ky, kx = 0..3) of a 128 (co) x 64 (ci) block and the dy
+// tile is shared by them: 8 waves as tap x co-half, wave tile 64 x 64, BK = 64 output pixels per K step.
+//
+// Why: every conv kernel of this file runs at the rate its LDS fills allow -- bytes in flight per CU / latency (~96 KB /
+// 2.3 us = 41 GB/s per CU under load, measured on every variant: register staging or LDS-DMA, 3- or 6-slot rings, L2-local
+// tile orders made no difference).  One tap per workgroup moves 24 KB per 1.05 MFLOP; four taps move
+// 16 KB (dy) + 4 x 8 KB (x) per 4.2 MFLOP: half the bytes per FLOP.  The four x gathers of a filter row are neighbouring
+// pixels of the same input row.
+//
+// Both operands go global -> LDS by `buffer_load ... lds` into a 3-slot ring (tiles t+1, t+2 in flight behind a counted vmcnt
+// + raw s_barrier); the [k][row] images are read transposed with ds_read_b64_tr_b16.  An LDS-DMA instruction writes 1 KB
+// lane-linearly, so the images cannot be padded; bank conflicts of the transposed reads are removed by XOR swizzles applied
+// to the SOURCE chunk each lane fetches and to the read address:
+//   A = dy tile [64 k][128 co] (256-B rows, 16 chunks of 16 B):  chunk ^ (((k & 3) << 2) | ((k >> 2) & 3))
+//       (cdna_hip_programming.md T10 image (b): conflict-free for row reads and transposed reads)
+//   B = x tiles [4 taps][64 k][64 ci] (128-B rows, 8 chunks):    chunk ^ (((k >> 1) & 1) << 2)
+//       (swaps the 64-B halves of k rows 2, 3 mod 4: the four k rows a 32-lane half reads then cover the four 64-B phases of
+//        a 256-B bank row)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef typename Frag16<T>::type FragT;
+    constexpr int BM = 128, BN = 64, BK = 64, NLA = 2, NLB = 4, NL = NLA + NLB;      // DMA instructions per wave per K tile
+    constexpr int A_BYTES = BK * BM * 2, B_TAP = BK * BN * 2, STAGE = A_BYTES + 4 * B_TAP;   // 16 KB + 4 x 8 KB
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) {                                                  // a K split's workgroups on one XCD (see conv_wgrad_kernel)
+        const int gx = gridDim.x, per = gx * gridDim.y, ns = gridDim.z;
+        const int L = bx + gx * (by + (int)gridDim.y * bz), full = (ns >> 3) * 8 * per;
+        int t;
+        if (L < full) { const int j = L >> 3; bz = (j / per) * 8 + (L & 7); t = j % per; }
+        else { const int r = L - full; bz = (ns & ~7) + r / per; t = r % per; }
+        bx = t % gx; by = t / gx;
+    }
+    const int co0 = bx * BM;
+    const int ntile_ci = p.Cin / BN;
+    const int ky = by / ntile_ci, ci0 = (by % ntile_ci) * BN;           // the workgroup's filter row and input-channel block
+    const int wtap = wave >> 1, wm0 = (wave & 1) * 64;                  // the wave's tap kx and co half
+    const int Wo = p.Wi >> 1, Ktot = p.M;
+    const int kt_beg = bz * p.ktiles_per_split;
+    int kt_end = kt_beg + p.ktiles_per_split;
+    const int nkt = (Ktot + BK - 1) / BK;
+    if (kt_end > nkt) kt_end = nkt;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), dr = make_rsrc(p.w, p.w_bytes);
+
+    // ---- DMA.  A piece j = 2*wave + jj (0..15): k rows 4j + (lane>>4), physical chunk lane&15.
+    //            B piece id = 4*wave + jj (0..31): tap kx = id>>3, k rows 8 (id&7) + (lane>>3), physical chunk lane&7.
+    auto issue = [&](int t, int slot) {
+        unsigned char* base = lds + slot * STAGE;
+        const int k0 = t * BK;
+#pragma unroll
+        for (int jj = 0; jj < NLA; ++jj) {
+            const int j = 2 * wave + jj, kr = 4 * j + (lane >> 4), k = k0 + kr;
+            const int lc = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (lds_void_p)(base + j * 1024), 16,
+                k < Ktot ? (unsigned)((k * p.ldw + co0 + lc * 8) * 2) : OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < NLB; ++jj) {
+            const int id = 4 * wave + jj, kx = id >> 3, j = id & 7, kr = 8 * j + (lane >> 3), k = k0 + kr;
+            const int lc = (lane & 7) ^ (((kr >> 1) & 1) << 2);
+            const int n = k >> p.lgHoWo, rem = k & ((1 << p.lgHoWo) - 1);
+            const int iy = 2 * (rem >> p.lgWo) - 1 + ky, ix = 2 * (rem & (Wo - 1)) - 1 + kx;
+            const bool ok = k < Ktot && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_p)(base + A_BYTES + id * 1024), 16,
+                ok ? (unsigned)((((n * p.Hi + iy) * p.Wi + ix) * p.ldx + ci0 + lc * 8) * 2) : OOB, 0, 0, 0);
+        }
+    };
+    // ---- transposed fragment reads (ds_read_b64_tr_b16: per 16-lane group a 4 (k) x 16 (row) block, column-major out).
+    // Lane 4q+pp of group g supplies k row kb = 16 ks + 8 (g>>1) + q (and kb + 4 for the second half of the fragment),
+    // rows r0 + 16 (g&1) + 4 pp .. +3.  The swizzle keys do not depend on ks (16 ks = 0 mod 16).
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3, hq = 8 * (g >> 1) + q;     // kb = 16 ks + hq
+    const int keyA0 = ((hq & 3) << 2) | ((hq >> 2) & 3), keyA1 = (((hq + 4) & 3) << 2) | (((hq + 4) >> 2) & 3);
+    const int keyB = ((hq >> 1) & 1) << 2;                              // (hq + 4 has the same bit 1)
+    int aoff[2][2], boff[2][2];                                         // byte offsets inside a slot for ks = 0: [block][lo/hi]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cb = (wm0 + 32 * i + 16 * (g & 1) + 4 * pp) * 2;     // byte column of the lane's 4 co rows
+        aoff[i][0] = 256 * hq + 16 * ((cb >> 4) ^ keyA0) + (cb & 15);
+        aoff[i][1] = 256 * (hq + 4) + 16 * ((cb >> 4) ^ keyA1) + (cb & 15);
+        const int cc = (32 * i + 16 * (g & 1) + 4 * pp) * 2;           // ... of its 4 ci columns, in the wave's tap image
+        boff[i][0] = A_BYTES + wtap * B_TAP + 128 * hq + 16 * ((cc >> 4) ^ keyB) + (cc & 15);
+        boff[i][1] = A_BYTES + wtap * B_TAP + 128 * (hq + 4) + 16 * ((cc >> 4) ^ keyB) + (cc & 15);
+    }
+    auto trfrag = [&](const unsigned char* lo, const unsigned char* hi) -> FragT {
+        const s16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lo));
+        const s16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(hi));
+        const s16x8 r = {l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+        return __builtin_bit_cast(FragT, r);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (kt_beg < kt_end) {
+        issue(kt_beg, 0);
+        if (kt_beg + 1 < kt_end) issue(kt_beg + 1, 1);
+        int slot = 0;
+        for (int t = kt_beg; t < kt_end; ++t) {
+            if (t + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* S = lds + slot * STAGE;
+            FragT a[4][2], b[4][2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    b[ks][i] = trfrag(S + boff[i][0] + ks * 2048, S + boff[i][1] + ks * 2048);
+                    a[ks][i] = trfrag(S + aoff[i][0] + ks * 4096, S + aoff[i][1] + ks * 4096);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < kt_end) issue(t + 2, slot == 0 ? 2 : slot - 1);     // the slot of tile t-1
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma(a[ks][i], b[ks][j], acc[i][j]);
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
+    float* slab = static_cast<float*>(p.y) + (size_t)bz * p.Cout * 16 * p.Cin;
+    const int tap = ky * 4 + wtap;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm0 + 32 * i + crow(r, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                slab[((size_t)co * 16 + tap) * p.Cin + ci0 + 32 * j + (lane & 31)] = acc[i][j][r];
+        }
 #endif
 }
 
@@ -1384,6 +1554,10 @@ int ksplit_max() {
     static int v = [] { const char* e = getenv("GCSSL_KSPLIT_MAX"); return e ? atoi(e) : 8; }();
     return v;
 }
+int sib_remap() {
+    static int v = [] { const char* e = getenv("GCSSL_SIB_REMAP"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
 int wgrad_xcd() {
     static int v = [] { const char* e = getenv("GCSSL_WGRAD_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
     return v;
@@ -1541,6 +1715,7 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
     if (ldx % kv || !aligned16(x) || !aligned16(wf)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = x; p.w = wf; p.y = y; p.bias = bias; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
     p.ldx = ldx; p.ldy = ldy; p.act = act; p.out_f32 = out_f32; p.split_stride = split_stride;
+    p.sib_remap = sib_remap();
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)Cout * 16 * Cin, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
     {   // output extent for buffer stores: the last pixel's Cout channels end it
@@ -1566,6 +1741,7 @@ int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, c
     ConvParams p{}; p.x = dy; p.w = wt; p.y = dx; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
     static const int class_major = [] { const char* e = getenv("GCSSL_DGRAD_ORDER"); return (e && e[0] == '1') ? 1 : 0; }();
     p.class_major = class_major;
+    p.sib_remap = class_major ? 0 : sib_remap();
     p.ldx = lddy; p.ldy = lddx; p.out_f32 = out_f32; p.split_stride = split_stride;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     if (!fill_bytes(p, (size_t)N * (Hi / 2) * (Wi / 2) * lddy, (size_t)Cin * 16 * Cout, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
@@ -1580,14 +1756,27 @@ int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, c
 }
 
 // number of split-K slabs gcssl_conv4x4s2_wgrad will write for this geometry (caller sizes the workspace)
+// The filter-row LDS-DMA wgrad kernel serves the layers that give 256 workgroups >= 8 K steps each; with less work per
+// workgroup its 128-KB slab tile costs more than the halved fills save (G.down2..4, G.up1 at batch 256: 17.6 vs 16.3 us).
+static bool wgrad_dma_shape(int N, int Hi, int Wi, int Cin, int Cout) {
+    static const int on = [] { const char* e = getenv("GCSSL_WGRAD_DMA"); return e ? atoi(e) : 1; }();   // A/B knob: 0 off, 2 always
+    if (!on || !use_dma() || Cin % 64 || Cout % 128) return false;
+    const long nkt = ((long)N * (Hi / 2) * (Wi / 2) + 63) / 64, tiles = (long)(Cout / 128) * 4 * (Cin / 64);
+    return on == 2 || tiles * (nkt / 16) >= 128;
+}
+
 int gcssl_conv4x4s2_wgrad_splits(int N, int Hi, int Wi, int Cin, int Cout) {
     if (check_geom(N, Hi, Wi, Cin, Cout)) return GCSSL_EBADSHAPE;
     const int bm = Cout >= 128 ? 128 : 64, bn = Cin >= 128 ? 128 : (Cin >= 64 ? 64 : (Cin == 8 ? 8 : 0));
     if (!bn) return GCSSL_EBADSHAPE;
-    const long tiles = (long)(Cout / bm) * 16 * (Cin / bn) / (Cin == 8 ? 16 : 1);
+    // the LDS-DMA kernel gives a workgroup a whole filter row of a 128 x 64 block and holds one workgroup per CU (144 KB of
+    // LDS); the count depends on the shape only, so that one slab size serves every element type
+    const bool row4 = wgrad_dma_shape(N, Hi, Wi, Cin, Cout);
+    const long tiles = row4 ? (long)(Cout / 128) * 4 * (Cin / 64) : (long)(Cout / bm) * 16 * (Cin / bn) / (Cin == 8 ? 16 : 1);
     const int nkt = (N * (Hi / 2) * (Wi / 2) + 63) / 64;       // K granules of 64 output pixels (dtype independent)
-    static const long target = [] { const char* e = getenv("GCSSL_WGRAD_WGS"); return e ? atol(e) : 512L; }();
-    long want = (target + tiles - 1) / tiles;              // ~2 workgroups per CU
+    static const long target_e = [] { const char* e = getenv("GCSSL_WGRAD_WGS"); return e ? atol(e) : 0L; }();
+    const long target = target_e ? target_e : (row4 ? 256L : 512L);
+    long want = (target + tiles - 1) / tiles;              // ~2 workgroups per CU (1 for the filter-row kernel)
     // padded first layers have a single tile, so only K splits fill the chip: 128 / 256 / 512 splits of D.c1.wgrad (1024
     // samples) take 25.8 / 16.0 / 13.9 us -- a workgroup's time is its K steps -- and the 32-KB slabs stay cheap to reduce
     static const long cap = [] { const char* e = getenv("GCSSL_WGRAD_CAP"); return e ? atol(e) : 512L; }();
@@ -1621,9 +1810,15 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
     hipStream_t st = (hipStream_t)stream;
     const int bm = Cout >= 128 ? 128 : 64, bn = Cin >= 128 ? 128 : 64;
     const bool smallc = Cin == 8;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (dtype != GCSSL_F32 && wgrad_dma_shape(N, Hi, Wi, Cin, Cout)) {
+        dim3 gd(Cout / 128, 4 * (Cin / 64), nsplit);                    // LDS-DMA ring, one filter row (4 taps) per workgroup
+        if (dtype == GCSSL_F16) hipLaunchKernelGGL(conv_wgrad_dma_kernel<f16_t>, gd, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL(conv_wgrad_dma_kernel<bf16_t>, gd, dim3(512), 0, st, p);
+        return gcssl_launch_status();
+    }
     dim3 grid(Cout / bm, smallc ? 1 : 16 * (Cin / bn), nsplit);
 #define WG(T, A, B, S) hipLaunchKernelGGL((conv_wgrad_kernel<T, A, B, S>), grid, dim3(NT), 0, st, p)
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     GCSSL_DISPATCH(dtype,
         if (smallc) { if (bm == 128) WG(T, 128, 128, true); else WG(T, 64, 128, true); }
         else if (bm == 128 && bn == 128) WG(T, 128, 128, false); else if (bm == 128) WG(T, 128, 64, false);
