@@ -128,6 +128,17 @@ template <int NW> __device__ __forceinline__ float block_sum(float v, float* sm)
     return r;
 }
 
+// ---- raw buffer access.  A raw buffer load whose offset lies outside the descriptor's range returns 0 in hardware and a
+// store there is dropped, so validity is a v_cndmask on the OFFSET instead of an exec-mask branch around the access: every
+// lane always issues, and the compiler can batch the loads of a whole tile / row set behind one s_waitcnt.  A descriptor of
+// 0 bytes makes an absent optional operand read as zeros without touching memory.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
 __device__ __forceinline__ float lrelu_f(float x) { return x > 0.f ? x : 0.2f * x; }
 
 // ---- zero fills as KERNELS.  hipMemsetAsync / hipMemset2DAsync must not be used on a path that may be stream-captured: on

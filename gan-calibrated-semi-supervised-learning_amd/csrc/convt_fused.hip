@@ -29,7 +29,6 @@
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_void_p;
-constexpr unsigned OOB = 0x80000000u;
 constexpr float IN_EPS = 1e-5f;
 
 template <typename T> struct FragOf;

@@ -113,11 +113,7 @@ template <int ROWS> struct MMajor<f16_t, ROWS> : MMajor16<f16_t, ROWS> {};
 // Branch-free gather loads.  hipcc turns `ok ? load(p) : 0` into an exec-mask branch per load (each with its own
 // vmcnt drain), which serialises the whole tile fetch; a raw buffer load with an out-of-range offset returns 0 in
 // hardware instead, so every lane always issues the load and validity is a single v_cndmask on the offset.
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-constexpr unsigned OOB = 0x80000000u;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
+// (OOB / make_rsrc: common.h)
 template <typename T> __device__ __forceinline__ Vec16<T> bload(__amdgpu_buffer_rsrc_t r, unsigned off);
 template <> __device__ __forceinline__ Vec16<float> bload<float>(__amdgpu_buffer_rsrc_t r, unsigned off) {
     Vec16<float> v; v.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); return v;

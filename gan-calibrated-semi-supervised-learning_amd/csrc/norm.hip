@@ -55,49 +55,49 @@ __device__ __forceinline__ int replica_offset(int nrep, int rep_stride) {
     return (int)(wg % (unsigned)nrep) * rep_stride;
 }
 
+// Sum RG_ consecutive row groups per 4-channel column; every thread gets its segment's totals.  Threads are laid out
+// threadIdx = ty * 16 + tx, so a wave holds the row groups 4w..4w+3 at lanes l, l+16, l+32, l+48: two xor-shuffles sum
+// them in registers (a 4-group segment is done there), and only the four per-wave partials of a 16-group segment go
+// through LDS.  (The first form -- every thread re-reading all 16 partials of its NV x 4 values from LDS, fully unrolled --
+// cost 128 VGPRs in the backward kernel and held it at one wave per SIMD.)
+template <int NV, int RG_>
+__device__ __forceinline__ void combine_seg(float (&v)[NV][VC], float (*sm)[RGN][CW], int tx, int ty) {
+    static_assert(RG_ == 1 || RG_ == 4 || RG_ == 16, "row groups per segment");
+    static_assert(CGN == 16 && RGN == 16, "lane layout");
+    if (RG_ == 1) return;                                  // the lane already holds its sample's full column sums
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < VC; ++j) {
+            v[i][j] += __shfl_xor(v[i][j], 16, 64);
+            v[i][j] += __shfl_xor(v[i][j], 32, 64);
+        }
+    if (RG_ == 4) return;
+    const int w = ty >> 2;
+    __syncthreads();
+    if ((ty & 3) == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < VC; ++j) sm[i][w][tx * VC + j] = v[i][j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < VC; ++j)
+            v[i][j] = (sm[i][0][tx * VC + j] + sm[i][1][tx * VC + j]) + (sm[i][2][tx * VC + j] + sm[i][3][tx * VC + j]);
+}
+// all 16 row groups of the workgroup
 template <int NV>
 __device__ __forceinline__ void combine16(float (&v)[NV][VC], float (*sm)[RGN][CW], int tx, int ty) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-        for (int j = 0; j < VC; ++j) sm[i][ty][tx * VC + j] = v[i][j];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-        for (int j = 0; j < VC; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int g = 0; g < RGN; ++g) s += sm[i][g][tx * VC + j];
-            v[i][j] = s;
-        }
+    combine_seg<NV, 16>(v, sm, tx, ty);
 }
 
-// Small maps (H*W <= 64): a lane owns 4 rows x 4 channels, RGN_ = ceil(HW/4) in {1,4,16} row-group lanes make up one
-// sample and 16/RGN_ samples share a 256-thread pass (so 2x2 and 4x4 maps still use every lane); a workgroup runs
+// Small maps (H*W <= 64): a lane owns 4 rows x 4 channels, RG_ = ceil(HW/4) in {1,4,16} row-group lanes make up one
+// sample and 16/RG_ samples share a 256-thread pass (so 2x2 and 4x4 maps still use every lane); a workgroup runs
 // several passes and keeps its bias / spectral-norm partial sums in registers -> ONE set of atomics per workgroup
 // (same-address float atomics serialise at ~12 ns each: 1536 workgroups on 3 addresses cost more than the data pass).
-template <int NV, int RG>
-__device__ __forceinline__ void combine_seg(float (&v)[NV][VC], float (*sm)[RGN][CW], int tx, int ty) {
-    if (RG == 1) return;                                   // the lane already holds its sample's full column sums
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-        for (int j = 0; j < VC; ++j) sm[i][ty][tx * VC + j] = v[i][j];
-    __syncthreads();
-    const int g0 = (ty / RG) * RG;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-        for (int j = 0; j < VC; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int g = 0; g < RG; ++g) s += sm[i][g0 + g][tx * VC + j];
-            v[i][j] = s;
-        }
-}
 
 __device__ __forceinline__ void ld4(const float* p, float (&o)[VC]) {
     const float4 t = *reinterpret_cast<const float4*>(p); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
@@ -368,9 +368,30 @@ struct InBwdParams {
     int HW, C, act;
 };
 
+// 16-byte row accesses through buffer descriptors (common.h): offsets that are OOB read 0 / drop the store
+__device__ __forceinline__ void bld4(__amdgpu_buffer_rsrc_t r, unsigned off, float (&o)[VC]) {
+    const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+}
+template <typename T> __device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned off, const float (&v)[VC]) {
+    if constexpr (sizeof(T) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), r, off, 0, 0);
+    } else {
+        const u32x2 w = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(w, r, off, 0, 0);
+    }
+}
+__device__ __forceinline__ unsigned rsrc_bytes(size_t b) { return b < 0x7fffffffu ? (unsigned)b : 0x7fffffffu; }
+
 // small maps: fused backward, several samples per pass and several passes per workgroup (see combine_seg)
 // SLAB: the incoming gradient arrives as split-K slabs.  A separate instantiation, because the mere presence of the fold's
 // store (taken or not) cost the plain kernel 17 -> 28 us: the compiler stops overlapping the samples' loads across it.
+//
+// The row loops are BRANCH-FREE: every row access is a raw buffer access whose offset is OOB for rows past H*W / samples
+// past N (reads 0, store dropped), and an absent optional operand sits behind ONE uniform branch around its whole row set.
+// With per-row `if (p >= HW) continue` / `if (da2p) ...` tests hipcc emitted one exec-mask branch and one vmcnt drain per
+// load -- 4 rows x up to 5 operands of serial round trips at one wave per SIMD (256 VGPRs): D.c2's backward over 768
+// samples took 52 us for 71 MB (1.4 TB/s).  The host refuses tensors of 2 GiB or more (32-bit byte offsets).
 template <typename T, int RG, int MR = MAXR, bool SLAB = false>
 __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, int N, int spb, int mixed_groups) {
     __shared__ float sm[2][RGN][CW];
@@ -380,6 +401,13 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
     const int slot = ty / RG, rg = ty % RG;
     const int c = blockIdx.x * CW + tx * VC;
     const int HW = q.HW, C = q.C;
+    const size_t nhw = (size_t)N * HW;
+    const __amdgpu_buffer_rsrc_t zr = make_rsrc(q.z, rsrc_bytes(nhw * q.ldz * 4)),
+                                 dar = make_rsrc(q.da, q.da ? rsrc_bytes(nhw * q.ldda * 4) : 0u),
+                                 da2r = make_rsrc(q.da2, q.da2 ? rsrc_bytes(nhw * q.ldda2 * 4) : 0u),
+                                 mkr = make_rsrc(q.mask, q.mask ? rsrc_bytes(nhw * C) : 0u),
+                                 ztr = make_rsrc(q.zt, q.zt ? rsrc_bytes((size_t)(N - q.zt_n0) * HW * C * 4) : 0u),
+                                 outr = make_rsrc(q.dzs, rsrc_bytes(nhw * q.lddz * sizeof(T)));
     float b[VC] = {0.f, 0.f, 0.f, 0.f};
     if (q.bias) ld4(q.bias + c, b);
     float sb[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
@@ -388,62 +416,82 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
     for (int n0 = nb; n0 < min(N, nb + spb); n0 += SPP) {
         const int n = n0 + slot;
         const bool live = n < N;
-        const float* zp = q.z + (size_t)n * HW * q.ldz + c;
-        const float* dap = q.da ? q.da + (size_t)n * HW * q.ldda + c : nullptr;
-        const float* da2p = q.da2 ? q.da2 + (size_t)n * HW * q.ldda2 + c : nullptr;
-        const uint8_t* mp = q.mask ? q.mask + (size_t)n * HW * C + c : nullptr;
         float mu[VC] = {0.f, 0.f, 0.f, 0.f}, r[VC] = {0.f, 0.f, 0.f, 0.f}, dab[VC] = {0.f, 0.f, 0.f, 0.f};
         if (live) {
             ld4(q.mean + (size_t)n * C + c, mu); ld4(q.rstd + (size_t)n * C + c, r);
             if (q.da_bcast) ld4(q.da_bcast + (size_t)n * C + c, dab);
         }
-        if (SLAB && dap && live)                                     // split-K slabs of the producing conv
-            fold_slabs<RG, MR>(const_cast<float*>(dap), q.ldda, q.da_nslab, q.da_slab_stride, rg, HW);
+        if (SLAB && q.da && live)                                    // split-K slabs of the producing conv
+            fold_slabs<RG, MR>(const_cast<float*>(q.da) + (size_t)n * HW * q.ldda + c, q.ldda, q.da_nslab, q.da_slab_stride, rg, HW);
+        unsigned pix[MR];                                            // pixel index of row i, or OOB
+#pragma unroll
+        for (int i = 0; i < MR; ++i) { const int p = rg + RG * i; pix[i] = (live && p < HW) ? (unsigned)(n * HW + p) : OOB; }
         float zv[MR][VC], dn[MR][VC];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) bld4(zr, pix[i] != OOB ? (pix[i] * q.ldz + c) * 4u : OOB, zv[i]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) bld4(dar, pix[i] != OOB ? (pix[i] * q.ldda + c) * 4u : OOB, dn[i]);
+        if (q.da2) {
+            float t[MR][VC];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) bld4(da2r, pix[i] != OOB ? (pix[i] * q.ldda2 + c) * 4u : OOB, t[i]);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < VC; ++j) dn[i][j] = (dab[j] + dn[i][j]) + t[i][j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < VC; ++j) dn[i][j] = dab[j] + dn[i][j];
+        }
+        if (q.mask) {
+            unsigned w[MR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b32(mkr, pix[i] != OOB ? pix[i] * C + c : OOB, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < VC; ++j) dn[i][j] *= ((w[i] >> (8 * j)) & 0xFF) ? 2.f : 0.f;
+        }
         float s[2][VC] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int i = 0; i < MR; ++i) {
-            const int p = rg + RG * i;
-            if (!live || p >= HW) continue;
-            ld4(zp + (size_t)p * q.ldz, zv[i]);
-            float d[VC] = {dab[0], dab[1], dab[2], dab[3]};
-            if (dap) {
-                float t[VC]; ld4(dap + (size_t)p * q.ldda, t);
-#pragma unroll
-                for (int j = 0; j < VC; ++j) d[j] += t[j];
-            }
-            if (da2p) {
-                float t[VC]; ld4(da2p + (size_t)p * q.ldda2, t);
-#pragma unroll
-                for (int j = 0; j < VC; ++j) d[j] += t[j];
-            }
-            float k[VC] = {1.f, 1.f, 1.f, 1.f};
-            if (mp) keep4(mp + (size_t)p * C, k);
+        for (int i = 0; i < MR; ++i)
 #pragma unroll
             for (int j = 0; j < VC; ++j) {
                 const float xh = (zv[i][j] - mu[j]) * r[j];
-                dn[i][j] = d[j] * k[j] * act_grad(xh, q.act);
+                dn[i][j] = dn[i][j] * act_grad(xh, q.act);           // (dead rows: dn = 0)
                 s[0][j] += dn[i][j]; s[1][j] += dn[i][j] * xh;
             }
-        }
         combine_seg<2, RG>(s, sm, tx, ty);
         const float gs = (q.gscale && live) ? q.gscale[n / q.group_n] : 1.f;
-        const float* ztp = (q.zt && live && n >= q.zt_n0) ? q.zt + (size_t)(n - q.zt_n0) * HW * C + c : nullptr;
-        T* op = static_cast<T*>(q.dzs) + (size_t)n * HW * q.lddz + c;
+        float zt[MR][VC];
+        if (q.zt) {
+            const bool tn = live && n >= q.zt_n0;
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                bld4(ztr, (tn && pix[i] != OOB) ? ((pix[i] - (unsigned)(q.zt_n0 * HW)) * C + c) * 4u : OOB, zt[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < VC; ++j) zt[i][j] = 0.f;
+        }
+        float m1[VC], m2[VC];
+#pragma unroll
+        for (int j = 0; j < VC; ++j) { m1[j] = s[0][j] / HW; m2[j] = s[1][j] / HW; }
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
-            const int p = rg + RG * i;
-            if (!live || p >= HW) continue;
-            float t[VC] = {0.f, 0.f, 0.f, 0.f}, o[VC];
-            if (ztp) ld4(ztp + (size_t)p * C, t);
+            float o[VC];
 #pragma unroll
             for (int j = 0; j < VC; ++j) {
                 const float xh = (zv[i][j] - mu[j]) * r[j];
-                const float dz = r[j] * (dn[i][j] - s[0][j] / HW - xh * (s[1][j] / HW)) + t[j];
+                float dz = r[j] * (dn[i][j] - m1[j] - xh * m2[j]) + zt[i][j];
+                dz = pix[i] != OOB ? dz : 0.f;                       // dead rows add nothing to the bias / SN sums
                 sb[0][j] += dz; sd += dz * gs * (zv[i][j] - b[j]);
                 o[j] = dz * gs;
             }
-            st4<T>(op + (size_t)p * q.lddz, o);
+            bst4<T>(outr, pix[i] != OOB ? (pix[i] * q.lddz + c) * (unsigned)sizeof(T) : OOB, o);
         }
         if (mixed_groups && q.cdot) {          // tiny batches only: a pass may straddle sample groups
             if (live && sd != 0.f) atomicAdd(q.cdot + replica_offset(q.nrep, q.rep_stride) + n / q.group_n, sd);
