@@ -13,6 +13,7 @@
 // same reason every INCOMING gradient of the backward kernels (da, da2, gb_a, qz, zt) is fp32 -- they come out of fp32
 // MFMA accumulators anyway -- and only the tensors that feed the next MFMA (a, dzs, gt_a, gb_zs) are in `dtype`.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -129,7 +130,23 @@ __device__ __forceinline__ void keep4(const uint8_t* mp, float (&k)[VC]) {
     for (int j = 0; j < VC; ++j) k[j] = ((w >> (8 * j)) & 0xFF) ? 2.f : 0.f;
 }
 
+// 16-byte row accesses through buffer descriptors (common.h): offsets that are OOB read 0 / drop the store
+__device__ __forceinline__ void bld4(__amdgpu_buffer_rsrc_t r, unsigned off, float (&o)[VC]) {
+    const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+}
+template <typename T> __device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned off, const float (&v)[VC]) {
+    if constexpr (sizeof(T) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), r, off, 0, 0);
+    } else {
+        const u32x2 w = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(w, r, off, 0, 0);
+    }
+}
+__device__ __forceinline__ unsigned rsrc_bytes(size_t b) { return b < 0x7fffffffu ? (unsigned)b : 0x7fffffffu; }
+
 // ---- forward, small maps: a = act((z - mean) * rstd) [* keep * 2]; writes mean/rstd [N][C]
+// Row accesses are branch-free buffer accesses (see in_bwd_small_kernel): dead rows read 0 and are left out of the variance.
 template <typename T, int RG, int MR = MAXR, bool SLAB = false>
 __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(float* __restrict__ z, int ldz, T* __restrict__ a, int lda,
                                                                 float* __restrict__ mean, float* __restrict__ rstd,
@@ -140,39 +157,45 @@ __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(float* __restri
     const int tx = threadIdx.x % CGN, ty = threadIdx.x / CGN;
     const int slot = ty / RG, rg = ty % RG;
     const int c = blockIdx.x * CW + tx * VC;
+    const size_t nhw = (size_t)N * HW;
+    const __amdgpu_buffer_rsrc_t zr = make_rsrc(z, rsrc_bytes(nhw * ldz * 4)), mkr = make_rsrc(mask, mask ? rsrc_bytes(nhw * C) : 0u),
+                                 outr = make_rsrc(a, rsrc_bytes(nhw * lda * sizeof(T)));
     for (int n0 = blockIdx.y * spb; n0 < min(N, (int)(blockIdx.y + 1) * spb); n0 += SPP) {
         const int n = n0 + slot;
         const bool live = n < N;
-        float* zp = z + (size_t)n * HW * ldz + c;
+        unsigned pix[MR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) { const int p = rg + RG * i; pix[i] = (live && p < HW) ? (unsigned)(n * HW + p) : OOB; }
         float v[MR][VC];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) bld4(zr, pix[i] != OOB ? (pix[i] * ldz + c) * 4u : OOB, v[i]);
+        if (SLAB) {                               // split-K partial sums of the producing conv: add the slabs, keep the total
+            for (int k = 1; k < nslab; ++k) {
+                const __amdgpu_buffer_rsrc_t sr = make_rsrc(z + (size_t)k * slab_stride, rsrc_bytes(nhw * ldz * 4));
+                float t[MR][VC];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) bld4(sr, pix[i] != OOB ? (pix[i] * ldz + c) * 4u : OOB, t[i]);
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < VC; ++j) v[i][j] += t[i][j];
+            }
+#pragma unroll
+            for (int i = 0; i < MR; ++i) bst4<float>(zr, pix[i] != OOB ? (pix[i] * ldz + c) * 4u : OOB, v[i]);
+        }
         float s[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int i = 0; i < MR; ++i) {
-            const int p = rg + RG * i;
-            if (live && p < HW) {
-                ld4(zp + (size_t)p * ldz, v[i]);
-                if (SLAB) {                       // split-K partial sums of the producing conv: add the slabs, keep the total
-                    for (int k = 1; k < nslab; ++k) {
-                        float t[VC]; ld4(zp + (size_t)k * slab_stride + (size_t)p * ldz, t);
+        for (int i = 0; i < MR; ++i)
 #pragma unroll
-                        for (int j = 0; j < VC; ++j) v[i][j] += t[j];
-                    }
-                    st4<float>(zp + (size_t)p * ldz, v[i]);
-                }
-#pragma unroll
-                for (int j = 0; j < VC; ++j) s[0][j] += v[i][j];
-            }
-        }
+            for (int j = 0; j < VC; ++j) s[0][j] += v[i][j];
         combine_seg<1, RG>(s, sm, tx, ty);
         float mu[VC], r[VC];
 #pragma unroll
         for (int j = 0; j < VC; ++j) { mu[j] = s[0][j] / HW; s[0][j] = 0.f; }
 #pragma unroll
         for (int i = 0; i < MR; ++i)
-            if (live && rg + RG * i < HW) {
 #pragma unroll
-                for (int j = 0; j < VC; ++j) { const float d = v[i][j] - mu[j]; s[0][j] += d * d; }
-            }
+            for (int j = 0; j < VC; ++j) { const float d = v[i][j] - mu[j]; s[0][j] += pix[i] != OOB ? d * d : 0.f; }
         combine_seg<1, RG>(s, sm, tx, ty);
 #pragma unroll
         for (int j = 0; j < VC; ++j) r[j] = 1.0f / sqrtf(s[0][j] / HW + IN_EPS);
@@ -180,16 +203,20 @@ __global__ __launch_bounds__(CGN * RGN) void in_fwd_small_kernel(float* __restri
             st4<float>(mean + (size_t)n * C + c, mu);
             st4<float>(rstd + (size_t)n * C + c, r);
         }
-        T* ap = a + (size_t)n * HW * lda + c;
+        unsigned w[MR];
+        if (mask) {
+#pragma unroll
+            for (int i = 0; i < MR; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b32(mkr, pix[i] != OOB ? pix[i] * C + c : OOB, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
-            const int p = rg + RG * i;
-            if (!live || p >= HW) continue;
-            float o[VC], k[VC] = {1.f, 1.f, 1.f, 1.f};
-            if (mask) keep4(mask + ((size_t)n * HW + p) * C + c, k);
+            float o[VC];
 #pragma unroll
-            for (int j = 0; j < VC; ++j) o[j] = act_fwd((v[i][j] - mu[j]) * r[j], act) * k[j];
-            st4<T>(ap + (size_t)p * lda, o);
+            for (int j = 0; j < VC; ++j) {
+                o[j] = act_fwd((v[i][j] - mu[j]) * r[j], act);
+                if (mask) o[j] *= ((w[i] >> (8 * j)) & 0xFF) ? 2.f : 0.f;
+            }
+            bst4<T>(outr, pix[i] != OOB ? (pix[i] * lda + c) * (unsigned)sizeof(T) : OOB, o);
         }
     }
 }
@@ -367,21 +394,6 @@ struct InBwdParams {
     int da_nslab; long da_slab_stride; // da is the first of da_nslab split-K partial-sum slabs of the producing conv (floats apart)
     int HW, C, act;
 };
-
-// 16-byte row accesses through buffer descriptors (common.h): offsets that are OOB read 0 / drop the store
-__device__ __forceinline__ void bld4(__amdgpu_buffer_rsrc_t r, unsigned off, float (&o)[VC]) {
-    const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
-}
-template <typename T> __device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned off, const float (&v)[VC]) {
-    if constexpr (sizeof(T) == 4) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), r, off, 0, 0);
-    } else {
-        const u32x2 w = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-        __builtin_amdgcn_raw_buffer_store_b64(w, r, off, 0, 0);
-    }
-}
-__device__ __forceinline__ unsigned rsrc_bytes(size_t b) { return b < 0x7fffffffu ? (unsigned)b : 0x7fffffffu; }
 
 // small maps: fused backward, several samples per pass and several passes per workgroup (see combine_seg)
 // SLAB: the incoming gradient arrives as split-K slabs.  A separate instantiation, because the mere presence of the fold's
@@ -669,67 +681,84 @@ __global__ __launch_bounds__(CW * RG) void in_dbl_bwd_kernel(InDblParams q) {
 // small maps, vectorised double backward (same math as in_dbl_bwd_kernel)
 template <typename T, int RG, bool SLAB = false>
 __global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, int N, int spb) {
+    // (branch-free buffer row accesses, as in in_bwd_small_kernel)
     __shared__ float sm[5][RGN][CW];
     __shared__ float red[CGN * RGN / 64];
-    constexpr int SPP = RGN / RG;
+    constexpr int SPP = RGN / RG, MR = MAXR;
     const int tx = threadIdx.x % CGN, ty = threadIdx.x / CGN;
     const int slot = ty / RG, rg = ty % RG;
     const int c = blockIdx.x * CW + tx * VC;
     const int HW = q.HW, C = q.C;
+    const size_t nhw = (size_t)N * HW;
+    const __amdgpu_buffer_rsrc_t zr = make_rsrc(q.z, rsrc_bytes(nhw * q.ldz * 4)), gr = make_rsrc(q.gb_a, rsrc_bytes(nhw * q.ldgb * 4)),
+                                 qr = make_rsrc(q.qz, rsrc_bytes(nhw * q.ldq * 4)),
+                                 gzr = make_rsrc(q.gb_zs, q.gb_zs ? rsrc_bytes(nhw * q.ldgz * sizeof(T)) : 0u),
+                                 gar = make_rsrc(q.gt_a, rsrc_bytes(nhw * q.ldga * sizeof(T))), ztr = make_rsrc(q.zt, rsrc_bytes(nhw * C * 4));
     float sd = 0.f;
     const int nb = blockIdx.y * spb;
     for (int n0 = nb; n0 < min(N, nb + spb); n0 += SPP) {
         const int n = n0 + slot;
         const bool live = n < N;
-        const float* zp = q.z + (size_t)n * HW * q.ldz + c;
-        const float* gp = q.gb_a + (size_t)n * HW * q.ldgb + c;
-        const float* qp = q.qz + (size_t)n * HW * q.ldq + c;
-        const T* gzp = q.gb_zs ? static_cast<const T*>(q.gb_zs) + (size_t)n * HW * q.ldgz + c : nullptr;
         float mu[VC] = {0.f, 0.f, 0.f, 0.f}, r[VC] = {0.f, 0.f, 0.f, 0.f};
         if (live) { ld4(q.mean + (size_t)n * C + c, mu); ld4(q.rstd + (size_t)n * C + c, r); }
         if (SLAB && live)                                             // split-K slabs of the producing conv (see fold_slabs)
-            fold_slabs<RG, MAXR>(const_cast<float*>(qp), q.ldq, q.q_nslab, q.q_slab_stride, rg, HW);
-        float xh[MAXR][VC], dn[MAXR][VC], qq[MAXR][VC], ag[MAXR][VC];
+            fold_slabs<RG, MAXR>(const_cast<float*>(q.qz) + (size_t)n * HW * q.ldq + c, q.ldq, q.q_nslab, q.q_slab_stride, rg, HW);
+        unsigned pix[MR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) { const int p = rg + RG * i; pix[i] = (live && p < HW) ? (unsigned)(n * HW + p) : OOB; }
+        float xh[MR][VC], dn[MR][VC], qq[MR][VC];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) bld4(zr, pix[i] != OOB ? (pix[i] * q.ldz + c) * 4u : OOB, xh[i]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) bld4(gr, pix[i] != OOB ? (pix[i] * q.ldgb + c) * 4u : OOB, dn[i]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) bld4(qr, pix[i] != OOB ? (pix[i] * q.ldq + c) * 4u : OOB, qq[i]);
+        if (q.gb_zs) {
+            float gz[MR][VC];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                const unsigned off = pix[i] != OOB ? (pix[i] * q.ldgz + c) * (unsigned)sizeof(T) : OOB;
+                if constexpr (sizeof(T) == 4) bld4(gzr, off, gz[i]);
+                else {
+                    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(gzr, off, 0, 0);
+                    gz[i][0] = Bits16<T>::dec(w[0]); gz[i][1] = Bits16<T>::dec(w[0] >> 16);
+                    gz[i][2] = Bits16<T>::dec(w[1]); gz[i][3] = Bits16<T>::dec(w[1] >> 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < VC; ++j) sd += gz[i][j] * qq[i][j];
+        }
         float s[5][VC];
 #pragma unroll
         for (int i = 0; i < 5; ++i)
 #pragma unroll
             for (int j = 0; j < VC; ++j) s[i][j] = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
-            const int p = rg + RG * i;
-            if (!live || p >= HW) continue;
-            float zv[VC], g[VC];
-            ld4(zp + (size_t)p * q.ldz, zv); ld4(gp + (size_t)p * q.ldgb, g); ld4(qp + (size_t)p * q.ldq, qq[i]);
-            float gz[VC] = {0.f, 0.f, 0.f, 0.f};
-            if (gzp) ldT4<T>(gzp + (size_t)p * q.ldgz, gz);
+        for (int i = 0; i < MR; ++i)
 #pragma unroll
             for (int j = 0; j < VC; ++j) {
-                xh[i][j] = (zv[j] - mu[j]) * r[j];
-                ag[i][j] = act_grad(xh[i][j], q.act);
-                dn[i][j] = ag[i][j] * g[j];
+                xh[i][j] = pix[i] != OOB ? (xh[i][j] - mu[j]) * r[j] : 0.f;
+                dn[i][j] = act_grad(xh[i][j], q.act) * dn[i][j];              // (dead rows: gb_a = q = 0)
                 s[0][j] += dn[i][j]; s[1][j] += dn[i][j] * xh[i][j]; s[2][j] += qq[i][j];
                 s[3][j] += qq[i][j] * xh[i][j]; s[4][j] += qq[i][j] * dn[i][j];
-                sd += gz[j] * qq[i][j];
             }
-        }
         combine_seg<5, RG>(s, sm, tx, ty);
         const float inv = 1.f / HW;
-        T* gap = static_cast<T*>(q.gt_a) + (size_t)n * HW * q.ldga + c;
-        float* ztp = q.zt + (size_t)n * HW * C + c;
+        float m1[VC], m2[VC], mq[VC], mqx[VC], mqd[VC];
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
-            const int p = rg + RG * i;
-            if (!live || p >= HW) continue;
+        for (int j = 0; j < VC; ++j) { m1[j] = s[0][j] * inv; m2[j] = s[1][j] * inv; mq[j] = s[2][j] * inv; mqx[j] = s[3][j] * inv; mqd[j] = s[4][j] * inv; }
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
             float o[VC], zt[VC];
 #pragma unroll
             for (int j = 0; j < VC; ++j) {
-                const float m1 = s[0][j] * inv, m2 = s[1][j] * inv, mq = s[2][j] * inv, mqx = s[3][j] * inv, mqd = s[4][j] * inv;
-                o[j] = ag[i][j] * r[j] * (qq[i][j] - mq - xh[i][j] * mqx);
-                zt[j] = r[j] * r[j] * (-xh[i][j] * (mqd - mq * m1 - 3.f * mqx * m2) - m2 * (qq[i][j] - mq) - mqx * (dn[i][j] - m1));
+                o[j] = act_grad(xh[i][j], q.act) * r[j] * (qq[i][j] - mq[j] - xh[i][j] * mqx[j]);
+                zt[j] = r[j] * r[j] * (-xh[i][j] * (mqd[j] - mq[j] * m1[j] - 3.f * mqx[j] * m2[j]) - m2[j] * (qq[i][j] - mq[j]) - mqx[j] * (dn[i][j] - m1[j]));
             }
-            st4<T>(gap + (size_t)p * q.ldga, o);
-            st4<float>(ztp + (size_t)p * C, zt);
+            bst4<T>(gar, pix[i] != OOB ? (pix[i] * q.ldga + c) * (unsigned)sizeof(T) : OOB, o);
+            bst4<float>(ztr, pix[i] != OOB ? (pix[i] * C + c) * 4u : OOB, zt);
         }
     }
     if (q.cdot) {
@@ -835,6 +864,8 @@ bool bad_dtype(int dt) { return gcssl_bad_dtype(dt); }
 
 // row-group lanes per sample for a small map, and samples per workgroup (a multiple of the samples per pass that keeps
 // >= ~256 workgroups and, when per-group sums are accumulated, never straddles a sample group)
+// the small-map kernels address rows with 32-bit byte offsets into buffer descriptors
+bool fits_buffer(size_t n, size_t hw, int ld_max) { return n * hw * (size_t)ld_max * 4 < 0x80000000ull; }
 int small_rg(int HW) { return HW <= 4 ? 1 : (HW <= 16 ? 4 : 16); }
 int small_spb(int N, int C, int rg, int group_n) {
     // streaming passes want several workgroups per CU in flight (256 -> 1024: +2 % on the whole iteration); the sums they
@@ -872,6 +903,7 @@ int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean
     if (!aligned16(z) || (((uintptr_t)a) & 7)) return GCSSL_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     if (HW <= MID_HW && !pool) {
+        if (!fits_buffer(N, HW, ldz > lda ? ldz : lda)) return GCSSL_EBADSHAPE;
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, 0);
         dim3 grid(C / CW, (N + spb - 1) / spb);
 #define FWD_SMALL(T, RG, MR) do { if (nslab > 1) hipLaunchKernelGGL((in_fwd_small_kernel<T, RG, MR, true>), grid, dim3(CGN * RGN), 0, st, z, ldz, (T*)a, lda, mean, rstd, mask, N, HW, C, act, spb, nslab, slab_stride); \
@@ -923,6 +955,7 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
                   group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, nrep, rep_stride, da_nslab, da_slab_stride, HW, C, act};
     hipStream_t st = (hipStream_t)stream;
     if (HW <= MID_HW) {
+        if (!fits_buffer(N, HW, std::max(std::max(ldz, lddz), std::max(da ? ldda : 0, da2 ? ldda2 : 0)))) return GCSSL_EBADSHAPE;
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, cdot ? q.group_n : 0);
         const int mixed = (cdot && q.group_n % spb) ? 1 : 0;
         dim3 grid(C / CW, (N + spb - 1) / spb);
@@ -953,6 +986,7 @@ int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, in
     const bool small = HW <= SMALL_HW && !(ldgb % 4) && !(ldq % 4) && !(ldz % 4) && !(ldga % 4) && (!gb_zs || !(ldgz % 4));
     if (q_nslab > 1 && !small) return GCSSL_EBADSHAPE;      // slabs are summed by the fused small-map kernel only
     if (small) {
+        if (!fits_buffer(N, HW, std::max(std::max(ldz, ldgb), std::max(std::max(ldq, ldga), std::max(ldgz, C))))) return GCSSL_EBADSHAPE;
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, 0);
         dim3 sgrid(C / CW, (N + spb - 1) / spb);
         hipStream_t st = (hipStream_t)stream;
