@@ -63,9 +63,9 @@ __global__ void prep_c5_kernel(const float* __restrict__ w, float* __restrict__ 
     wp[idx] = w[(size_t)ci * 16 + tap];
 }
 
-// one wave per output element
+// one wave per output element, one channel per lane and load (shapes the vector form below does not take)
 template <typename T>
-__global__ void c5_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ wp, float* __restrict__ out,
+__global__ void c5_fwd_scalar_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ wp, float* __restrict__ out,
                               int N, int Hi, int Wi, int C) {
     const int Ho = Hi - 1, Wo = Wi - 1;
     const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -81,6 +81,51 @@ __global__ void c5_fwd_kernel(const T* __restrict__ x, int ldx, const float* __r
             const T* xp = x + ((size_t)(n * Hi + iy) * Wi + ix) * ldx;
             const float* wq = wp + (ky * 4 + kx) * C;
             for (int c = lane; c < C; c += 64) s += Elem<T>::ld(xp + c) * wq[c];
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[wid] = s;
+}
+
+// one wave per output element; a lane owns 16 bytes of channels per tap, and the 16 taps' loads are issued together as
+// raw buffer loads (taps outside the map: OOB offset, reads 0) -- the scalar form is a chain of dependent 2-byte loads.
+// Needs C and ldx to be multiples of the 16-byte vector and a 16-byte aligned x.
+template <typename T>
+__global__ __launch_bounds__(256) void c5_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ wp,
+                                                    float* __restrict__ out, int N, int Hi, int Wi, int C) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int Ho = Hi - 1, Wo = Wi - 1;
+    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wid >= N * Ho * Wo) return;
+    const int n = wid / (Ho * Wo), oy = (wid / Wo) % Ho, ox = wid % Wo;
+    const size_t xb = (size_t)N * Hi * Wi * ldx * sizeof(T);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, xb < 0x7fffffffu ? (unsigned)xb : 0x7fffffffu);
+    float s = 0.f;
+    for (int c = lane * VEC; c < C; c += 64 * VEC) {
+        u32x4 xv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int iy = oy - 1 + (t >> 2), ix = ox - 1 + (t & 3);
+            const bool ok = (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+            xv[t] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((((n * Hi + iy) * Wi + ix) * ldx + c) * sizeof(T)) : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int iy = oy - 1 + (t >> 2), ix = ox - 1 + (t & 3);
+            if ((unsigned)iy >= (unsigned)Hi || (unsigned)ix >= (unsigned)Wi) continue;      // (uniform over the wave)
+            const float* wq = wp + t * C + c;
+            float wv[VEC], xf[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; j += 4) { const float4 w4 = *reinterpret_cast<const float4*>(wq + j); wv[j] = w4.x; wv[j + 1] = w4.y; wv[j + 2] = w4.z; wv[j + 3] = w4.w; }
+            if constexpr (sizeof(T) == 4) {
+                const float4 f = __builtin_bit_cast(float4, xv[t]);
+                xf[0] = f.x; xf[1] = f.y; xf[2] = f.z; xf[3] = f.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xf[2 * j] = Bits16<T>::dec(xv[t][j]); xf[2 * j + 1] = Bits16<T>::dec(xv[t][j] >> 16); }
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s += xf[j] * wv[j];
         }
     }
     s = wave_sum(s);
@@ -197,89 +242,111 @@ __global__ void pack_fake_interp_kernel(const float* __restrict__ pred, const fl
 struct SnLayer { const float* w; float* u; float* v; float* t; float* s; int rows, cols; };
 struct SnBatch { SnLayer l[4]; int nl; float* sigma; float* isig; float* u_hist; float* v_hist; int hist_stride_u, hist_stride_v; int slot, nslots; };
 
-// t += W^T u : block = 64 columns x 4 row groups over a 64-row slab (blockIdx.z); t is zeroed by the launcher.
-// Row slabs give every layer >= 8x more workgroups than a column-only split (the 512x4096 layer: 512 instead of 64).
+// t += W^T u : block = 256 columns (64 lanes x 4) x 4 row groups over a 32-row slab (blockIdx.z); t is zero on entry.
+// A lane's 8 rows are 8 independent 16-byte loads (row / column overruns are clamped and weighted 0, so no branches sit
+// between them); row slabs give the 512 x 4096 layer 256 workgroups.  Column counts that are not a multiple of 4 take the
+// scalar form (one column per lane).
+constexpr int SN_SLAB = 32;
 __global__ __launch_bounds__(256) void sn_wtu_kernel(SnBatch b) {
     const SnLayer L = b.l[blockIdx.y];
-    __shared__ float sm[4][64];
+    __shared__ float sm[4][256];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + tx;
-    const int r0 = blockIdx.z * 64, r1 = min(L.rows, r0 + 64);
-    if (blockIdx.x * 64 >= L.cols || r0 >= L.rows) return;
-    float s = 0.f;
-    if (col < L.cols)
-        for (int r = r0 + ty; r < r1; r += 4) s += L.w[(size_t)r * L.cols + col] * L.u[r];
-    sm[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && col < L.cols) atomicAdd(L.t + col, sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx]);
+    const int r0 = blockIdx.z * SN_SLAB;
+    const bool vec = (L.cols & 3) == 0;
+    const int cpb = vec ? 256 : 64;
+    if ((int)blockIdx.x * cpb >= L.cols || r0 >= L.rows) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+        const int col = (blockIdx.x * 64 + tx) * 4, cc = col < L.cols ? col : 0;
+#pragma unroll
+        for (int k = 0; k < SN_SLAB / 4; ++k) {
+            const int r = r0 + ty + 4 * k, rc = r < L.rows ? r : L.rows - 1;
+            const float4 w = *reinterpret_cast<const float4*>(L.w + (size_t)rc * L.cols + cc);
+            const float u = r < L.rows ? L.u[rc] : 0.f;
+            acc[0] += w.x * u; acc[1] += w.y * u; acc[2] += w.z * u; acc[3] += w.w * u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[ty][tx * 4 + j] = acc[j];
+        __syncthreads();
+        if (ty == 0 && col < L.cols) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                atomicAdd(L.t + col + j, (sm[0][tx * 4 + j] + sm[1][tx * 4 + j]) + (sm[2][tx * 4 + j] + sm[3][tx * 4 + j]));
+        }
+    } else {
+        const int col = blockIdx.x * 64 + tx;
+        if (col < L.cols)
+            for (int r = r0 + ty; r < min(L.rows, r0 + SN_SLAB); r += 4) acc[0] += L.w[(size_t)r * L.cols + col] * L.u[r];
+        sm[ty][tx] = acc[0];
+        __syncthreads();
+        if (ty == 0 && col < L.cols) atomicAdd(L.t + col, (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]));
+    }
 }
 
-// Blocks-finished counters of sn_wv_kernel, one per layer slot; self-resetting.  One power iteration may be in flight
-// per process at a time (the engine issues them on one stream).
-__device__ unsigned g_sn_done[4];
+// waves that share a row: each streams <= 1024 columns, i.e. 4 16-byte loads per lane, all in flight at once
+__host__ __device__ __forceinline__ int sn_waves_per_row(int cols) { return (cols & 3) ? 1 : (cols >= 4096 ? 4 : (cols >= 2048 ? 2 : 1)); }
 
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// s = (W t) / max(|t|, eps): one wave per row (4 rows per block), one pass of 16-byte loads that accumulates both
-// the row's dot product and |t|^2 (every wave reads all of t anyway); block 0 also publishes v.  (One row per block -- 960 blocks -- measured
-// SLOWER, 25 vs 16 us: every block ends with an atomic on the layer's completion counter and same-address atomics
-// serialise at ~12 ns.)  The last block of a
-// layer to finish then closes the iteration: u = s / max(|s|, eps), sigma = u . s, and t is zeroed again for the next
-// call (every block of the layer has consumed it by then).
+// s = (W t) / max(|t|, eps).  A block is 4 waves = 4 / wpr rows; a wave streams its column segment of the row once with
+// 16-byte loads and accumulates both the dot product and |t|^2 of the segment (the waves of a row cover all of t between
+// them); block 0 also publishes v.  (The first form -- one wave per whole row, 128 blocks for the 512 x 4096 layer -- was
+// latency-bound at 16 us: 4 dependent load batches per wave on half the CUs.)
+//
+// The iteration is closed by sn_finish_kernel, a separate launch, NOT by "the last block to finish": that pattern needs a
+// device-scope release fence + counter atomic in every block, and on this part a device-scope release writes the XCD's L2
+// back (the L2s of the 8 XCDs are not coherent with each other) -- measured 16 us with 128 blocks, 22.6 us with 512 blocks
+// behind two-level counters, 25 us with 960 blocks.  A kernel boundary does that write-back once.
 __global__ __launch_bounds__(256) void sn_wv_kernel(SnBatch b) {
     const SnLayer L = b.l[blockIdx.y];
-    __shared__ float red[4];
-    __shared__ int last;
-    const int nblk = (L.rows + 3) / 4;
+    __shared__ float part[2][4];
+    const int wpr = sn_waves_per_row(L.cols), rpb = 4 / wpr;
+    const int nblk = (L.rows + rpb - 1) / rpb;
     if ((int)blockIdx.x >= nblk) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
+    const int row = blockIdx.x * rpb + wave / wpr, seg = wave % wpr;
+    const bool rv = row < L.rows;
     const int c4 = (L.cols & 3) ? 0 : L.cols >> 2;          // vector part (all of it for the critic's shapes)
+    const int per = (c4 + wpr - 1) / wpr, cbeg = seg * per, cend = min(c4, cbeg + per);
     const float4* t4 = reinterpret_cast<const float4*>(L.t);
+    const float4* w4 = reinterpret_cast<const float4*>(L.w + (size_t)(rv ? row : 0) * L.cols);
     float q = 0.f, s = 0.f;
-    if (row < L.rows) {
-        const float4* w4 = reinterpret_cast<const float4*>(L.w + (size_t)row * L.cols);
 #pragma unroll 4
-        for (int c = lane; c < c4; c += 64) {
-            const float4 t = t4[c], w = w4[c];
-            q += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
-            s += w.x * t.x + w.y * t.y + w.z * t.z + w.w * t.w;
-        }
-        for (int c = c4 * 4 + lane; c < L.cols; c += 64) { const float t = L.t[c]; q += t * t; s += L.w[(size_t)row * L.cols + c] * t; }
-    } else {
-        for (int c = lane; c < L.cols; c += 64) { const float t = L.t[c]; q += t * t; }
+    for (int c = cbeg + lane; c < cend; c += 64) {
+        const float4 t = t4[c], w = w4[c];
+        q += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+        s += w.x * t.x + w.y * t.y + w.z * t.z + w.w * t.w;
+    }
+    for (int c = c4 * 4 + lane; c < L.cols; c += 64) {       // (columns not a multiple of 4: wpr == 1)
+        const float t = L.t[c]; q += t * t; s += L.w[(size_t)(rv ? row : 0) * L.cols + c] * t;
     }
     q = wave_sum(q); s = wave_sum(s);
-    const float inv = 1.f / fmaxf(sqrtf(q), 1e-12f);
-    if (row < L.rows && lane == 0) L.s[row] = s * inv;
+    if (lane == 0) { part[0][wave] = q; part[1][wave] = s; }
+    __syncthreads();
+    float qq = 0.f, ss = 0.f;
+    for (int k = 0; k < wpr; ++k) { qq += part[0][(wave / wpr) * wpr + k]; ss += part[1][(wave / wpr) * wpr + k]; }
+    const float inv = 1.f / fmaxf(sqrtf(qq), 1e-12f);
+    if (rv && seg == 0 && lane == 0) L.s[row] = ss * inv;
     if (blockIdx.x == 0) {
         float* vh = b.v_hist + ((size_t)blockIdx.y * b.nslots + b.slot) * b.hist_stride_v;
         for (int c = threadIdx.x; c < L.cols; c += 256) { const float vv = L.t[c] * inv; L.v[c] = vv; vh[c] = vv; }
     }
-    __syncthreads();                                         // all four rows (and v) of this block are written
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(&g_sn_done[blockIdx.y], 1u) == (unsigned)(nblk - 1);
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    float qq = 0.f;
-    for (int r = threadIdx.x; r < L.rows; r += 256) { const float sv = ld_agent(L.s + r); qq += sv * sv; }
-    const float ss = block_sum<4>(qq, red);
-    const float uinv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
-    float* uh = b.u_hist + ((size_t)blockIdx.y * b.nslots + b.slot) * b.hist_stride_u;
-    for (int r = threadIdx.x; r < L.rows; r += 256) { const float uu = ld_agent(L.s + r) * uinv; L.u[r] = uu; uh[r] = uu; }
+}
+// one block per layer: u = s / max(|s|, eps), sigma = u . s, and t is zeroed again for the next iteration
+__global__ __launch_bounds__(256) void sn_finish_kernel(SnBatch b) {
+    const SnLayer L = b.l[blockIdx.x];
+    __shared__ float red[4];
+    float q2 = 0.f;
+    for (int r = threadIdx.x; r < L.rows; r += 256) { const float sv = L.s[r]; q2 += sv * sv; }
+    const float s2 = block_sum<4>(q2, red);
+    const float uinv = 1.f / fmaxf(sqrtf(s2), 1e-12f);
+    float* uh = b.u_hist + ((size_t)blockIdx.x * b.nslots + b.slot) * b.hist_stride_u;
+    for (int r = threadIdx.x; r < L.rows; r += 256) { const float uu = L.s[r] * uinv; L.u[r] = uu; uh[r] = uu; }
     for (int c = threadIdx.x; c < L.cols; c += 256) L.t[c] = 0.f;
     if (threadIdx.x == 0) {
-        const float sg = ss * uinv;
-        b.sigma[blockIdx.y * b.nslots + b.slot] = sg;
-        b.isig[blockIdx.y * b.nslots + b.slot] = 1.f / sg;
-        g_sn_done[blockIdx.y] = 0u;
+        const float sg = s2 * uinv;
+        b.sigma[blockIdx.x * b.nslots + b.slot] = sg;
+        b.isig[blockIdx.x * b.nslots + b.slot] = 1.f / sg;
     }
 }
-
-// eval mode: sigma = u . (W v) with the stored u, v (no iteration)
 __global__ __launch_bounds__(256) void sn_sigma_kernel(SnBatch b) {
     const SnLayer L = b.l[blockIdx.x];
     __shared__ float red[4];
@@ -686,7 +753,12 @@ int gcssl_conv4x4s1_c1_fwd(int dtype, const void* x, int ldx, const float* wp, f
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || ldx < C) return GCSSL_EBADSHAPE;
     const size_t threads = (size_t)N * (Hi - 1) * (Wi - 1) * 64;
-    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(c5_fwd_kernel<T>, GRID1(threads), (const T*)x, ldx, wp, out, N, Hi, Wi, C));
+    const int vec = dtype == GCSSL_F32 ? 4 : 8;
+    const bool vec_ok = C % vec == 0 && ldx % vec == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)wp) & 15) == 0 &&
+                        (size_t)N * Hi * Wi * ldx * (dtype == GCSSL_F32 ? 4 : 2) < 0x80000000ull;
+    GCSSL_DISPATCH(dtype,
+        if (vec_ok) hipLaunchKernelGGL(c5_fwd_kernel<T>, GRID1(threads), (const T*)x, ldx, wp, out, N, Hi, Wi, C);
+        else hipLaunchKernelGGL(c5_fwd_scalar_kernel<T>, GRID1(threads), (const T*)x, ldx, wp, out, N, Hi, Wi, C));
     return gcssl_launch_status();
 }
 
@@ -722,21 +794,25 @@ int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* c
     if (!w || !u || !v || !t || !s || !rows || !cols || !sigma || !isig || !u_hist || !v_hist) return GCSSL_ENULL;
     if (nl < 1 || nl > 4 || slot < 0 || slot >= nslots) return GCSSL_EBADSHAPE;
     SnBatch b{};
-    int maxc = 0, maxr = 0;
+    int maxcb = 0, maxr = 0, maxblk = 0;
     for (int i = 0; i < nl; ++i) {
         if (!w[i] || !u[i] || !v[i] || !t[i] || !s[i]) return GCSSL_ENULL;
         if (rows[i] <= 0 || cols[i] <= 0 || rows[i] > hist_stride_u || cols[i] > hist_stride_v) return GCSSL_EBADSHAPE;
         b.l[i] = SnLayer{w[i], u[i], v[i], t[i], s[i], rows[i], cols[i]};
-        if (cols[i] > maxc) maxc = cols[i];
+        const int cb = (cols[i] & 3) ? (cols[i] + 63) / 64 : (cols[i] + 255) / 256;
+        if (cb > maxcb) maxcb = cb;
         if (rows[i] > maxr) maxr = rows[i];
+        const int rpb = 4 / sn_waves_per_row(cols[i]), nb = (rows[i] + rpb - 1) / rpb;
+        if (nb > maxblk) maxblk = nb;
     }
     b.nl = nl; b.sigma = sigma; b.isig = isig; b.u_hist = u_hist; b.v_hist = v_hist;
     b.hist_stride_u = hist_stride_u; b.hist_stride_v = hist_stride_v; b.slot = slot; b.nslots = nslots;
     hipStream_t st = (hipStream_t)stream;
     if (iterate) {
-        // t is zero on entry (caller allocates it zeroed) and sn_wv_kernel leaves it zero again
-        hipLaunchKernelGGL(sn_wtu_kernel, dim3((maxc + 63) / 64, nl, (maxr + 63) / 64), dim3(256), 0, st, b);
-        hipLaunchKernelGGL(sn_wv_kernel, dim3((maxr + 3) / 4, nl), dim3(256), 0, st, b);
+        // t is zero on entry (caller allocates it zeroed) and sn_finish_kernel leaves it zero again
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3(maxcb, nl, (maxr + SN_SLAB - 1) / SN_SLAB), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(sn_wv_kernel, dim3(maxblk, nl), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(sn_finish_kernel, dim3(nl), dim3(256), 0, st, b);
     } else {
         hipLaunchKernelGGL(sn_sigma_kernel, dim3(nl), dim3(256), 0, st, b);
     }

@@ -249,9 +249,8 @@ def test_act_bwd_and_dot(ops, dt, tol):
 
 
 @pytest.mark.parametrize("dt,tol", DTS)
-@pytest.mark.parametrize("N,H", [(6, 2), (3, 4), (3, 8)])
-def test_critic_head(ops, dt, tol, N, H):
-    C = 512
+@pytest.mark.parametrize("N,H,C", [(6, 2, 512), (3, 4, 512), (3, 8, 512), (3, 4, 20)])    # C = 20: the scalar forward form
+def test_critic_head(ops, dt, tol, N, H, C):
     x = q(rnd(N, C, H, H, seed=30), dt)
     w = rnd(1, C, 4, 4, seed=31, scale=0.05)
     wp = torch.empty(16, C, device="cuda")
@@ -277,9 +276,12 @@ def test_critic_head(ops, dt, tol, N, H):
     assert rel_err(dw.cpu().view(1, C, 4, 4), conv2d_weight(x, w.shape, dconst.contiguous(), 1, 1)) < max(tol, 1e-4)
 
 
-def test_spectral_norm_power_iteration(ops):
+@pytest.mark.parametrize("shapes", [
+    [(64, 6 * 16), (128, 64 * 16), (256, 128 * 16), (512, 256 * 16)],     # the critic's layers
+    [(6, 18), (33, 130), (70, 1027), (67, 4100)],   # ragged rows; columns that are not a multiple of 4 (scalar forms) / of 1024
+])
+def test_spectral_norm_power_iteration(ops, shapes):
     from oracle import manual_step as M
-    shapes = [(64, 6 * 16), (128, 64 * 16), (256, 128 * 16), (512, 256 * 16)]
     ws = [rnd(r, c, seed=40 + i, scale=0.05) for i, (r, c) in enumerate(shapes)]
     us = [F.normalize(rnd(r, seed=50 + i), dim=0) for i, (r, _) in enumerate(shapes)]
     vs = [F.normalize(rnd(c, seed=60 + i), dim=0) for i, (_, c) in enumerate(shapes)]
