@@ -1641,6 +1641,10 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
 }
 template <typename T>
 int dispatch_dgrad(ConvParams p, hipStream_t st) {
+    // (Tried for the 8-channel first layer, D.c1.gp_dgrad: MFMA operands loaded straight from memory, one 16-byte load per
+    //  lane and fragment, a wave per output parity class, no LDS.  Correct, and no faster than the generic tile -- 26.0 vs
+    //  27.4 us: a fragment load touches 32 different 128-byte lines per instruction and the L1 serves those at a few clocks
+    //  per line, so the 134 MB of fragment reads cost what the LDS ring costs.  Removed)
     if (Is16<T>::v && use_dma() && p.Cin >= 64) {
         const char* f = forced_tile();
         if (f && !strcmp(f, "256x128") && p.Cin >= 128) return launch_big<typename Op16<T>::type, 256, 128, 1>(p, st);

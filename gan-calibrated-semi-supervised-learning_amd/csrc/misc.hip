@@ -409,20 +409,21 @@ __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __re
 // clip_grad_norm_(max_norm) + Adam over flat fp32 buffers
 // (torch.nn.utils.clip_grad_norm_ + torch.optim.Adam at cgan/cgan_train_enhanced.py:256-257,331-332,368-369)
 // =========================================================================================
-// state (8 doubles): [0] step count, [1] sum of squares accumulator (zero between calls), [2] last total norm,
-// [3] clip coefficient, [4] lr / (1 - b1^t), [5] sqrt(1 - b2^t), [6] blocks-finished counter (as u64),
-// [7] learning-rate override (> 0: used instead of the launch argument -- an LR scheduler writes it between iterations
-//     without re-capturing the graph).
-// Few blocks (same-address fp64 atomics serialise at ~12 ns each); the last block to finish advances the step and
-// derives the scalars of this update, following torch's single-tensor Adam (python doubles, cast to float where
-// they meet the tensor).
+// state (GCSSL_ADAM_STATE = 264 doubles): [0] step count, [1] unused, [2] last total norm, [3] clip coefficient,
+// [4] lr / (1 - b1^t), [5] sqrt(1 - b2^t), [6] unused, [7] learning-rate override (> 0: used instead of the launch argument
+// -- an LR scheduler writes it between iterations without re-capturing the graph), [8..263] the per-block partial sums of
+// squares of the current call.
+// Two launches, no device-scope fences: sumsq_kernel's blocks each STORE their partial sum (block 0 also advances the step
+// count); every adam_kernel block then adds the <= 256 partials in a fixed order and derives the scalars of this update,
+// following torch's single-tensor Adam (python doubles, cast to float where they meet the tensor).  (The first form
+// closed the reduction in sumsq_kernel's last block to finish: a fence + two atomics per block, and on this part a
+// device-scope release writes the XCD's L2 back -- 13 us for an 11-MB read; see sn_wv_kernel.)
 // gscale: the gradient the optimiser sees is g * gscale (1/world_size of a data-parallel SUM all-reduce: the averaging
 // multiply rides in the two passes that read g anyway); the norm, the clip coefficient and what is written back are those
 // of the scaled gradient.
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* state, double lr, double b1,
-                                                    double b2, double max_norm, double gscale) {
+constexpr int ADAM_PARTS = 256, ADAM_PART0 = 8;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* state) {
     __shared__ double red[4];
-    __shared__ int last;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // fp32 per-thread partials (<= ~100 elements each), fp64 from there
     const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -441,24 +442,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(state + 1, red[0] + red[1] + red[2] + red[3]);
-        __threadfence();
-        unsigned long long* cnt = reinterpret_cast<unsigned long long*>(state + 6);
-        last = atomicAdd(cnt, 1ull) == (unsigned long long)(gridDim.x - 1);
-        if (last) {
-            __threadfence();
-            const double ss = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * gscale * gscale;
-            const double t = state[0] + 1.0;
-            const float total = (float)sqrt(ss);
-            state[0] = t;
-            state[2] = sqrt(ss);
-            state[3] = (double)fminf(1.0f, (float)max_norm / (total + 1e-6f));
-            const double lr_eff = state[7] > 0.0 ? state[7] : lr;       // per-epoch scheduler override (graph-replay safe)
-            state[4] = (double)(float)(lr_eff / (1.0 - pow(b1, t)));
-            state[5] = (double)(float)sqrt(1.0 - pow(b2, t));
-            state[1] = 0.0;
-            *cnt = 0ull;
-        }
+        state[ADAM_PART0 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (blockIdx.x == 0) state[0] += 1.0;           // single writer; adam_kernel (next launch) reads the new count
     }
 }
 
@@ -476,26 +461,48 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, size_t n, const double* __restrict__ state, double b1,
-                                                   double b2, double eps, int after, float gscale) {
-    const float coef = (float)state[3] * gscale, step = (float)state[4], bc2s = (float)state[5];
+                                                   float* __restrict__ v, size_t n, double* __restrict__ state, int nparts,
+                                                   double lr, double b1, double b2, double eps, double max_norm, int after,
+                                                   double gscale) {
+    __shared__ double red[4];
+    __shared__ float sc[3];
+    {   // the scalars of this update, from the partial sums (every block: same order, same result)
+        double part = (int)threadIdx.x < nparts ? state[ADAM_PART0 + threadIdx.x] : 0.0;
+        part = wave_sum_d(part);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double ss = ((red[0] + red[1]) + (red[2] + red[3])) * gscale * gscale;
+            const double t = state[0];
+            const float total = (float)sqrt(ss);
+            const float coef = fminf(1.0f, (float)max_norm / (total + 1e-6f));
+            const double lr_eff = state[7] > 0.0 ? state[7] : lr;       // per-epoch scheduler override (graph-replay safe)
+            const float step = (float)(lr_eff / (1.0 - pow(b1, t))), bc2s = (float)sqrt(1.0 - pow(b2, t));
+            sc[0] = coef * (float)gscale; sc[1] = step; sc[2] = bc2s;
+            if (blockIdx.x == 0) { state[2] = sqrt(ss); state[3] = (double)coef; state[4] = (double)step; state[5] = (double)bc2s; }
+        }
+        __syncthreads();
+    }
+    const float coef = sc[0], step = sc[1], bc2s = sc[2];
     const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2), epsf = (float)eps;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n4 = n / 4;
-    if (i < n4) {
-        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<float4*>(g)[i];
-        float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
-        adam_one(P.x, G.x, M.x, V.x, coef, step, bc2s, w1, b2f, w2, epsf, after);
-        adam_one(P.y, G.y, M.y, V.y, coef, step, bc2s, w1, b2f, w2, epsf, after);
-        adam_one(P.z, G.z, M.z, V.z, coef, step, bc2s, w1, b2f, w2, epsf, after);
-        adam_one(P.w, G.w, M.w, V.w, coef, step, bc2s, w1, b2f, w2, epsf, after);
-        reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
-        if (after) reinterpret_cast<float4*>(g)[i] = G;
-    } else if (i - n4 < (n & 3)) {
-        const size_t j = n4 * 4 + (i - n4);
-        float P = p[j], G = g[j], M = m[j], V = v[j];
-        adam_one(P, G, M, V, coef, step, bc2s, w1, b2f, w2, epsf, after);
-        p[j] = P; m[j] = M; v[j] = V;
-        if (after) g[j] = G;
+    const size_t n4 = n / 4, items = n4 + (n & 3), stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += stride) {
+        if (i < n4) {
+            float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<float4*>(g)[i];
+            float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+            adam_one(P.x, G.x, M.x, V.x, coef, step, bc2s, w1, b2f, w2, epsf, after);
+            adam_one(P.y, G.y, M.y, V.y, coef, step, bc2s, w1, b2f, w2, epsf, after);
+            adam_one(P.z, G.z, M.z, V.z, coef, step, bc2s, w1, b2f, w2, epsf, after);
+            adam_one(P.w, G.w, M.w, V.w, coef, step, bc2s, w1, b2f, w2, epsf, after);
+            reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
+            if (after) reinterpret_cast<float4*>(g)[i] = G;
+        } else {
+            const size_t j = n4 * 4 + (i - n4);
+            float P = p[j], G = g[j], M = m[j], V = v[j];
+            adam_one(P, G, M, V, coef, step, bc2s, w1, b2f, w2, epsf, after);
+            p[j] = P; m[j] = M; v[j] = V;
+            if (after) g[j] = G;
+        }
     }
 }
 
@@ -846,11 +853,12 @@ int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* stat
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return GCSSL_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     const size_t n4 = (size_t)n / 4;
-    int blocks = (int)((n4 + 256 * 8 - 1) / (256 * 8)); if (blocks > 256) blocks = 256; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, (size_t)n, state, lr, b1, b2, max_norm, grad_scale);
+    int blocks = (int)((n4 + 256 * 8 - 1) / (256 * 8)); if (blocks > ADAM_PARTS) blocks = ADAM_PARTS; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, (size_t)n, state);
     const size_t items = n4 + ((size_t)n & 3);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, g, m, v, (size_t)n, state, b1, b2,
-                       eps, write_clipped, (float)grad_scale);
+    size_t ablocks = (items + 255) / 256; if (ablocks > 2048) ablocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ablocks), dim3(256), 0, st, p, g, m, v, (size_t)n, state, blocks, lr, b1, b2,
+                       eps, max_norm, write_clipped, grad_scale);
     return gcssl_launch_status();
 }
 

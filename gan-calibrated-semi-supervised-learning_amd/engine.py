@@ -72,7 +72,7 @@ class FlatParams:
         self.m = torch.zeros(n, device=device)
         self.v = torch.zeros(n, device=device)
         self.grads_zero = True                                            # g is all-zero (fresh, or zeroed by the last update)
-        self.state = torch.zeros(8, device=device, dtype=torch.float64)   # step, sumsq, last grad norm, ... (gcssl.h)
+        self.state = torch.zeros(ops.ADAM_STATE, device=device, dtype=torch.float64)   # step, sumsq, last grad norm, ... (gcssl.h)
         self.views, self.gviews, off = {}, {}, 0
         for k in keys:
             t = sd[k]

@@ -281,9 +281,13 @@ def scale_rows(x, coef, y, B):
     call("gcssl_scale_rows", code(y), x, coef, y, x.numel() // B, B)
 
 
+ADAM_STATE = 264        # doubles in a clip_adam state block (GCSSL_ADAM_STATE, include/gcssl.h)
+
+
 def clip_adam(p, g, m, v, state, lr, b1, b2, eps=1e-8, max_norm=1.0, write_clipped=False, grad_scale=1.0):
-    """write_clipped: False/0 leave g, True/1 store the clipped gradient, 2 zero g (fused zero_grad).  state: 8 doubles.
+    """write_clipped: False/0 leave g, True/1 store the clipped gradient, 2 zero g (fused zero_grad).  state: ADAM_STATE doubles.
     grad_scale: the optimiser sees g * grad_scale (1/world after a data-parallel SUM all-reduce)."""
+    assert state.numel() >= ADAM_STATE and state.dtype == torch.float64
     call("gcssl_clip_adam", p, g, m, v, p.numel(), state, float(lr), float(b1), float(b2), float(eps),
          float(max_norm), int(write_clipped), float(grad_scale))
 

@@ -175,13 +175,15 @@ int gcssl_gp_norm(const float* g, long per_sample, int B, float lambda_gp, float
 int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long per_sample, int B, void* stream);
 
 /* ---- clip_grad_norm_(1.0) + Adam (cgan/cgan_train_enhanced.py:256-257,331-332,368-369) over flat fp32 buffers ---
- * state: 8 doubles, zeroed once by the caller: {step, sumsq accumulator, last total norm, clip coef, lr/(1-b1^t),
- * sqrt(1-b2^t), completion counter, lr override}; the step is advanced on the device (graph replay safe); a
- * positive state[7] replaces `lr` (what ReduceLROnPlateau at cgan/cgan_train_enhanced.py:260-261,427-428 changes).
+ * state: GCSSL_ADAM_STATE doubles, zeroed once by the caller: {step, -, last total norm, clip coef, lr/(1-b1^t),
+ * sqrt(1-b2^t), -, lr override, then the call's <= 256 partial sums of squares}; the step is advanced on the device
+ * (graph replay safe); a positive state[7] replaces `lr` (what ReduceLROnPlateau at
+ * cgan/cgan_train_enhanced.py:260-261,427-428 changes).
  * write_clipped: 0 leave g, 1 store g*clip_coef (what clip_grad_norm_ leaves in .grad), 2 zero g (fused zero_grad).
  * grad_scale (> 0): the optimiser sees g * grad_scale -- 1/world_size after a data-parallel SUM all-reduce, 1 otherwise;
  * norm, clip coefficient and the written-back gradient are those of the scaled gradient.
  * p, g, m, v must be 16-byte aligned. */
+#define GCSSL_ADAM_STATE 264
 int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* state, double lr, double b1, double b2,
                     double eps, double max_norm, int write_clipped, double grad_scale, void* stream);
 

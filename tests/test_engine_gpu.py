@@ -392,25 +392,31 @@ def test_graph_replay_matches_eager_at_bench_config(synth, dtype):
     the captured graph must contain the gradient zero fills although a fresh engine's buckets are zero at capture time --
     replays used to accumulate onto the previous iteration's clipped gradients (a 2x error at the second replay)."""
     engine, eng_e, call = _bench_like(synth, dtype, lr=0.0)
+    _, eng_e2, call_e2 = _bench_like(synth, dtype, lr=0.0)      # a second eager run: the noise floor of the comparison
     _, eng_g, call_g = _bench_like(synth, dtype, lr=0.0)
     gi = engine.GraphedIteration(eng_g, *call_g)                # captured on the fresh engine, nothing executed yet
     assert float(eng_g.G.state[0]) == 0.0 and float(eng_g.D.state[0]) == 0.0
     for it in range(3):
         eng_e.run_iteration(*call)
+        eng_e2.run_iteration(*call_e2)
         gi.replay()
         torch.cuda.synchronize()
         assert float(eng_g.D.state[0]) == float(eng_e.D.state[0]) == 2 * (it + 1)      # optimiser step counts
         assert float(eng_g.G.state[0]) == float(eng_e.G.state[0]) == it + 1
-        for fg, fe, name in ((eng_g.D, eng_e.D, "D"), (eng_g.G, eng_e.G, "G")):
+        for fg, fe, fe2, name in ((eng_g.D, eng_e.D, eng_e2.D, "D"), (eng_g.G, eng_e.G, eng_e2.G, "G")):
             a, b = fg.g, fe.g
             assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
             err = float((a - b).norm() / b.norm())
+            floor = float((fe2.g - b).norm() / b.norm())         # eager vs eager: float-atomic order through 16-bit roundings
             per_key = sorted(((float((fg.gviews[k] - fe.gviews[k]).norm() / (fe.gviews[k].norm() + 1e-30)), k,
                               float(fe.gviews[k].norm()), float(fg.gviews[k].norm())) for k in fe.keys), reverse=True)[:3]
-            assert err < 2e-2, (it, name, err, per_key)           # (stale accumulation: ~1.0)
-        for x, y in ((float(eng_e.gp_sum), float(eng_g.gp_sum)), (float(eng_e.eiou_acc), float(eng_g.eiou_acc)),
-                     (float(eng_e.D.state[2]), float(eng_g.D.state[2])), (float(eng_e.G.state[2]), float(eng_g.G.state[2]))):
-            assert np.isfinite(x) and abs(x - y) <= 2e-3 * max(abs(x), 1e-6), (it, x, y)
+            # measured: bf16 1.5e-2..2.7e-2 on the critic (its first layer's gradient, behind four InstanceNorms and the
+            # double backward), fp16 ~3e-3, for graph-vs-eager and eager-vs-eager alike; stale accumulation would be ~1.0
+            assert err < max(2e-2, 3.0 * floor) and err < 0.1, (it, name, err, floor, per_key)
+        scal = lambda e: (float(e.gp_sum), float(e.eiou_acc), float(e.D.state[2]), float(e.G.state[2]))
+        for x, y, x2 in zip(scal(eng_e), scal(eng_g), scal(eng_e2)):      # penalty, box loss, the two total gradient norms
+            assert np.isfinite(x) and abs(x - y) <= max(2e-3 * max(abs(x), 1e-6), 3.0 * abs(x - x2)) and \
+                abs(x - y) <= 2e-2 * max(abs(x), 1e-6), (it, x, y, x2)
     for l in range(4):                                            # spectral-norm state advanced the same number of times
         assert rel_err(eng_g.u[l].cpu(), eng_e.u[l].cpu()) < 1e-5
 
@@ -422,21 +428,26 @@ def test_graph_replay_trains_like_eager(synth, dtype):
     are finite and no element is further apart than Adam's steps allow."""
     lr = 2e-4
     engine, eng_e, call = _bench_like(synth, dtype, keep_clipped_grads=False)
+    _, eng_e2, call_e2 = _bench_like(synth, dtype, keep_clipped_grads=False)    # eager vs eager: the noise floor
     _, eng_g, call_g = _bench_like(synth, dtype, keep_clipped_grads=False)
     gi = engine.GraphedIteration(eng_g, *call_g)
     for it in range(3):
         eng_e.run_iteration(*call)
+        eng_e2.run_iteration(*call_e2)
         gi.replay()
         torch.cuda.synchronize()
-        for a, b, steps, name in ((eng_g.D.p, eng_e.D.p, 2 * (it + 1), "D"), (eng_g.G.p, eng_e.G.p, it + 1, "G")):
+        for a, b, b2, steps, name in ((eng_g.D.p, eng_e.D.p, eng_e2.D.p, 2 * (it + 1), "D"),
+                                      (eng_g.G.p, eng_e.G.p, eng_e2.G.p, it + 1, "G")):
             assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
             diff = (a - b).abs()
             assert float(diff.max()) <= 2.2 * lr * steps, (it, name, float(diff.max()))
             if it == 0:
-                # measured: D 0.72-0.95 in the 16-bit modes (0.9999 in fp32), G 0.997: the critic's second update of the iteration
-                # already sees the first one's sign flips.  (Exact agreement is what the lr = 0 test above checks.)
+                # measured: D 0.45-0.95 in the 16-bit modes (0.9999 in fp32), G 0.997: the critic's second update of the iteration
+                # already sees the first one's sign flips -- two EAGER runs agree no better, which is the bound.  (Agreement
+                # of the gradients themselves is what the lr = 0 test above checks.)
                 close = float((diff <= 2e-6).float().mean())
-                assert close >= 0.5, (name, close)
+                close_ee = float(((b2 - b).abs() <= 2e-6).float().mean())
+                assert close >= min(0.5, 0.75 * close_ee), (name, close, close_ee)
     me, mg = eng_e.means.tolist(), eng_g.means.tolist()
     assert all(np.isfinite(v) for v in me + mg) and np.isfinite(float(eng_g.gp_sum))
 

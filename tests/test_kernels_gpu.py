@@ -346,7 +346,7 @@ def test_clip_adam_matches_torch(ops):
     ref = p0.clone().requires_grad_(True)
     opt = torch.optim.Adam([ref], lr=2e-4, betas=(0.5, 0.999))
     p = p0.cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
-    state = torch.zeros(8, device="cuda", dtype=torch.float64)
+    state = torch.zeros(ops.ADAM_STATE, device="cuda", dtype=torch.float64)
     for t in range(3):
         g = rnd(n, seed=81 + t, scale=0.05)
         ref.grad = g.clone()

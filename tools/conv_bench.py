@@ -5,7 +5,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 ops = importlib.import_module("gan-calibrated-semi-supervised-learning_amd.ops")
 kind, N, Hi, Cin, Cout = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-dt = torch.bfloat16 if (len(sys.argv) < 7 or sys.argv[6] == "bf16") else torch.float32
+dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[sys.argv[6] if len(sys.argv) > 6 else "bf16"]
 reps = int(sys.argv[7]) if len(sys.argv) > 7 else 20
 x = (torch.rand(N, Hi, Hi, Cin, device="cuda") * 2 - 1).to(dt)
 dy = (torch.rand(N, Hi // 2, Hi // 2, Cout, device="cuda") * 2 - 1).to(dt)
