@@ -249,8 +249,9 @@ def main():
     pmc = ROOT / "profiles" / "round2_pmc_dominant.json"
     if pmc.exists():
         rec = json.loads(pmc.read_text())
-        if rec.get("label") == dom and rec.get("config") == [B, S, c, args.dtype, args.generator]:
-            traffic, traffic_src = rec["hbm_bytes_per_launch"], f"profiles/{pmc.name} (committed rocprofv3 --pmc passes, not this run)"
+        lab = rec.get("labels", {}).get(dom)
+        if lab and lab.get("hbm_bytes_per_launch") and rec.get("config") == [B, S, c, args.dtype, args.generator]:
+            traffic, traffic_src = lab["hbm_bytes_per_launch"], f"profiles/{pmc.name} (committed rocprofv3 --pmc passes of this label's launch shape, not this run)"
     roofline = dict(bound="hbm" if hbm_bound else "mfma", kernel=dom,
                     achieved=round(ach_gbs if hbm_bound else ach, 2), peak=HBM_PEAK_GBS if hbm_bound else peak,
                     unit="GB/s" if hbm_bound else "TFLOP/s", frac=round(ach_gbs / HBM_PEAK_GBS if hbm_bound else ach / peak, 4),

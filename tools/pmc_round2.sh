@@ -1,0 +1,39 @@
+#!/bin/bash
+# Round-2 PMC passes for the conv launches that lead bench.py's per-label table at the headline configuration
+# (batch 256, 32x32, n_critic 2, fp16).  Per launch shape: separate rocprofv3 runs for FETCH_SIZE, WRITE_SIZE and two SQ sets,
+# --kernel-trace only (pool rule), the program directly after `--`, each bounded by its own timeout.  Writes
+# gpurun_out/pmc_r2/<tag>/pN/ and gpurun_out/pmc_r2/round2_pmc_dominant.json (copied to profiles/ by hand).
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/pmc_r2
+mkdir -p $OUT
+DT=${1:-fp16}
+# tag | kernel-name filter | program + args
+CASES=(
+ "D.c2.fwd[n=768]|conv_dma|tools/conv_bench.py fwd 768 16 64 128 $DT 5"
+ "D.c3.fwd[n=768]|conv_dma|tools/conv_bench.py fwd 768 8 128 256 $DT 5"
+ "D.c4.fwd[n=768]|conv_dma|tools/conv_bench.py fwd 768 4 256 512 $DT 5"
+ "D.c2.wgrad|conv_wgrad|tools/conv_bench.py wgrad 1024 16 64 128 $DT 5"
+ "D.c3.wgrad|conv_wgrad|tools/conv_bench.py wgrad 1024 8 128 256 $DT 5"
+ "D.c4.wgrad|conv_wgrad|tools/conv_bench.py wgrad 1024 4 256 512 $DT 5"
+ "D.c2.dgrad|conv_dma|tools/conv_bench.py dgrad 768 16 64 128 $DT 5"
+ "D.c3.dgrad|conv_dma|tools/conv_bench.py dgrad 768 8 128 256 $DT 5"
+ "D.c4.dgrad|conv_dma|tools/conv_bench.py dgrad 768 4 256 512 $DT 5"
+ "D.c1.fwd[n=768]|conv_dma|tools/conv_bench.py fwd 768 32 8 64 $DT 5"
+ "D.c1.gp_dgrad|conv_|tools/conv_bench.py dgrad 256 32 8 64 $DT 5"
+ "G.up4.fwd[n=768]|convt_in_relu|tools/convt_bench.py 768 16 128"
+)
+SETS=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE")
+for c in "${CASES[@]}"; do
+  IFS='|' read -r tag flt prog <<< "$c"
+  d=$OUT/$(echo "$tag" | tr '[]=' '___')
+  mkdir -p $d
+  i=0
+  for set in "${SETS[@]}"; do
+    i=$((i+1))
+    (cd $R && timeout -k 10 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d/p$i -o r -- python3 $prog > $d/p$i.log 2>&1) || { echo "$tag pass $i failed"; tail -3 $d/p$i.log; exit 1; }
+  done
+  echo "$tag done" >> $OUT/progress.txt
+done
+cd $R && python3 tools/pmc_round2_summary.py $OUT $DT
