@@ -47,10 +47,10 @@ def _algorithmic_bytes(label: str, args, es: int):
     algo = stored = 0
     for i, t in enumerate(ts):
         n = t.numel()
-        if label.endswith("wgrad") and t.dim() == 4 and t.dtype == torch.float32 and i == 2:
-            n //= t.shape[0]                                          # slab [nsplit][Cout][16][Cin]
-        algo += n * es
         stored += n * t.element_size()
+        if label.endswith("wgrad") and t.dim() == 4 and t.dtype == torch.float32 and i == 2:
+            n //= t.shape[0]                                          # slab [nsplit][Cout][16][Cin]: ONE gradient tensor
+        algo += n * es
     return algo, stored
 
 
