@@ -1177,6 +1177,18 @@ __device__ __forceinline__ void wgrad_reduce_body(float (*tile)[65], int co, int
     // slab group zi of zn owns a group of splits (accumulate == 2: dw was zeroed by the caller, groups add atomically)
     const int per = (nsplit + zn - 1) / zn;
     const int k0 = zi * per, k1 = min(nsplit, k0 + per);
+    // the rank-1 correction's operands (this thread's OUTPUT element: ci, 4 consecutive taps) are fetched first, so that their
+    // latency lies under the slab loads instead of behind the barrier
+    const int ocil = threadIdx.x >> 2, otp = (threadIdx.x & 3) * 4, oci = ci0 + ocil;
+    float uk[4];
+    float4 vk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool on = k < nrank && zi == 0;
+        uk[k] = on ? coef[k] * (cscale ? cscale[k] : 1.f) * u[(size_t)k * ustride + co] : 0.f;
+        vk[k] = (on && ocil < cw && oci < Cin_real) ? *reinterpret_cast<const float4*>(v + (size_t)k * vstride + oci * 16 + otp)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     {   // 16-byte loads: thread -> (tap, 4 consecutive ci); 256 threads cover the 16 x 64 tile once
         const int tap = threadIdx.x >> 4, cil = (threadIdx.x & 15) * 4;
         if (cil < cw) {
@@ -1191,21 +1203,16 @@ __device__ __forceinline__ void wgrad_reduce_body(float (*tile)[65], int co, int
         }
     }
     __syncthreads();
-    float uk[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        uk[k] = (k < nrank && zi == 0) ? coef[k] * (cscale ? cscale[k] : 1.f) * u[(size_t)k * ustride + co] : 0.f;
     // output: thread -> (ci, 4 consecutive taps): the 64 ci x 16 taps of one co are 4 KB contiguous in dw
-    const int cil = threadIdx.x >> 2, tp = (threadIdx.x & 3) * 4;
-    const int ci = ci0 + cil;
+    const int cil = ocil, tp = otp;
+    const int ci = oci;
     if (cil < cw && ci < Cin_real) {
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float sv = tile[tp + j][cil];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < nrank) sv -= uk[k] * v[(size_t)k * vstride + ci * 16 + tp + j];
+            for (int k = 0; k < 4; ++k) sv -= uk[k] * (j == 0 ? vk[k].x : j == 1 ? vk[k].y : j == 2 ? vk[k].z : vk[k].w);
             o[j] = sv;
         }
         float* op = dw + ((size_t)co * Cin_real + ci) * 16 + tp;
@@ -1603,8 +1610,125 @@ int launch_big(const ConvParams& p, hipStream_t st) {
     return gcssl_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// forward of the FIRST layers (Cin padded to 8, Cout = 64: D.c1, G.down1 and the reverse GP chain's c1): K = 16 taps x 8
+// channels = 128, two K steps of the generic 64-deep ring -- a launch that is all prologue and epilogue (28-36 us for 38 MB
+// at batch 768).  These layers are HBM-bound, so the kernel is built around its memory accesses:
+//   * a workgroup owns 128 consecutive output pixels of one sample (R = 128 / Wo output rows) and loads the 2R + 2 input
+//     rows they touch ONCE, with coalesced 16-byte loads (a pixel's 8 channels are 16 bytes), into an LDS image with a zero
+//     pixel at both row ends and zero rows outside the map: no bounds logic after this point;
+//   * an MFMA A fragment (lane = output pixel, one tap's 8 channels) is one ds_read_b128 of that image -- the im2col
+//     happens in the LDS address;
+//   * the 16 B fragments of a wave (64 output channels x K = 128) come straight from the 16-KB packed weight and stay in
+//     registers;
+//   * the 128 x 64 result goes through an LDS transpose so that the stores are full 128-byte (16-bit) / 256-byte (fp32)
+//     runs per pixel.
+// Geometry: Wo in {16, 32, 64} (32x32 ... 128x128 inputs), one sample's rows per tile; other shapes take the generic path.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_fwd_c8_kernel(ConvParams p, int ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef typename Frag16<T>::type FragT;
+    constexpr int MT = 128, WROW = 17;                                   // weight rows of 16 chunks + 1 pad chunk (272 B)
+    extern __shared__ __attribute__((aligned(16))) unsigned char c8_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Wo = p.Wi >> 1, Ho = p.Hi >> 1, R = MT >> p.lgWo, rows = 2 * R + 2, rowpx = p.Wi + 2;
+    const int tiles_per_n = Ho / R;
+    uint4* img = reinterpret_cast<uint4*>(c8_lds);                       // [rows][Wi + 2] pixels of 16 bytes
+    unsigned char* outt = c8_lds + (size_t)rows * rowpx * 16;            // [128][64] result tile; first: the weight image
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+    // The packed weight Wf[64 co][16 taps][8 ci] (16 KB) is fetched ONCE per workgroup with coalesced 16-byte loads and
+    // passed through LDS (rows padded to 17 chunks: the fragment reads of 32 consecutive co are conflict-free).  Loading
+    // the fragments straight from memory touches 32 different 128-byte lines per instruction, and L1 serves lines, not
+    // bytes: that version ran at the generic kernel's 30 us.
+    {
+        uint4* wimg = reinterpret_cast<uint4*>(outt);
+        for (int c = tid; c < 64 * 16; c += 256)
+            wimg[(c >> 4) * WROW + (c & 15)] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)c * 16u, 0, 0));
+        __syncthreads();
+    }
+    FragT bf[2][8];                                                      // lane -> co = 32 j + (lane & 31), tap = 2 ks + (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            bf[j][ks] = __builtin_bit_cast(FragT, reinterpret_cast<const uint4*>(outt)[(32 * j + (lane & 31)) * WROW + 2 * ks + (lane >> 5)]);
+    const int pl = 32 * wave + (lane & 31), oyl = pl >> p.lgWo, ox = pl & (Wo - 1), h = lane >> 5;
+    const bool f32out = p.out_f32;
+    const int cpp = f32out ? 16 : 8, es = f32out ? 4 : 2;                // 16-byte chunks per output pixel (64 channels)
+    unsigned char* yb = static_cast<unsigned char*>(p.y);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_n, oy0 = (tile - n * tiles_per_n) * R;
+        // input image: chunk c -> (row, px); rows outside the map read OOB = 0; the two pad pixels of a row are zeroed.
+        // (The barrier that follows also closes the previous tile's reads of `outt` / the weight image.)
+        const int iy0 = 2 * oy0 - 1, nchunk = rows * p.Wi;
+        for (int c = tid; c < nchunk; c += 256) {
+            const int row = c >> (p.lgWo + 1), px = c & (p.Wi - 1), iy = iy0 + row;
+            const bool ok = (unsigned)iy < (unsigned)p.Hi;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((((n * p.Hi + iy) * p.Wi + px) * p.ldx) * 2) : OOB, 0, 0);
+            img[row * rowpx + px + 1] = __builtin_bit_cast(uint4, v);
+        }
+        if (tid < 2 * rows) img[(tid >> 1) * rowpx + ((tid & 1) ? p.Wi + 1 : 0)] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        // A fragments: lane -> output pixel pl of the tile, tap = 2 ks + h: one ds_read_b128 of the image each
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        FragT af[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int tap = 2 * ks + h, ky = tap >> 2, kx = tap & 3;
+            af[ks] = __builtin_bit_cast(FragT, img[(2 * oyl + ky) * rowpx + 2 * ox + kx]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = mfma(af[ks], bf[j][ks], acc[j]);
+        // epilogue: scale, bias, activation; transpose through LDS; 16-byte stores
+        const float gs = p.gscale ? p.gscale[n / p.group_n] : 1.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = 32 * j + (lane & 31);
+            const float b = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int prow = 32 * wave + crow(r, lane);
+                float v = acc[j][r] * gs + b;
+                if (p.act == 1) v = lrelu_f(v);
+                if (f32out) reinterpret_cast<float*>(outt)[prow * 64 + co] = v;
+                else reinterpret_cast<unsigned short*>(outt)[prow * 64 + co] = (unsigned short)Bits16<T>::enc(v);
+            }
+        }
+        __syncthreads();
+        const size_t m0 = (size_t)(n * Ho + oy0) * Wo;                   // first output pixel of the tile
+        for (int c = tid; c < MT * cpp; c += 256) {
+            const int px = f32out ? c >> 4 : c >> 3, ch = c & (cpp - 1);
+            *reinterpret_cast<uint4*>(yb + ((m0 + px) * p.ldy) * es + ch * 16) = reinterpret_cast<const uint4*>(outt)[c];
+        }
+    }
+#endif
+}
+// (A/B knob: GCSSL_C8_FWD=0 sends these shapes back to the generic tiles)
+bool c8_fwd_on() { static const bool v = [] { const char* e = getenv("GCSSL_C8_FWD"); return !(e && e[0] == '0'); }(); return v; }
+
 template <typename T>
 int dispatch_fwd(ConvParams p, hipStream_t st) {
+    if constexpr (Is16<T>::v) {
+        const int Wo = p.Wi / 2;
+        if (p.Cin == 8 && p.Cout == 64 && (Wo == 16 || Wo == 32 || Wo == 64) && (p.Hi / 2) % (128 / Wo) == 0 && c8_fwd_on() &&
+            p.ldx % 8 == 0 && p.ldy % (p.out_f32 ? 4 : 8) == 0 && aligned16(p.y)) {
+            if (p.plan_out) { *p.plan_out = 1; return GCSSL_OK; }
+            const int R = 128 / Wo, rows = 2 * R + 2;
+            size_t tile_b = (size_t)128 * 64 * (p.out_f32 ? 4 : 2);
+            if (tile_b < (size_t)64 * 17 * 16) tile_b = (size_t)64 * 17 * 16;       // the region first holds the padded weight image
+            const size_t lds = (size_t)rows * (p.Wi + 2) * 16 + tile_b;
+            const int ntiles = p.N * ((p.Hi / 2) / R), per = (ntiles + 1023) / 1024, grid = (ntiles + per - 1) / per;
+            hipLaunchKernelGGL(conv_fwd_c8_kernel<T>, dim3((unsigned)grid), dim3(256), lds, st, p, ntiles);
+            return gcssl_launch_status();
+        }
+    }
     if (Is16<T>::v && use_dma() && p.Cin >= 64) {
         const char* f = forced_tile();
         if (f && !strcmp(f, "256x128") && p.Cout >= 128) return launch_big<typename Op16<T>::type, 256, 128, 0>(p, st);
@@ -1639,12 +1763,123 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
     }
     return launch_fwd<T, 64, 64>(p, st);
 }
+// ------------------------------------------------------------------------------------------
+// data gradient of the first layer (Cin padded to 8, Cout = 64: D.c1 in the gradient-penalty chain; 0.8 GFLOP whose result
+// is 8 channels wide), built like conv_fwd_c8_kernel: a workgroup owns R dy rows of one sample (R * Wo = 32), loads the
+// R + 2 rows its outputs touch once with coalesced 16-byte loads into an LDS image (zero pixel at both row ends, zero rows
+// outside the map; the 8 chunks of a 128-byte pixel XOR-swizzled by the pixel index so that fragment reads of consecutive
+// pixels spread over the banks); wave = output parity class (py, px) = its 2 x 2 taps; an A fragment is one ds_read_b128;
+// the wave's 16 B fragments (Wt rows of the 8 real input channels, columns 8..31 zero) come through LDS once per
+// workgroup and stay in registers; the 2R x Wi x 8 result tile is assembled in LDS in memory order and leaves as full rows.
+//   dx[n][2 jy + py][2 jx + px][ci] = gscale * sum_{a,b,co} dy[n][oy_a][ox_b][co] Wt[ci][ky_a * 4 + kx_b][co]
+//   a = 0: ky = 1 + py, oy = jy;   a = 1: ky = 3 - 3 py, oy = jy - 1 + 2 py   (and the same in x)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_dgrad_c8_kernel(ConvParams p, int ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef typename Frag16<T>::type FragT;
+    constexpr int WROW = 129;                                            // a ci row of Wt: 128 chunks + 1 pad chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char c8_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int py = wave >> 1, px = wave & 1;
+    const int Ho = p.Hi >> 1, Wo = p.Wi >> 1, R = 32 >> p.lgWo, rows = R + 2, rowpx = Wo + 2;
+    const int tiles_per_n = Ho / R;
+    uint4* img = reinterpret_cast<uint4*>(c8_lds);                       // [rows][Wo + 2] pixels x 8 chunks
+    unsigned char* outt = c8_lds + (size_t)rows * rowpx * 128;           // [2R][Wi][8] result tile; first: the weight image
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+    {
+        uint4* wimg = reinterpret_cast<uint4*>(outt);
+        for (int c = tid; c < 8 * 128; c += 256)
+            wimg[(c >> 7) * WROW + (c & 127)] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)c * 16u, 0, 0));
+        __syncthreads();
+    }
+    const int h = lane >> 5, ci = lane & 31;
+    FragT bf[2][2][4];                                                   // [a][b][ks]: channels 16 ks + 8 h .. + 7 of tap (a, b)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int tap = (a ? 3 - 3 * py : 1 + py) * 4 + (b ? 3 - 3 * px : 1 + px);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 w = reinterpret_cast<const uint4*>(outt)[(ci < 8 ? ci : 0) * WROW + tap * 8 + 2 * ks + h];
+                bf[a][b][ks] = __builtin_bit_cast(FragT, ci < 8 ? w : make_uint4(0u, 0u, 0u, 0u));
+            }
+        }
+    const int r = lane & 31, jyl = r >> p.lgWo, jx = r & (Wo - 1);       // the lane's output pixel (of its class) in the tile
+    const bool f32out = p.out_f32;
+    const int es = f32out ? 4 : 2;
+    unsigned char* yb = static_cast<unsigned char*>(p.y);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_n, oy0 = (tile - n * tiles_per_n) * R;
+        // dy image: chunk c -> (row, pixel, 16-byte chunk); image row i = dy row oy0 - 1 + i
+        const int nchunk = rows * Wo * 8;
+        for (int c = tid; c < nchunk; c += 256) {
+            const int ch = c & 7, pxl = (c >> 3) & (Wo - 1), row = c >> (3 + p.lgWo), oy = oy0 - 1 + row;
+            const bool ok = (unsigned)oy < (unsigned)Ho;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((((n * Ho + oy) * Wo + pxl) * p.ldx + ch * 8) * 2) : OOB, 0, 0);
+            const int pix = row * rowpx + pxl + 1;
+            img[pix * 8 + (ch ^ (pix & 7))] = __builtin_bit_cast(uint4, v);
+        }
+        if (tid < 2 * rows * 8) {                                        // the two pad pixels of every row
+            const int pix = (tid >> 4) * rowpx + (((tid >> 3) & 1) ? Wo + 1 : 0);
+            img[pix * 8 + (tid & 7)] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int row = (a ? jyl - 1 + 2 * py : jyl) + 1, col = (b ? jx - 1 + 2 * px : jx) + 1;
+                const int pix = row * rowpx + col;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    acc = mfma(__builtin_bit_cast(FragT, img[pix * 8 + ((2 * ks + h) ^ (pix & 7))]), bf[a][b][ks], acc);
+            }
+        // result tile in memory order: [2R rows][Wi][8 channels]
+        const float gs = p.gscale ? p.gscale[n / p.group_n] : 1.f;
+        if (ci < 8) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int rr = crow(q, lane), oyl = 2 * (rr >> p.lgWo) + py, oxl = 2 * (rr & (Wo - 1)) + px;
+                const float v = acc[q] * gs;
+                const int e = (oyl * p.Wi + oxl) * 8 + ci;
+                if (f32out) reinterpret_cast<float*>(outt)[e] = v;
+                else reinterpret_cast<unsigned short*>(outt)[e] = (unsigned short)Bits16<T>::enc(v);
+            }
+        }
+        __syncthreads();
+        const int cpp = f32out ? 2 : 1;                                  // 16-byte chunks per output pixel (8 channels)
+        const size_t pix0 = (size_t)(n * p.Hi + 2 * oy0) * p.Wi;         // first output pixel of the tile (2R full rows)
+        for (int c = tid; c < 2 * R * p.Wi * cpp; c += 256) {
+            const int opx = f32out ? c >> 1 : c, chn = f32out ? c & 1 : 0;
+            *reinterpret_cast<uint4*>(yb + ((pix0 + opx) * p.ldy) * es + chn * 16) = reinterpret_cast<const uint4*>(outt)[c];
+        }
+    }
+#endif
+}
+// (A/B knob: GCSSL_C8_DGRAD=0 sends the shape back to the generic tiles)
+bool c8_dgrad_on() { static const bool v = [] { const char* e = getenv("GCSSL_C8_DGRAD"); return !(e && e[0] == '0'); }(); return v; }
+
 template <typename T>
 int dispatch_dgrad(ConvParams p, hipStream_t st) {
-    // (Tried for the 8-channel first layer, D.c1.gp_dgrad: MFMA operands loaded straight from memory, one 16-byte load per
-    //  lane and fragment, a wave per output parity class, no LDS.  Correct, and no faster than the generic tile -- 26.0 vs
-    //  27.4 us: a fragment load touches 32 different 128-byte lines per instruction and the L1 serves those at a few clocks
-    //  per line, so the 134 MB of fragment reads cost what the LDS ring costs.  Removed)
+    if constexpr (Is16<T>::v) {
+        const int Wo = p.Wi / 2;
+        if (p.Cin == 8 && p.Cout == 64 && (Wo == 16 || Wo == 32) && (p.Hi / 2) % (32 / Wo) == 0 && c8_dgrad_on() &&
+            p.ldx % 8 == 0 && p.ldy % (p.out_f32 ? 4 : 8) == 0 && aligned16(p.y)) {
+            if (p.plan_out) { *p.plan_out = 1; return GCSSL_OK; }
+            const int R = 32 / Wo, rows = R + 2;
+            size_t tile_b = (size_t)2 * R * p.Wi * 8 * (p.out_f32 ? 4 : 2);
+            if (tile_b < (size_t)8 * 129 * 16) tile_b = (size_t)8 * 129 * 16;       // the region first holds the padded weight image
+            const size_t lds = (size_t)rows * (Wo + 2) * 128 + tile_b;
+            const int ntiles = p.N * ((p.Hi / 2) / R), per = (ntiles + 1023) / 1024, grid = (ntiles + per - 1) / per;
+            hipLaunchKernelGGL(conv_dgrad_c8_kernel<T>, dim3((unsigned)grid), dim3(256), lds, st, p, ntiles);
+            return gcssl_launch_status();
+        }
+    }
     if (Is16<T>::v && use_dma() && p.Cin >= 64) {
         const char* f = forced_tile();
         if (f && !strcmp(f, "256x128") && p.Cin >= 128) return launch_big<typename Op16<T>::type, 256, 128, 1>(p, st);
@@ -1833,6 +2068,7 @@ int gcssl_wgrad_reduce(const float* slab, int nsplit, float* dw, int Cout, int C
     if (!slab || !dw || (nrank > 0 && (!coef || !u || !v))) return GCSSL_ENULL;
     if (nsplit <= 0 || Cout <= 0 || Cin <= 0 || Cin_real <= 0 || Cin_real > Cin) return GCSSL_EBADSHAPE;
     if (nrank > 4 || (nrank > 0 && (ustride < Cout || vstride < Cin_real * 16))) return GCSSL_EBADSHAPE;
+    if (nrank > 0 && (vstride % 4 || !aligned16(v))) return GCSSL_EALIGN;                 // 16-byte loads of the v rows
     int zg = 1;
     if (accumulate == 2) { zg = (nsplit + 15) / 16; if (zg > 16) zg = 16; }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + 63) / 64), (unsigned)Cout, (unsigned)zg), dim3(256), 0,
@@ -1852,6 +2088,7 @@ int gcssl_wgrad_reduce_batch(int nl, const float* const* slab, const int* nsplit
         if (!slab[i] || !dw[i] || (nrank > 0 && (!coef[i] || !u[i] || !v[i]))) return GCSSL_ENULL;
         if (nsplit[i] <= 0 || Cout[i] <= 0 || Cin[i] <= 0 || Cin_real[i] <= 0 || Cin_real[i] > Cin[i]) return GCSSL_EBADSHAPE;
         if (nrank > 0 && (ustride < Cout[i] || vstride < Cin_real[i] * 16)) return GCSSL_EBADSHAPE;
+        if (nrank > 0 && (vstride % 4 || !aligned16(v[i]))) return GCSSL_EALIGN;      // 16-byte loads of the v rows
         int zg = 1;
         if (accumulate == 2) { zg = (nsplit[i] + 15) / 16; if (zg > 16) zg = 16; }
         b.l[i] = RedLayer{slab[i], dw[i], nrank ? coef[i] : nullptr, nrank ? u[i] : nullptr, nrank ? v[i] : nullptr,

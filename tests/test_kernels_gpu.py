@@ -67,6 +67,8 @@ CONV_CASES = [  # N, Hi, Cin(real), CinP, Cout
     (651, 16, 64, 64, 128),   # 652 fwd tiles / 2604 dgrad tiles of 128x64 (ragged last one): the persistent LDS-DMA kernel
     (256, 32, 64, 64, 128),   # G.up4 / D.c2 shapes at the bench batch: 2048 dgrad tiles
     (768, 32, 6, 8, 64),      # D.c1 at the bench batch: 1536 tiles of two K steps (8-channel persistent form)
+    (3, 64, 6, 8, 64),        # first-layer forward kernel at 64x64 (2 tiles of 4 output rows per sample)
+    (2, 128, 6, 8, 64),       # ... and 128x128 (Wo = 64: 2 output rows per tile)
     (16, 64, 128, 128, 256),  # filter-row LDS-DMA wgrad (>= 16 K steps for each of 256 workgroups): 2 x 2 channel blocks
     (1027, 8, 128, 128, 256), # ... with a ragged last K tile (16432 output pixels) and a short last split
 ]
