@@ -1,9 +1,14 @@
 set -o pipefail
 mkdir -p gpurun_out/r2g
-timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q --maxfail 5 -k "conv_fwd or conv_dgrad" > gpurun_out/r2g/k_tests.log 2>&1; echo "kernel tests rc=$?"; tail -3 gpurun_out/r2g/k_tests.log
-GCSSL_BENCH_VERBOSE=1 timeout -k 10 200 python bench.py --steps 30 --warmup 3 --dtype fp16 --no-cpu-baseline --probe-steps 2 --sustain-s 0 2>gpurun_out/r2g/b1.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'])"; grep "c1\.\|down1" gpurun_out/r2g/b1.err
-cd /tmp && export TMPDIR=/tmp
-rm -rf $GRAFT_REPO_ROOT/gpurun_out/r2g/prof
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r2g/prof -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --dtype fp16 --sustain-s 0 > $GRAFT_REPO_ROOT/gpurun_out/r2g/bench_prof.json 2> $GRAFT_REPO_ROOT/gpurun_out/r2g/bench_prof.err; echo "prof rc=$?"
-cd $GRAFT_REPO_ROOT
-python tools/prof_summary.py $(ls gpurun_out/r2g/prof/*results.db | head -1) --csv gpurun_out/r2g/kernel_stats.csv > gpurun_out/r2g/prof_summary.txt; grep "_c8_\|iterations" gpurun_out/r2g/prof_summary.txt
+timeout -k 10 400 python -m pytest tests/test_kernels_gpu.py -m gpu -q --maxfail 5 -k "conv_fwd or conv_dgrad or split" > gpurun_out/r2g/k_tests.log 2>&1; rc=$?; echo "kernel tests rc=$rc"; tail -3 gpurun_out/r2g/k_tests.log
+for v in 1 0 1 0; do GCSSL_RING=$v GCSSL_BENCH_VERBOSE=1 timeout -k 10 200 python bench.py --steps 30 --warmup 3 --dtype fp16 --no-cpu-baseline --probe-steps 2 --sustain-s 0 2>gpurun_out/r2g/b$v.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench ring=$v', d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['d_convs'])"; done
+python - <<'PY'
+import re
+rows = {}
+for v in ("1", "0"):
+    for l in open(f"gpurun_out/r2g/b{v}.err"):
+        m = re.match(r"\[probe\] (\S+)\s+(\d+)/iter\s+([\d.]+) us", l)
+        if m: rows.setdefault(m.group(1), {})[v] = float(m.group(3))
+for k, d in sorted(rows.items(), key=lambda kv: -abs(kv[1].get("1", 0) - kv[1].get("0", 0))):
+    if abs(d.get("1", 0) - d.get("0", 0)) > 1.5: print(f"{k:26s} ring {d.get('1'):7.1f}  off {d.get('0'):7.1f}")
+PY

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/tile_ab
 mkdir -p $O
 for shape in "$@"; do
-  for ft in none 128x128 256x128 256x64; do
+  for ft in ${FTS:-none 128x128 256x128 256x64}; do
     tag=$(echo "$shape-$ft" | tr ' ' '_')
     if [ $ft = none ]; then unset GCSSL_FORCE_TILE; else export GCSSL_FORCE_TILE=$ft; fi
     rm -rf $O/$tag
