@@ -69,6 +69,8 @@ CONV_CASES = [  # N, Hi, Cin(real), CinP, Cout
     (768, 32, 6, 8, 64),      # D.c1 at the bench batch: 1536 tiles of two K steps (8-channel persistent form)
     (3, 64, 6, 8, 64),        # first-layer forward kernel at 64x64 (2 tiles of 4 output rows per sample)
     (2, 128, 6, 8, 64),       # ... and 128x128 (Wo = 64: 2 output rows per tile)
+    (768, 8, 128, 128, 256),  # D.c3 at the bench batch: forward = 192 tiles of 128x128 on the loader/consumer ring
+    (768, 4, 256, 256, 512),  # D.c4: ring forward in two K halves (96 tiles), ring dgrad (192 tiles)
     (16, 64, 128, 128, 256),  # filter-row LDS-DMA wgrad (>= 16 K steps for each of 256 workgroups): 2 x 2 channel blocks
     (1027, 8, 128, 128, 256), # ... with a ragged last K tile (16432 output pixels) and a short last split
 ]

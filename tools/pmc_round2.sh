@@ -9,6 +9,9 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_r2
 mkdir -p $OUT
 DT=${1:-fp16}
+# rocprofv3's own --stats table of the bench command (csv output), for profiles/round2_rocprofv3_kernel_stats.csv
+rm -rf $OUT/bench_stats
+(cd $R && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o r -- python3 bench.py --no-cpu-baseline > $OUT/bench_stats.json 2> $OUT/bench_stats.err) || echo "bench stats pass failed"
 # tag | kernel-name filter | program + args
 CASES=(
  "D.c2.fwd[n=768]|conv_dma|tools/conv_bench.py fwd 768 16 64 128 $DT 5"
@@ -20,7 +23,7 @@ CASES=(
  "D.c2.dgrad|conv_dma|tools/conv_bench.py dgrad 768 16 64 128 $DT 5"
  "D.c3.dgrad|conv_dma|tools/conv_bench.py dgrad 768 8 128 256 $DT 5"
  "D.c4.dgrad|conv_dma|tools/conv_bench.py dgrad 768 4 256 512 $DT 5"
- "D.c1.fwd[n=768]|conv_dma|tools/conv_bench.py fwd 768 32 8 64 $DT 5"
+ "D.c1.fwd[n=768]|conv_|tools/conv_bench.py fwd 768 32 8 64 $DT 5"
  "D.c1.gp_dgrad|conv_|tools/conv_bench.py dgrad 256 32 8 64 $DT 5"
  "G.up4.fwd[n=768]|convt_in_relu|tools/convt_bench.py 768 16 128"
 )
