@@ -218,6 +218,8 @@ struct ConvParams {
                             // the consumer (gcssl_in_act_fwd nslab) adds the slabs: float atomics run at 1.3 TB/s chip-wide
     unsigned x_bytes, w_bytes;   // extents of the two operand buffers (buffer-load bounds; < 2^31)
     unsigned y_bytes;            // extent of the output (buffer-store bounds of the persistent kernel); 0 = unknown/too large
+    int dbg;                     // timing experiments (GCSSL_RING_DEBUG): 1 = loaders issue nothing, 2 = consumers compute nothing
+    int epi_lds;                 // conv_dma_kernel: result tile through LDS, 16-byte row stores (GCSSL_EPI_LDS=0: per-lane stores)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -610,7 +612,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
         constexpr int AHEAD = NSLOT - 1;                                   // K tiles issued ahead of the one being consumed
         if (loader) {
             for (int q = 0; q < AHEAD; ++q)
-                if (t_beg + q < t_end) issue(t_beg + q, q);
+                if (t_beg + q < t_end && !(p.dbg & 1)) issue(t_beg + q, q);
             int slot = 0;
             for (int t = t_beg; t < t_end; ++t) {
                 // tile t has landed once only the younger tiles' DMA instructions (NL each) are outstanding
@@ -620,18 +622,21 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
                 else if (young == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();      // tile t is published; tile t-1 is released (its slot is refilled now)
-                if (t + AHEAD < t_end) issue(t + AHEAD, slot == 0 ? NSLOT - 1 : slot - 1);
+                if (t + AHEAD < t_end && !(p.dbg & 1)) issue(t + AHEAD, slot == 0 ? NSLOT - 1 : slot - 1);
                 slot = slot == NSLOT - 1 ? 0 : slot + 1;
             }
             return;                                                        // (no barrier follows: the epilogue is the consumers')
         }
-        int slot = 0;
-        for (int t = t_beg; t < t_end; ++t) {
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
+        // Consumers, software-pipelined over the barrier: after barrier j the fragment reads of tile j are ISSUED and the MFMAs
+        // of tile j-1 (fragments already in registers) run while those reads are in flight.  With reads -> wait -> MFMAs inside
+        // one barrier interval a step cost ~1550 cycles for 512 cycles of MFMA per SIMD: all eight waves read at once right
+        // after the barrier, then all run their MFMAs, and nothing overlaps.  (tools/probes/fill_probe.hip: the loaders alone
+        // bring this layer's gather in at 80 GB/s per CU, twice what the unpipelined loop consumed.)
+        FragT a0[BK / 16][TM], b0[BK / 16][TN], a1[BK / 16][TM], b1[BK / 16][TN];
+        auto rd = [&](FragT (&a)[BK / 16][TM], FragT (&b)[BK / 16][TN], int slot) {
+            if (p.dbg & 2) return;
             const unsigned char* At = lds + slot * STAGE;
             const unsigned char* Bt = At + A_BYTES;
-            FragT a[BK / 16][TM], b[BK / 16][TN];
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
 #pragma unroll
@@ -639,13 +644,45 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[kk][j] = frag(Bt, wn0 + 32 * j, kk);
             }
+        };
+        auto mm = [&](const FragT (&a)[BK / 16][TM], const FragT (&b)[BK / 16][TN]) {
+            if (p.dbg & 2) return;
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = mfma(a[kk][i], b[kk][j], acc[i][j]);
-            slot = slot == NSLOT - 1 ? 0 : slot + 1;
+        };
+        auto next = [](int slot) { return slot == NSLOT - 1 ? 0 : slot + 1; };
+        if (t_beg < t_end) {
+            int slot = 0, t = t_beg;
+            __builtin_amdgcn_s_barrier();                                  // barrier of tile t_beg
+            rd(a0, b0, slot); slot = next(slot);
+            // (lgkmcnt(0) in front of every barrier: the loaders refill the slot of the tile whose reads were issued in the
+            //  interval that ends there -- those reads must have returned; they were issued a whole MFMA block earlier)
+            for (; t + 2 < t_end; t += 2) {                                // tiles t (in a0/b0), t+1, t+2
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                rd(a1, b1, slot); slot = next(slot);
+                mm(a0, b0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                rd(a0, b0, slot); slot = next(slot);
+                mm(a1, b1);
+            }
+            if (t + 1 < t_end) {                                           // two tiles left: t in a0/b0 and t+1
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                rd(a1, b1, slot);
+                mm(a0, b0);
+                mm(a1, b1);
+            } else {
+                mm(a0, b0);
+            }
         }
     } else if (t_beg < t_end) {
         issue(t_beg, 0);
@@ -704,6 +741,50 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
             if (p.gscale && m < p.M)          // sample -> group without an integer division (exact below 2^21 samples)
                 sc[i][r] = p.gscale[(int)(((float)(m >> p.lgHoWo) + 0.5f) * p.inv_group_n)];
         }
+    // ---- result tile through LDS (default): the MFMA C layout gives a lane one 4-byte element per row, i.e. 32 store
+    // instructions of 2 x 128 bytes per wave for a 32 x 64 wave tile; after a transpose through the (now idle) ring every
+    // store instruction writes 64 x 16 bytes of whole rows.  tools/tile_ab.sh with GCSSL_RING_DEBUG=3 (no DMA, no MFMA:
+    // launch + prologue + barriers + epilogue) put D.c3.fwd's skeleton at 14.5 of its 24 us.
+    {
+        const int es = (p.out_f32 || p.ksplit > 1) ? 4 : 2;                // element size of what is stored
+        const bool rows16 = p.epi_lds && !(p.ksplit > 1 && !p.split_stride) && (p.ldy * es) % 16 == 0 &&
+                            (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 && (p.split_stride * 4) % 16 == 0 && ncols % (16 / es) == 0;
+        if (rows16) {
+            const int RS = BN * es + 16;                                   // padded row stride of the LDS tile
+            static_assert(BM * (BN * 4 + 16) <= NSLOT * STAGE, "result tile must fit the ring");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                  // every wave is done with the ring
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm0 + 32 * i + crow(r, lane);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int colt = wn0 + 32 * j + (lane & 31);
+                        float v = acc[i][j][r] * sc[i][r] + bcol[j];
+                        if (MODE == 0 && p.act == 1 && p.ksplit <= 1) v = lrelu_f(v);
+                        if (es == 4) *reinterpret_cast<float*>(lds + row * RS + colt * 4) = v;
+                        else *reinterpret_cast<unsigned short*>(lds + row * RS + colt * 2) = (unsigned short)Bits16<T>::enc(v);
+                    }
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int cpr = BN * es / 16;                                  // 16-byte chunks per tile row (a power of two)
+            unsigned char* yb = static_cast<unsigned char*>(p.y) + (p.ksplit > 1 ? (size_t)ks * p.split_stride * 4 : 0);
+            for (int c = threadIdx.x; c < BM * cpr; c += NCW * 64) {
+                const int row = c / cpr, ch = c % cpr, m = m0 + row, col0 = n0 + ch * (16 / es);
+                if (m >= p.M || col0 >= ncols) continue;
+                size_t pix = (size_t)m;
+                if (MODE == 1) {
+                    const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
+                    pix = (size_t)(n * p.Hi + 2 * (rem >> p.lgWo) + py) * p.Wi + 2 * (rem & (Wo - 1)) + px;
+                }
+                *reinterpret_cast<uint4*>(yb + (pix * p.ldy + col0) * es) = *reinterpret_cast<const uint4*>(lds + row * RS + ch * 16);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1582,6 +1663,8 @@ void fill_geom(ConvParams& p, int N, int Hi, int Wi, int Cin, int Cout) {
     p.lgWo = ilog2(Wi / 2); p.lgHoWo = ilog2((Hi / 2) * (Wi / 2));
     p.lgCin = ilog2(Cin); p.lgCout = ilog2(Cout);
     p.M = N * (Hi / 2) * (Wi / 2);
+    static const int epi = [] { const char* e = getenv("GCSSL_EPI_LDS"); return e ? atoi(e) : 1; }();
+    p.epi_lds = epi;
 }
 
 // pick the workgroup tile so that the grid fills the 256 CUs when the problem allows it
@@ -1677,7 +1760,9 @@ int launch_ring(const ConvParams& p, hipStream_t st) {
     if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     const int ncols = MODE == 0 ? p.Cout : p.Cin;
     dim3 grid((p.M + 127) / 128, (ncols + 127) / 128, (MODE == 1 ? 4 : 1) * (p.ksplit > 1 ? p.ksplit : 1));
-    hipLaunchKernelGGL((conv_dma_kernel<T, 128, 128, MODE, 4, 2, false, 4, 4>), grid, dim3(768), 0, st, p);
+    static const int dbg = [] { const char* e = getenv("GCSSL_RING_DEBUG"); return e ? atoi(e) : 0; }();
+    ConvParams q = p; q.dbg = dbg;
+    hipLaunchKernelGGL((conv_dma_kernel<T, 128, 128, MODE, 4, 2, false, 4, 4>), grid, dim3(768), 0, st, q);
     return gcssl_launch_status();
 }
 template <typename T, int BM, int BN, int MODE>
