@@ -14,4 +14,8 @@ rm -rf $O/prof
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof -o r -- python3 $R/bench.py --no-cpu-baseline > $O/round2_bench_under_rocprof.json 2> $O/round2_bench_under_rocprof.err; echo "prof rc=$?"
 cd $R
 python tools/prof_summary.py $(ls $O/prof/*results.db | head -1) --csv $O/round2_kernel_stats.csv > $O/round2_kernel_summary.txt; head -12 $O/round2_kernel_summary.txt
-ls $O/prof
+rm -rf $O/prof                                   # the raw trace (tens of MB) stays on the box: gpurun copies back <= 64 MiB
+# rocprofv3's own --stats table (csv) of the same bench command
+rm -rf $O/bench_stats
+(cd $R && cd /tmp && TMPDIR=/tmp timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -o r -- python3 $R/bench.py --no-cpu-baseline > $O/bench_stats.json 2> $O/bench_stats.err) || echo "bench stats pass failed"
+rm -f $O/bench_stats/r_kernel_trace.csv $O/bench_stats/*.db; ls $O/bench_stats | head
