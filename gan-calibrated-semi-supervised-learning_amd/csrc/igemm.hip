@@ -229,7 +229,8 @@ struct ConvParams {
                             // the consumer (gcssl_in_act_fwd nslab) adds the slabs: float atomics run at 1.3 TB/s chip-wide
     unsigned x_bytes, w_bytes;   // extents of the two operand buffers (buffer-load bounds; < 2^31)
     unsigned y_bytes;            // extent of the output (buffer-store bounds of the persistent kernel); 0 = unknown/too large
-    int dbg;                     // timing experiments (GCSSL_RING_DEBUG): 1 = loaders issue nothing, 2 = consumers compute nothing
+    int dbg;                     // timing experiments on the ring form (GCSSL_RING_DEBUG bits): 1 loaders issue nothing, 2 consumers
+                                 // compute nothing, 4 no epilogue, 8 return at entry, 16 no K loop (results are garbage)
     int epi_lds;                 // conv_dma_kernel: result tile through LDS, 16-byte row stores (GCSSL_EPI_LDS=0: per-lane stores)
 };
 
@@ -519,6 +520,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool loader = LW > 0 && wave >= NCW;
+    if (LW > 0 && (p.dbg & 8)) return;                                  // (timing experiment: launch cost only)
     const int tid = LW ? (int)threadIdx.x - NCW * 64 : (int)threadIdx.x;   // index among the fetching threads (loaders: >= 0)
     const int fwave = LW ? wave - NCW : wave;
     int mxi = blockIdx.x, nyi = blockIdx.y;
@@ -617,7 +619,9 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
     const int nk_all = K / BK;
     const int t_beg = p.ksplit > 1 ? ks * p.ktiles_per_split : 0;
     const int t_end = p.ksplit > 1 ? min(nk_all, t_beg + p.ktiles_per_split) : nk_all;
-    if (LW > 0) {
+    if (LW > 0 && (p.dbg & 16)) {
+        if (loader) return;                                              // (timing experiment: no K loop)
+    } else if (LW > 0) {
         constexpr int AHEAD = NSLOT - 1;                                   // K tiles issued ahead of the one being consumed
         if (loader) {
             for (int q = 0; q < AHEAD; ++q)
@@ -728,6 +732,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
             slot = slot == 2 ? 0 : slot + 1;
         }
     }
+    if (LW > 0 && (p.dbg & 4)) return;                                  // (timing experiment: no epilogue)
     // ---- epilogue.  Everything the stores depend on is loaded FIRST: a load that sits between two stores cannot be
     // hoisted by the compiler (the output may alias it), so the per-row group scale used to serialise the tail into
     // 16-32 dependent load -> store round trips per wave (measured with s_memtime: a third of the workgroup's life).
