@@ -494,7 +494,7 @@ __device__ __forceinline__ void tile_decode(int L, int tiles_m, int tiles_n, int
 
 // WM x WN waves per workgroup (4 or 8 waves); SMALLK: the K-tile spans several taps (first layer, Cin padded to 8),
 // otherwise the tap of a K-tile is wave-uniform and its address arithmetic runs on the scalar unit.
-template <typename T, int BM, int BN, int MODE, int WM, int WN, bool SMALLK, int LW = 0, int NSLOT = 3>
+template <typename T, int BM, int BN, int MODE, int WM, int WN, bool SMALLK, int LW = 0, int NSLOT = 3, bool PIPE = true>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParams p) {
     // The host pass only needs the launch stub; it silently marks this body invalid (device-only LDS-DMA builtin and
     // inline asm with template-dependent operands) and then emits NO stub, so the body is device-pass only.
@@ -645,6 +645,30 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
         // one barrier interval a step cost ~1550 cycles for 512 cycles of MFMA per SIMD: all eight waves read at once right
         // after the barrier, then all run their MFMAs, and nothing overlaps.  (tools/probes/fill_probe.hip: the loaders alone
         // bring this layer's gather in at 80 GB/s per CU, twice what the unpipelined loop consumed.)
+        if constexpr (!PIPE) {                                             // reads -> MFMAs inside one barrier interval (fewer registers)
+            int slot = 0;
+            for (int t = t_beg; t < t_end; ++t) {
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned char* At = lds + slot * STAGE;
+                const unsigned char* Bt = At + A_BYTES;
+                FragT a[BK / 16][TM], b[BK / 16][TN];
+#pragma unroll
+                for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[kk][i] = frag(At, wm0 + 32 * i, kk);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[kk][j] = frag(Bt, wn0 + 32 * j, kk);
+                }
+#pragma unroll
+                for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = mfma(a[kk][i], b[kk][j], acc[i][j]);
+                slot = slot == NSLOT - 1 ? 0 : slot + 1;
+            }
+        } else {
         FragT a0[BK / 16][TM], b0[BK / 16][TN], a1[BK / 16][TM], b1[BK / 16][TN];
         auto rd = [&](FragT (&a)[BK / 16][TM], FragT (&b)[BK / 16][TN], int slot) {
             if (p.dbg & 2) return;
@@ -696,6 +720,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
             } else {
                 mm(a0, b0);
             }
+        }
         }
     } else if (t_beg < t_end) {
         issue(t_beg, 0);
@@ -1732,6 +1757,7 @@ int ring_ksplit(long tiles, int nk, bool split_allowed) {
     static const int on = [] { const char* e = getenv("GCSSL_RING"); return e ? atoi(e) : 1; }();
     if (!on || !use_dma() || tiles <= 0 || tiles > cu_count()) return 0;
     if (tiles >= 160) return 1;
+    // (D.c4.fwd[n=768] unsplit on 96 CUs is 28.5 vs 30.6 us stand-alone, but 39 vs 32 us inside the iteration: kept in two halves)
     if (!split_allowed || ksplit_max() <= 1) return 0;
     // ... a split only in two halves of >= 32 K steps (D.c4.fwd[n=768], 96 tiles: 40.0 -> 32.5 us); deeper splits of the
     // B-sample layers lost to the 64 x 64 split-K form (G.up2.dgrad 23.4 -> 34.1 us, D.c3.gp_dgrad 20.3 -> 24.2 us)
@@ -1774,7 +1800,11 @@ int launch_ring(const ConvParams& p, hipStream_t st) {
     dim3 grid((p.M + 127) / 128, (ncols + 127) / 128, (MODE == 1 ? 4 : 1) * (p.ksplit > 1 ? p.ksplit : 1));
     static const int dbg = [] { const char* e = getenv("GCSSL_RING_DEBUG"); return e ? atoi(e) : 0; }();
     ConvParams q = p; q.dbg = dbg;
-    // (8 loader waves -- 1024 threads, 128 registers per lane -- spill and run at half the speed: 53.9 vs 23.8 us)
+    // 8 loader waves (1024 threads, <= 128 registers: the consumers read -> wait -> MFMA inside one barrier interval) against 4
+    // loader waves with consumers software-pipelined across the barrier: 20.9 vs 23.8 us (D.c3.fwd), 20.8 vs 23.9 (D.c4.dgrad).
+    // The K loop of the 4-loader form ran at the loaders' issue rate (8 pieces x ~105 cycles per wave and step).
+    static const int lw8 = [] { const char* e = getenv("GCSSL_RING_LW8"); return e ? atoi(e) : 1; }();
+    if (lw8) { hipLaunchKernelGGL((conv_dma_kernel<T, 128, 128, MODE, 4, 2, false, 8, 4, false>), grid, dim3(1024), 0, st, q); return gcssl_launch_status(); }
     hipLaunchKernelGGL((conv_dma_kernel<T, 128, 128, MODE, 4, 2, false, 4, 4>), grid, dim3(768), 0, st, q);
     return gcssl_launch_status();
 }
