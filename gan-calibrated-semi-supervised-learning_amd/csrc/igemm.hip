@@ -1205,15 +1205,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
 //       (swaps the 64-B halves of k rows 2, 3 mod 4: the four k rows a 32-lane half reads then cover the four 64-B phases of
 //        a 256-B bank row)
 // ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(ConvParams p) {
+template <typename T, int LW = 0>
+__global__ __launch_bounds__(512 + LW * 64) void conv_wgrad_dma_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef typename Frag16<T>::type FragT;
-    constexpr int BM = 128, BN = 64, BK = 64, NLA = 2, NLB = 4, NL = NLA + NLB;      // DMA instructions per wave per K tile
+    // LW = 8: the 8 waves of the tile only read fragments and run MFMAs, 8 more waves own the LDS-DMA (a piece costs ~105
+    // cycles of issue: 6 of them per wave and step sat in front of each wave's 16 MFMAs)
+    constexpr int BM = 128, BN = 64, BK = 64, NLA = 2, NLB = 4, NL = NLA + NLB;      // DMA instructions per fetching wave per K tile
     constexpr int A_BYTES = BK * BM * 2, B_TAP = BK * BN * 2, STAGE = A_BYTES + 4 * B_TAP;   // 16 KB + 4 x 8 KB
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = LW > 0 && wave >= 8;
+    const int fwave = LW ? wave - 8 : wave;                             // index among the fetching waves
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (p.xcd_remap) {                                                  // a K split's workgroups on one XCD (see conv_wgrad_kernel)
         const int gx = gridDim.x, per = gx * gridDim.y, ns = gridDim.z;
@@ -1241,14 +1245,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(ConvParams p) {
         const int k0 = t * BK;
 #pragma unroll
         for (int jj = 0; jj < NLA; ++jj) {
-            const int j = 2 * wave + jj, kr = 4 * j + (lane >> 4), k = k0 + kr;
+            const int j = 2 * fwave + jj, kr = 4 * j + (lane >> 4), k = k0 + kr;
             const int lc = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (lds_void_p)(base + j * 1024), 16,
                 k < Ktot ? (unsigned)((k * p.ldw + co0 + lc * 8) * 2) : OOB, 0, 0, 0);
         }
 #pragma unroll
         for (int jj = 0; jj < NLB; ++jj) {
-            const int id = 4 * wave + jj, kx = id >> 3, j = id & 7, kr = 8 * j + (lane >> 3), k = k0 + kr;
+            const int id = 4 * fwave + jj, kx = id >> 3, j = id & 7, kr = 8 * j + (lane >> 3), k = k0 + kr;
             const int lc = (lane & 7) ^ (((kr >> 1) & 1) << 2);
             const int n = k >> p.lgHoWo, rem = k & ((1 << p.lgHoWo) - 1);
             const int iy = 2 * (rem >> p.lgWo) - 1 + ky, ix = 2 * (rem & (Wo - 1)) - 1 + kx;
@@ -1289,7 +1293,42 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(ConvParams p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if (kt_beg < kt_end) {
+    if (LW > 0) {
+        if (loader) {
+            if (kt_beg < kt_end) issue(kt_beg, 0);
+            if (kt_beg + 1 < kt_end) issue(kt_beg + 1, 1);
+            int slot = 0;
+            for (int t = kt_beg; t < kt_end; ++t) {
+                if (t + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                           // tile t published, tile t-1 released
+                if (t + 2 < kt_end) issue(t + 2, slot == 0 ? 2 : slot - 1);
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+            return;                                                     // (the epilogue has no barrier)
+        }
+        int slot = 0;
+        for (int t = kt_beg; t < kt_end; ++t) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* S = lds + slot * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {                            // fragments per K sub-step: 16 live registers, not 64
+                FragT a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    b[i] = trfrag(S + boff[i][0] + ks * 2048, S + boff[i][1] + ks * 2048);
+                    a[i] = trfrag(S + aoff[i][0] + ks * 4096, S + aoff[i][1] + ks * 4096);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    } else if (kt_beg < kt_end) {
         issue(kt_beg, 0);
         if (kt_beg + 1 < kt_end) issue(kt_beg + 1, 1);
         int slot = 0;
@@ -2290,8 +2329,14 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
     if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (dtype != GCSSL_F32 && wgrad_dma_shape(N, Hi, Wi, Cin, Cout)) {
         dim3 gd(Cout / 128, 4 * (Cin / 64), nsplit);                    // LDS-DMA ring, one filter row (4 taps) per workgroup
-        if (dtype == GCSSL_F16) hipLaunchKernelGGL(conv_wgrad_dma_kernel<f16_t>, gd, dim3(512), 0, st, p);
-        else hipLaunchKernelGGL(conv_wgrad_dma_kernel<bf16_t>, gd, dim3(512), 0, st, p);
+        static const int lw = [] { const char* e = getenv("GCSSL_WGRAD_LW"); return e ? atoi(e) : 8; }();    // A/B knob: 0 = all waves fetch
+        if (lw) {
+            if (dtype == GCSSL_F16) hipLaunchKernelGGL((conv_wgrad_dma_kernel<f16_t, 8>), gd, dim3(1024), 0, st, p);
+            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<bf16_t, 8>), gd, dim3(1024), 0, st, p);
+            return gcssl_launch_status();
+        }
+        if (dtype == GCSSL_F16) hipLaunchKernelGGL((conv_wgrad_dma_kernel<f16_t, 0>), gd, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<bf16_t, 0>), gd, dim3(512), 0, st, p);
         return gcssl_launch_status();
     }
     dim3 grid(Cout / bm, smallc ? 1 : 16 * (Cin / bn), nsplit);
