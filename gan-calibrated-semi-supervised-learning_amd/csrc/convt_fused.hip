@@ -44,6 +44,7 @@ struct CtParams {
     void* a;            // nullable: activation output [N][2H][2H][lda] (16-bit)
     float* mean; float* rstd;   // [N][64]
     float* pool;        // nullable: [N][64] sum over the output pixels of the activation (written, not accumulated)
+    float* cnt;         // nullable (needs pool): [N][64] number of output pixels with a positive normalised value (written)
     int ldx, ldz, lda, z_n0;
     int N, lgH, K;      // H = 1 << lgH in {8, 16}; K input channels (multiple of 32)
     int nblocks;        // pixel blocks of 256 input pixels = N * H * H / 256
@@ -338,13 +339,16 @@ __global__ __launch_bounds__(NTH) void convt_in_relu_kernel(CtParams p) {
             for (int sl = 0; sl < nslot; ++sl)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    float v = 0.f;
+                    float v = 0.f, c = 0.f;
 #pragma unroll
                     for (int i = sl * bps; i < (sl + 1) * bps; ++i)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) v += fmaxf((acc[i][j][r] - mu[sl][j]) * rs[sl][j], 0.f);
-                    v += __shfl_xor(v, 32, 64);
-                    if (lane < 32) red[(wave * 2 + sl) * 64 + 32 * j + lane] = v;
+                        for (int r = 0; r < 16; ++r) {
+                            const float xh = (acc[i][j][r] - mu[sl][j]) * rs[sl][j];
+                            v += fmaxf(xh, 0.f); c += xh > 0.f ? 1.f : 0.f;
+                        }
+                    v += __shfl_xor(v, 32, 64); c += __shfl_xor(c, 32, 64);
+                    if (lane < 32) { red[(wave * 2 + sl) * 64 + 32 * j + lane] = v; red[1024 + (wave * 2 + sl) * 64 + 32 * j + lane] = c; }
                 }
             lds_barrier();
             if (writer) {
@@ -353,13 +357,15 @@ __global__ __launch_bounds__(NTH) void convt_in_relu_kernel(CtParams p) {
                     const int n = blk * spw + (HW >= 128 ? 0 : 2 * half + sl);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        float tsum = 0.f;
+                        float tsum = 0.f, csum = 0.f;
 #pragma unroll
                         for (int w = 0; w < 8; ++w) {
                             if (HW < 128 && (w & 1) != half) continue;
                             tsum += red[(w * 2 + sl) * 64 + 32 * j + lane];
+                            csum += red[1024 + (w * 2 + sl) * 64 + 32 * j + lane];
                         }
                         p.pool[(size_t)n * 64 + 32 * j + lane] = tsum;
+                        if (p.cnt) p.cnt[(size_t)n * 64 + 32 * j + lane] = csum;
                     }
                 }
             }
@@ -379,10 +385,13 @@ extern "C" {
 /* ConvTranspose2d(K -> 64, k4 s2 p1, no bias) + InstanceNorm2d + ReLU (+ the sums of AdaptiveAvgPool2d(1)) in one launch
  * (cgan/models.py:72-74,112-118), for inputs of 8x8 or 16x16 pixels.  wt: the dgrad pack Wt[64][16][K] of
  * gcssl_prep_conv_weight.  Outputs (each nullable except mean/rstd): a [N][2H][2H][lda] in `dtype`; z32 fp32 pre-norm values
- * for samples >= z_n0 (what gcssl_in_act_bwd reads); pool[N][64] = sum over pixels of the activation (written). */
+ * for samples >= z_n0 (what gcssl_in_act_bwd reads); pool[N][64] = sum over pixels of the activation (written); cnt[N][64]
+ * (needs pool) = number of output pixels whose normalised value is positive, i.e. sum of ReLU' (written): with pool it lets
+ * gcssl_in_act_bwd skip its statistics pass when the incoming gradient is a per-(n, c) constant (presum_cnt / presum_pos). */
 int gcssl_convT4x4s2_in_relu_fwd(int dtype, const void* x, int ldx, const void* wt, float* z32, int ldz, int z_n0, void* a,
-                                 int lda, float* mean, float* rstd, float* pool, int N, int H, int K, int Cout, void* stream) {
-    if (!x || !wt || !mean || !rstd) return GCSSL_ENULL;
+                                 int lda, float* mean, float* rstd, float* pool, float* cnt, int N, int H, int K, int Cout,
+                                 void* stream) {
+    if (!x || !wt || !mean || !rstd || (cnt && !pool)) return GCSSL_ENULL;
     if (dtype != GCSSL_BF16 && dtype != GCSSL_F16) return GCSSL_EBADDTYPE;
     if (N <= 0 || (H != 8 && H != 16) || K < 64 || K % 32 || Cout != 64 || ldx < K || ldx % 8) return GCSSL_EBADSHAPE;   // (K >= 64: 8 K steps > ring depth)
     if ((N * H * H) % 256) return GCSSL_EBADSHAPE;                      // whole pixel blocks (H = 8: N a multiple of 4)
@@ -391,7 +400,7 @@ int gcssl_convT4x4s2_in_relu_fwd(int dtype, const void* x, int ldx, const void* 
     const size_t xb = (size_t)N * H * H * ldx * 2, wb = (size_t)64 * 16 * K * 2;
     if (xb >= 0x7FFFFFFFull) return GCSSL_EBADSHAPE;
     CtParams p{};
-    p.x = x; p.wt = wt; p.z32 = z32; p.a = a; p.mean = mean; p.rstd = rstd; p.pool = pool;
+    p.x = x; p.wt = wt; p.z32 = z32; p.a = a; p.mean = mean; p.rstd = rstd; p.pool = pool; p.cnt = cnt;
     p.ldx = ldx; p.ldz = ldz; p.lda = lda; p.z_n0 = z_n0; p.N = N; p.lgH = H == 8 ? 3 : 4; p.K = K;
     p.nblocks = N * H * H / 256; p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
     static const int rot = [] { const char* e = getenv("GCSSL_CT_ROTATE"); return (e && e[0] == '0') ? 0 : 1; }();

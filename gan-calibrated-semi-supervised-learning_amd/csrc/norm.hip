@@ -393,6 +393,7 @@ struct InBwdParams {
     int nrep, rep_stride;              // dbias/cdot are nrep replicas rep_stride floats apart; a workgroup adds to one
     int da_nslab; long da_slab_stride; // da is the first of da_nslab split-K partial-sum slabs of the producing conv (floats apart)
     int HW, C, act;
+    const float* pre_cnt; const float* pre_pos; float pre_pos_scale;   // optional precomputed sums (see gcssl_in_act_bwd)
 };
 
 // small maps: fused backward, several samples per pass and several passes per workgroup (see combine_seg)
@@ -584,6 +585,13 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_kernel(InBwdParams q, float*
         combine16<2>(s, sm, tx, ty);
 #pragma unroll
         for (int j = 0; j < VC; ++j) { m1[j] = s[0][j] / HW; m2[j] = s[1][j] / HW; }
+    } else if (q.pre_cnt) {
+        // the incoming gradient is the per-(n, c) constant dab and the activation is ReLU: sum dn = dab * #{xhat > 0} and
+        // sum dn xhat = dab * sum relu(xhat), both of which the forward kernel already produced (count, pooled sum)
+        float cn[VC], ps[VC];
+        ld4(q.pre_cnt + (size_t)n * C + c, cn); ld4(q.pre_pos + (size_t)n * C + c, ps);
+#pragma unroll
+        for (int j = 0; j < VC; ++j) { m1[j] = dab[j] * cn[j] / HW; m2[j] = dab[j] * (ps[j] * q.pre_pos_scale) / HW; }
     } else {
 #pragma unroll
         for (int j = 0; j < VC; ++j) { m1[j] = ws[((size_t)n * C + c + j) * 2] / HW; m2[j] = ws[((size_t)n * C + c + j) * 2 + 1] / HW; }
@@ -953,7 +961,8 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
                      const float* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask,
                      const float* zt, int zt_n0, const float* gscale, int group_n, const float* bias,
                      void* dzs, int lddz, float* dbias, float* cdot, int nrep, int rep_stride, int da_nslab, long da_slab_stride,
-                     float* ws, int N, int HW, int C, int act, void* stream) {
+                     float* ws, const float* presum_cnt, const float* presum_pos, float presum_pos_scale, int N, int HW, int C,
+                     int act, void* stream) {
     if ((!da && !da_bcast) || !z || !mean || !rstd || !dzs) return GCSSL_ENULL;
     if (nrep < 1 || (nrep > 1 && rep_stride < C)) return GCSSL_EBADSHAPE;
     if (da_nslab < 1 || (da_nslab > 1 && (!da || da_slab_stride <= 0 || da_slab_stride % 4 || HW > MID_HW))) return GCSSL_EBADSHAPE;
@@ -961,7 +970,7 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
     if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lddz < C || ldz % 4 || lddz % 4 || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
     if ((da && ldda % 4) || (da2 && ldda2 % 4)) return GCSSL_EBADSHAPE;
     if ((gscale || cdot) && group_n <= 0) return GCSSL_EBADSHAPE;
-    if (HW > MID_HW && !ws) return GCSSL_ENULL;
+    if (HW > MID_HW && !ws && !(presum_cnt && presum_pos)) return GCSSL_ENULL;
     InBwdParams q{da, ldda, da2, ldda2, da_bcast, z, ldz, mean, rstd, mask, zt, zt_n0, gscale,
                   group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, nrep, rep_stride, da_nslab, da_slab_stride, HW, C, act};
     hipStream_t st = (hipStream_t)stream;
@@ -979,6 +988,12 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
         return gcssl_launch_status();
     }
     dim3 grid(C / CW, N, (HW + SMALL_HW - 1) / SMALL_HW);
+    if (presum_cnt && presum_pos) {                          // statistics known from the forward pass: the apply pass alone
+        if (da || da2 || mask || zt || !da_bcast || act != 2) return GCSSL_EBADSHAPE;
+        q.pre_cnt = presum_cnt; q.pre_pos = presum_pos; q.pre_pos_scale = presum_pos_scale;
+        GCSSL_DISPATCH(dtype, hipLaunchKernelGGL((in_bwd_kernel<T, 2>), grid, dim3(CGN * RGN), 0, st, q, ws));
+        return gcssl_launch_status();
+    }
     gcssl_zero_async(ws, 2 * (size_t)N * C, st);             // (a kernel, not a memset node: common.h)
     GCSSL_DISPATCH(dtype,
         hipLaunchKernelGGL((in_bwd_kernel<T, 1>), grid, dim3(CGN * RGN), 0, st, q, ws);

@@ -94,7 +94,7 @@ class FlatParams:
 class GFwd:
     """Forward-pass buffers of the U-Net generator for a batch of n samples (activations, pre-norm tensors with their
     split-K slab room, statistics, dropout masks, head)."""
-    FIELDS = ("cat3", "cat2", "cat1", "d4", "u4", "pooled", "poolsum", "traw", "delta", "x8")
+    FIELDS = ("cat3", "cat2", "cat1", "d4", "u4", "pooled", "poolsum", "ucnt", "traw", "delta", "x8")
     LISTS = ("zd", "zu", "dmean", "drstd", "umean", "urstd", "masks")
 
     def group(self, g: int, b: int) -> "GFwd":
@@ -401,12 +401,14 @@ class StepEngine:
         ga.masks = [ga.maskbuf[sum(sizes[:j]):sum(sizes[:j + 1])].view(sh) for j, sh in enumerate(shapes)]
         ga.pooled = torch.empty(n, 64, **f32)
         ga.poolsum = torch.zeros(n, 64, **f32)                     # sum over H*W of u4 (up4's IN apply pass adds, the head consumes and clears)
+        ga.ucnt = torch.zeros(n, 64, **f32)                        # fused up4: how many of u4's values are positive, per (n, c)
         ga.x8 = act(n, S, 8)                                       # NHWC8 input of the batched forward (pred, replicated per call)
         self.gf = gf = ga.group(self.c, B)
         self.g_cat3, self.g_cat2, self.g_cat1, self.g_d4, self.g_u4 = gf.cat3, gf.cat2, gf.cat1, gf.d4, gf.u4
         self.g_zd, self.g_zu, self.g_dmean, self.g_drstd = gf.zd, gf.zu, gf.dmean, gf.drstd
         self.g_umean, self.g_urstd, self.g_masks = gf.umean, gf.urstd, gf.masks
-        self.g_pooled, self.g_poolsum = gf.pooled, gf.poolsum
+        self.g_pooled, self.g_poolsum, self.g_ucnt = gf.pooled, gf.poolsum, gf.ucnt
+        self._up4_presums = False                                  # set by a fused up4 forward: cnt / pooled describe g_zu[3]
         self.g_dab = torch.empty(B, 64, **f32)
         # generator backward
         self.g_dzu = [act(B, S // 8, 256), act(B, S // 4, 128), act(B, S // 2, 64), act(B, S, 64)]
@@ -556,7 +558,9 @@ class StepEngine:
                 stored = (ins[k].numel() + self.gu_wt[k].numel() + (n * hw_o * coutt if k < 3 else 0)) * es + (n - z_n0) * hw_o * coutt * 4
                 self._conv(f"G.up{k + 1}.fwd{tag}", conv_flops(n, 2 * hin, coutt, cint), ops.convt_in_relu_fwd, ins[k],
                            self.gu_wt[k], f.umean[k], f.urstd[k], cint, z32=f.zu[k], z_n0=z_n0, a=outs[k] if k < 3 else None,
-                           pool=f.poolsum if k == 3 else None, _bytes=(algo, stored))
+                           pool=f.poolsum if k == 3 else None, cnt=f.ucnt if k == 3 else None, _bytes=(algo, stored))
+                if k == 3:
+                    self._up4_presums = True
                 continue
             ns, st = self._split("dgrad", f.zu[k], n, S >> (3 - k), coutt, cint) if k < 3 else (1, 0)
             self._conv(f"G.up{k + 1}.fwd{tag}", conv_flops(n, S >> (3 - k), coutt, cint), ops.conv_dgrad, ins[k],
@@ -564,6 +568,8 @@ class StepEngine:
             ops.in_act_fwd(f.zu[k], outs[k], f.umean[k], f.urstd[k], coutt, RELU,
                            mask=mk[k + 1] if k < 2 else None, pool=f.poolsum if k == 3 else None,
                            nslab=ns, slab_stride=st)
+            if k == 3:
+                self._up4_presums = False
         ops.pool_fc_tanh_fwd(f.u4, self.G.views["fc_delta.1.weight"], self.G.views["fc_delta.1.bias"],
                              self.delta_scale, f.pooled, f.traw, f.delta, pool_sum=f.poolsum)
         return f.delta
@@ -846,8 +852,12 @@ class StepEngine:
             cint, coutt = G_UP[k]
             key = f"up{k + 1}.model.0.weight" if k < 3 else "up4.0.weight"
             if k == 3:
+                # (after a fused up4 forward the statistics of this backward -- sum of ReLU' and sum of relu(xhat) per (n, c) --
+                #  are its `cnt` output and the head's pooled mean x H*W: maps of > 256 pixels skip their pass over z)
+                pre = self._up4_presums and S * S > 256 and os.environ.get("GCSSL_UP4_PRESUM", "1") != "0"      # (A/B knob)
                 ops.in_act_bwd(self.g_zu[3], self.g_umean[3], self.g_urstd[3], self.g_dzu[3], coutt, RELU,
-                               da_bcast=self.g_dab, ws=self.ws)
+                               da_bcast=self.g_dab, ws=self.ws, presum_cnt=self.g_ucnt if pre else None,
+                               presum_pos=self.g_pooled if pre else None, presum_pos_scale=float(S * S))
             else:
                 ops.in_act_bwd(self.g_zu[k], self.g_umean[k], self.g_urstd[k], self.g_dzu[k], coutt, RELU,
                                da=dcat[k + 1][..., :coutt], mask=self.g_masks[k + 1] if k < 2 else None, ws=self.ws)

@@ -95,13 +95,14 @@ def conv_dgrad(dy, wt, dx, cin, cout, gscale=None, group_n=0, split_stride=0):
          int(split_stride))
 
 
-def convt_in_relu_fwd(x, wt, mean, rstd, K, z32=None, z_n0=0, a=None, pool=None):
+def convt_in_relu_fwd(x, wt, mean, rstd, K, z32=None, z_n0=0, a=None, pool=None, cnt=None):
     """ConvTranspose2d(K -> 64, k4 s2 p1) + InstanceNorm + ReLU in one launch (csrc/convt_fused.hip).  x: [N][H][H][>=K],
     H in (8, 16), N*H*H a multiple of 256; wt: the dgrad pack [64][16][K].  Optional outputs: a (16-bit activation, may be a
-    channel slice of a concat buffer), z32 (fp32 pre-norm values, written for samples >= z_n0 only), pool ([N][64] sums)."""
+    channel slice of a concat buffer), z32 (fp32 pre-norm values, written for samples >= z_n0 only), pool ([N][64] sums),
+    cnt ([N][64] counts of positive outputs; with pool it lets in_act_bwd skip its statistics pass)."""
     N, H, _, _ = x.shape
     call("gcssl_convT4x4s2_in_relu_fwd", code(x), x, _ld(x), wt, z32, _ld(z32) if z32 is not None else 0, int(z_n0), a,
-         _ld(a) if a is not None else 0, mean, rstd, pool, N, H, K, 64)
+         _ld(a) if a is not None else 0, mean, rstd, pool, cnt, N, H, K, 64)
 
 
 def convt_fused_ok(dt: int, n: int, h: int, cout_t: int) -> bool:
@@ -199,13 +200,13 @@ def in_act_fwd(z, a, mean, rstd, C, act, mask=None, pool=None, nslab=1, slab_str
 
 def in_act_bwd(z, mean, rstd, dzs, C, act, da=None, da2=None, da_bcast=None, mask=None, zt=None, zt_n0=0,
                gscale=None, group_n=0, bias=None, dbias=None, cdot=None, ws=None, nrep=1, rep_stride=0, da_nslab=1,
-               da_slab_stride=0):
+               da_slab_stride=0, presum_cnt=None, presum_pos=None, presum_pos_scale=1.0):
     """da_nslab > 1: da is the first of that many split-K slabs (da_slab_stride floats apart), added on load.  nrep > 1: dbias / cdot point at replica 0 of nrep replicas rep_stride floats apart (fold with ReplicaSum)."""
     N, H, W, _ = z.shape
     assert z.dtype == torch.float32 and all(t is None or t.dtype == torch.float32 for t in (da, da2, zt))
     call("gcssl_in_act_bwd", code(dzs), da, _ld(da) if da is not None else 0, da2, _ld(da2) if da2 is not None else 0,
          da_bcast, z, _ld(z), mean, rstd, mask, zt, zt_n0, gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot, nrep, rep_stride,
-         da_nslab, int(da_slab_stride), ws, N, H * W, C, act)
+         da_nslab, int(da_slab_stride), ws, presum_cnt, presum_pos, float(presum_pos_scale), N, H * W, C, act)
 
 
 def in_dbl_bwd(gb_a, qz, gb_zs, z, mean, rstd, gt_a, zt, C, act, cdot=None, q_nslab=1, q_slab_stride=0):

@@ -127,8 +127,13 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
                      const float* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask, const float* zt,
                      int zt_n0, const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias,
                      float* cdot, int nrep, int rep_stride, int da_nslab, long da_slab_stride,
-                     float* ws, int N, int HW, int C, int act, void* stream);
-/* ws: caller-owned scratch of 2*N*C floats, required when H*W > 64 (two-kernel path), else may be NULL. */
+                     float* ws, const float* presum_cnt, const float* presum_pos, float presum_pos_scale,
+                     int N, int HW, int C, int act, void* stream);
+/* ws: caller-owned scratch of 2*N*C floats, required when H*W > 256 (two-kernel path), else may be NULL.
+ * presum_cnt / presum_pos (nullable, [N][C] fp32; only with act = ReLU and da_bcast as the sole incoming gradient): the
+ * number of positive normalised values and presum_pos_scale * presum_pos = their sum, as the forward pass left them
+ * (gcssl_convT4x4s2_in_relu_fwd's cnt, and its pool or the head's pooled mean with scale H*W): maps of more than 256
+ * pixels then skip the statistics pass over z and need no ws. */
 /* second-order backward (create_graph=True, cgan/losses.py:213-220): adjoint of dz=IN_bwd(z, act'*gb_a) for an
  * incoming adjoint qz: gt_a = act'(xhat) * d/d(dn), zt = d/dz; cdot += sum gb_zs*qz. */
 int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, int ldq, const void* gb_zs, int ldgz,
@@ -164,9 +169,10 @@ int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* c
  * x [N][H][H][ldx>=K]; wt = the dgrad pack Wt[64][16][K] of gcssl_prep_conv_weight.  Outputs, each nullable except
  * mean/rstd [N][64]: a [N][2H][2H][lda] in `dtype`; z32 = the fp32 pre-norm values of samples >= z_n0 only (what
  * gcssl_in_act_bwd reads for the samples that have a backward pass); pool [N][64] = sum over the output pixels of the
- * activation (written, not accumulated). */
+ * activation (written, not accumulated); cnt [N][64] (needs pool) = how many of them are positive (written). */
 int gcssl_convT4x4s2_in_relu_fwd(int dtype, const void* x, int ldx, const void* wt, float* z32, int ldz, int z_n0, void* a,
-                                 int lda, float* mean, float* rstd, float* pool, int N, int H, int K, int Cout, void* stream);
+                                 int lda, float* mean, float* rstd, float* pool, float* cnt, int N, int H, int K, int Cout,
+                                 void* stream);
 
 /* ---- gradient penalty (cgan/losses.py:223-231) -------------------------------------------------------------------
  * nrm[b] = sqrt(sum g_b^2 + 1e-12); gp_sum += mean((nrm-1)^2); coef[b] = lambda_gp*2/B*(nrm-1)/nrm. */

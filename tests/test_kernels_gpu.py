@@ -605,6 +605,24 @@ def test_fused_convT_instnorm_relu(ops, dt, tol, N, H, K, z_n0):
     assert rel_err(pool.cpu(), act.sum(dim=(2, 3))) < 1e-4
     # outputs are optional: statistics + pool only (what G.up4 needs for the samples of the no-grad forwards)
     mean2 = torch.empty_like(mean); rstd2 = torch.empty_like(rstd); pool2 = torch.empty_like(pool)
-    ops.convt_in_relu_fwd(xd, wt, mean2, rstd2, K, pool=pool2)
+    cnt = torch.full((N, 64), float("nan"), device="cuda")
+    ops.convt_in_relu_fwd(xd, wt, mean2, rstd2, K, pool=pool2, cnt=cnt)
     torch.cuda.synchronize()
     assert torch.equal(mean2, mean) and torch.equal(rstd2, rstd) and torch.equal(pool2, pool)
+    # cnt = number of positive normalised outputs per (n, c); values within 1e-5 of zero may land on either side
+    xh = (z - mu[:, :, None, None]) * r[:, :, None, None]
+    lo, hi = (xh > 1e-5).sum(dim=(2, 3)).double(), (xh > -1e-5).sum(dim=(2, 3)).double()
+    c = cnt.cpu().double()
+    assert bool(((c >= lo) & (c <= hi)).all()) and bool((c == c.round()).all())
+    if H == 16:
+        # ... and with the pooled sums it replaces the statistics pass of the InstanceNorm backward when the incoming gradient
+        # is a per-(n, c) constant (the generator head's average pool): maps of 32 x 32 = 1024 pixels
+        dab = rnd(N - z_n0, 64, seed=103).cuda()
+        zb = z32[z_n0:].contiguous()
+        ws = torch.zeros(2 * (N - z_n0) * 64, device="cuda")
+        dz_a = torch.empty(N - z_n0, 2 * H, 2 * H, 64, device="cuda", dtype=dt); dz_b = torch.empty_like(dz_a)
+        ops.in_act_bwd(zb, mean[z_n0:], rstd[z_n0:], dz_a, 64, 2, da_bcast=dab, ws=ws)
+        ops.in_act_bwd(zb, mean[z_n0:], rstd[z_n0:], dz_b, 64, 2, da_bcast=dab, presum_cnt=cnt[z_n0:], presum_pos=pool[z_n0:],
+                       presum_pos_scale=1.0)
+        torch.cuda.synchronize()
+        assert rel_err(dz_b.float().cpu(), dz_a.float().cpu()) < (2e-5 if dt == torch.float32 else tol)
