@@ -1,5 +1,6 @@
 set -o pipefail
-mkdir -p gpurun_out/r2h
-for cfg in "--batch 512 --size 32" "--batch 128 --size 64" "--batch 256 --size 64" "--batch 128 --size 128" "--batch 64 --size 128 --n_critic 5" "--batch 1024 --size 32" "--generator simple" "--batch 64 --size 32 --dtype fp32" "--batch 32 --size 32"; do
-  timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --probe-steps 1 --sustain-s 0 $cfg 2>gpurun_out/r2h/cfg.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$cfg', d['dtype'], d['value'], d['ms_per_step'], d['finite_after_run'])" || { echo "$cfg FAILED"; tail -3 gpurun_out/r2h/cfg.err; }
-done
+mkdir -p gpurun_out/r2g
+timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -m gpu -q --maxfail 5 -k "fused_convT" > gpurun_out/r2g/k_tests.log 2>&1; rc=$?; echo "fused tests rc=$rc"; tail -2 gpurun_out/r2g/k_tests.log
+[ $rc -eq 0 ] || { grep -n "^E " gpurun_out/r2g/k_tests.log | head -5; exit 1; }
+timeout -k 10 100 python tools/convt_bench.py 768 16 128; timeout -k 10 100 python tools/convt_bench.py 768 8 256
+for i in 1 2; do timeout -k 10 200 python bench.py --steps 30 --warmup 3 --dtype fp16 --no-cpu-baseline --probe-steps 2 --sustain-s 0 2>gpurun_out/r2g/b.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'])"; done
