@@ -232,6 +232,12 @@ struct ConvParams {
     int dbg;                     // timing experiments on the ring form (GCSSL_RING_DEBUG bits): 1 loaders issue nothing, 2 consumers
                                  // compute nothing, 4 no epilogue, 8 return at entry, 16 no K loop (results are garbage)
     int epi_lds;                 // conv_dma_kernel: result tile through LDS, 16-byte row stores (GCSSL_EPI_LDS=0: per-lane stores)
+    // ---- FIN forms (gcssl_conv4x4s2_in_act_fwd): InstanceNorm + activation in the epilogue.  y is the 16-bit ACTIVATION
+    // (pixel stride ldy); the whole H*W map of a sample lies inside one M tile, so the statistics need no second pass.
+    float* in_mean; float* in_rstd;       // [N][Cout] fp32 outputs
+    const uint8_t* in_mask;               // dropout keep mask [N][Ho*Wo][Cout] or null (kept values x 2)
+    void* in_apre; int ld_apre, apre_n0;  // optional second output: the activation WITHOUT dropout for samples n >= apre_n0
+                                          // ([N - apre_n0][Ho*Wo][ld_apre]): what the backward rebuilds xhat from
 };
 
 // ------------------------------------------------------------------------------------------
@@ -494,7 +500,13 @@ __device__ __forceinline__ void tile_decode(int L, int tiles_m, int tiles_n, int
 
 // WM x WN waves per workgroup (4 or 8 waves); SMALLK: the K-tile spans several taps (first layer, Cin padded to 8),
 // otherwise the tap of a K-tile is wave-uniform and its address arithmetic runs on the scalar unit.
-template <typename T, int BM, int BN, int MODE, int WM, int WN, bool SMALLK, int LW = 0, int NSLOT = 3, bool PIPE = true>
+// FIN: forward conv + InstanceNorm2d(eps 1e-5, biased variance) + LeakyReLU(0.2) [+ Dropout(0.5) mask] in ONE launch
+// (cgan/models.py:57-63,236-242): for maps of H*W <= 64 pixels a BM-row tile holds BM / (H*W) whole samples, so the per-(n, c)
+// statistics are complete inside the tile for its channel slice.  The fp32 accumulator tile goes to the idle ring, the
+// statistics are the exact two-pass ones computed from LDS, and what leaves is the 16-bit activation + fp32 mean / rstd:
+// the fp32 pre-norm tensor z (4 B written by the conv, 4 B read + 2 B written by a separate norm launch) never exists.
+template <typename T, int BM, int BN, int MODE, int WM, int WN, bool SMALLK, int LW = 0, int NSLOT = 3, bool PIPE = true,
+          bool FIN = false>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParams p) {
     // The host pass only needs the launch stub; it silently marks this body invalid (device-only LDS-DMA builtin and
     // inline asm with template-dependent operands) and then emits NO stub, so the body is device-pass only.
@@ -780,6 +792,77 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
             if (p.gscale && m < p.M)          // sample -> group without an integer division (exact below 2^21 samples)
                 sc[i][r] = p.gscale[(int)(((float)(m >> p.lgHoWo) + 0.5f) * p.inv_group_n)];
         }
+    if constexpr (FIN) {
+        // ---- InstanceNorm + activation epilogue (MODE 0, no K split; the host guarantees H*W <= 64 divides BM, 16-byte
+        // aligned activation rows and Cout % 8 == 0).  LDS: fp32 tile [BM][BN] (+16 B row pad), then mean | rstd per
+        // (sample of the tile, column).
+        constexpr int RS = BN * 4 + 16;
+        constexpr int CPR = BN / 8;                                        // 8-column chunks per tile row
+        const int lgHW = p.lgHoWo, HW = 1 << lgHW, nsamp = BM >> lgHW;
+        float* stat = reinterpret_cast<float*>(lds + BM * RS);             // [nsamp][BN][2]
+        static_assert(BM * RS + (BM / 4) * BN * 8 <= NSLOT * STAGE, "tile + statistics must fit the ring");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                      // every wave is done with the ring
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + 32 * i + crow(r, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    *reinterpret_cast<float*>(lds + row * RS + (wn0 + 32 * j + (lane & 31)) * 4) = acc[i][j][r] * sc[i][r] + bcol[j];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int s0 = m0 >> lgHW;                                         // first sample of the tile
+        const float inv_hw = 1.f / (float)HW;
+        for (int q = threadIdx.x; q < nsamp * BN; q += NCW * 64) {          // one (sample, column) per thread: column reads
+            const int s = q / BN, c = q % BN;                              // of consecutive lanes are consecutive words
+            const unsigned char* colp = lds + (s << lgHW) * RS + c * 4;
+            float sum = 0.f;
+            for (int r = 0; r < HW; ++r) sum += *reinterpret_cast<const float*>(colp + r * RS);
+            const float mu = sum * inv_hw;
+            float m2 = 0.f;
+            for (int r = 0; r < HW; ++r) { const float d = *reinterpret_cast<const float*>(colp + r * RS) - mu; m2 += d * d; }
+            const float rs = 1.0f / sqrtf(m2 * inv_hw + 1e-5f);
+            stat[q * 2] = mu; stat[q * 2 + 1] = rs;
+            const int n = s0 + s, cg = n0 + c;
+            if (n < p.N && cg < p.Cout) { p.in_mean[(size_t)n * p.Cout + cg] = mu; p.in_rstd[(size_t)n * p.Cout + cg] = rs; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        unsigned char* ab = static_cast<unsigned char*>(p.y);
+        unsigned char* pb = static_cast<unsigned char*>(p.in_apre);
+        for (int cix = threadIdx.x; cix < BM * CPR; cix += NCW * 64) {
+            const int row = cix / CPR, ch = cix % CPR, m = m0 + row, col0 = n0 + ch * 8;
+            if (m >= p.M || col0 >= p.Cout) continue;
+            const float4 v0 = *reinterpret_cast<const float4*>(lds + row * RS + ch * 32);
+            const float4 v1 = *reinterpret_cast<const float4*>(lds + row * RS + ch * 32 + 16);
+            const float4* st4p = reinterpret_cast<const float4*>(stat + ((row >> lgHW) * BN + ch * 8) * 2);
+            const float4 q0 = st4p[0], q1 = st4p[1], q2 = st4p[2], q3 = st4p[3];   // (mu, rs) x 8 columns
+            float o[8] = {lrelu_f((v0.x - q0.x) * q0.y), lrelu_f((v0.y - q0.z) * q0.w), lrelu_f((v0.z - q1.x) * q1.y),
+                          lrelu_f((v0.w - q1.z) * q1.w), lrelu_f((v1.x - q2.x) * q2.y), lrelu_f((v1.y - q2.z) * q2.w),
+                          lrelu_f((v1.z - q3.x) * q3.y), lrelu_f((v1.w - q3.z) * q3.w)};
+            if (pb) {
+                const int n = m >> lgHW;
+                if (n >= p.apre_n0) {
+                    uint4 w; w.x = pack2<T>(o[0], o[1]); w.y = pack2<T>(o[2], o[3]); w.z = pack2<T>(o[4], o[5]); w.w = pack2<T>(o[6], o[7]);
+                    *reinterpret_cast<uint4*>(pb + ((size_t)(m - (p.apre_n0 << lgHW)) * p.ld_apre + col0) * 2) = w;
+                }
+            }
+            if (p.in_mask) {
+                const uint2 mk = *reinterpret_cast<const uint2*>(p.in_mask + (size_t)m * p.Cout + col0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] *= ((mk.x >> (8 * e)) & 0xFF) ? 2.f : 0.f;
+                    o[4 + e] *= ((mk.y >> (8 * e)) & 0xFF) ? 2.f : 0.f;
+                }
+            }
+            uint4 w; w.x = pack2<T>(o[0], o[1]); w.y = pack2<T>(o[2], o[3]); w.z = pack2<T>(o[4], o[5]); w.w = pack2<T>(o[6], o[7]);
+            *reinterpret_cast<uint4*>(ab + ((size_t)m * p.ldy + col0) * 2) = w;
+        }
+        return;
+    }
     // ---- result tile through LDS (default): the MFMA C layout gives a lane one 4-byte element per row, i.e. 32 store
     // instructions of 2 x 128 bytes per wave for a 32 x 64 wave tile; after a transpose through the (now idle) ring every
     // store instruction writes 64 x 16 bytes of whole rows.  tools/tile_ab.sh with GCSSL_RING_DEBUG=3 (no DMA, no MFMA:
@@ -975,7 +1058,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
 // which needs a FIXED number of store instructions per tile: the epilogue is branch-free buffer stores whose
 // out-of-range lanes carry an out-of-bounds offset (dropped by the hardware, still counted).  No split-K here.
 // ------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int MODE, int WM, int WN, bool SMALLK = false>
+// FIN (forward conv, 8x8 output maps, 32 x 32 wave tiles): InstanceNorm + LeakyReLU in the epilogue, statistics IN REGISTERS --
+// the ring is busy with the next tile, so there is no LDS tile to stage through.  A 32-row C block lies inside one sample
+// (64 rows), a lane holds 16 rows of one column: two-pass mean / M2 over the block (16 registers + one xor-32 shuffle), Chan's
+// combination with the partner wave that holds the sample's other 32 rows (2 floats per column through 2 KB of LDS, one
+// barrier), then the 16 stores of the 16-bit activation + mean / rstd (two more store instructions for every wave, out-of-range
+// for the non-writers: the vmcnt bookkeeping needs a fixed count).
+template <typename T, int BM, int BN, int MODE, int WM, int WN, bool SMALLK = false, bool FIN = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvParams p, int tiles_m, int tiles_n, int total_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef typename Frag16<T>::type FragT;
@@ -984,10 +1073,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
     constexpr int NVA = BM / RPT, NVB = BN / RPT, NL = NVA + NVB;
     static_assert(NVA >= 1 && NVB >= 1, "tile too small for this many waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int NST = TM * TN * 16;                                    // epilogue store instructions per wave per tile
+    static_assert(!FIN || (TM == 1 && TN == 1 && MODE == 0 && WM % 2 == 0), "FIN: one 32 x 32 C block per wave, wave rows pair up");
+    constexpr int NST = TM * TN * 16 + (FIN ? 2 : 0);                    // epilogue store instructions per wave per tile
     static_assert(NL + NST <= 63, "vmcnt is a 6-bit counter");
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE + (FIN ? WM * WN * 32 * 8 : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
@@ -1156,6 +1246,41 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
                 if (p.gscale && m < p.M) sc[i][r] = p.gscale[(int)(((float)(m >> p.lgHoWo) + 0.5f) * p.inv_group_n)];
             }
         if (p.gscale || (MODE != 1 && p.bias)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // see note below
+        if constexpr (FIN) {
+            float v[16], sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { v[r] = acc[0][0][r] * sc[0][r] + bcol[0]; sum += v[r]; }
+            sum += __shfl_xor(sum, 32, 64);
+            const float mw = sum * (1.f / 32.f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = v[r] - mw; m2 += d * d; }
+            m2 += __shfl_xor(m2, 32, 64);
+            float* xs = reinterpret_cast<float*>(lds + 3 * STAGE);         // [wave][32 columns][mean, M2]
+            if (lane < 32) { xs[(wave * 32 + lane) * 2] = mw; xs[(wave * 32 + lane) * 2 + 1] = m2; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // (the next write to xs is a whole K loop of barriers away: no second barrier needed)
+            const float pm = xs[(((wave ^ WN) * 32) + (lane & 31)) * 2], pm2 = xs[(((wave ^ WN) * 32) + (lane & 31)) * 2 + 1];
+            const float mean = 0.5f * (mw + pm), dlt = mw - pm;
+            const float rstd = 1.0f / sqrtf((m2 + pm2 + dlt * dlt * 16.f) * (1.f / 64.f) + 1e-5f);
+            const int col = cur.n0 + wn0 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = cur.m0 + wm0 + crow(r, lane);
+                const bool ok = m < p.M && col < ncols;
+                const float o = lrelu_f((v[r] - mean) * rstd);
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)Bits16<T>::enc(o), yr,
+                                                      ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)col) * 2u : OOB, 0, 0);
+            }
+            const __amdgpu_buffer_rsrc_t mr = make_rsrc(p.in_mean, (unsigned)p.N * (unsigned)p.Cout * 4u),
+                                         rr = make_rsrc(p.in_rstd, (unsigned)p.N * (unsigned)p.Cout * 4u);
+            const int n = (cur.m0 + wm0) >> 6;
+            const bool wr = ((wave / WN) & 1) == 0 && lane < 32 && n < p.N && col < ncols;
+            const unsigned so = wr ? ((unsigned)n * (unsigned)p.Cout + (unsigned)col) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean), mr, so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd), rr, so, 0, 0);
+        } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1178,6 +1303,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
                     else __builtin_amdgcn_raw_buffer_store_b16((unsigned short)Bits16<T>::enc(v), yr, ok ? e * 2u : OOB, 0, 0);
                 }
             }
+        }
         if (!has_next) break;
         cur = nxt; tile = next_tile; first = false;
     }
@@ -2028,6 +2154,51 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
     }
     return launch_fwd<T, 64, 64>(p, st);
 }
+// ---- forward conv + InstanceNorm + LeakyReLU in one launch (the FIN instantiations of conv_dma_kernel).
+// Which form serves these shapes: 0 none (the caller keeps the conv -> fp32 z -> gcssl_in_act_fwd pair), 1 the loader /
+// consumer ring (128 x 128 tiles, one round of the chip), 2 128 x 64 tiles, 3 64 x 64 tiles.  No K split: the statistics need
+// the complete sums, so shapes that only fill the chip by splitting K (B-sample c4) stay on the unfused pair.
+int fin_form(const ConvParams& p) {
+    static const int on = [] { const char* e = getenv("GCSSL_FIN"); return e ? atoi(e) : 1; }();
+    static const long ring_min = [] { const char* e = getenv("GCSSL_FIN_RING_MIN"); return e ? atol(e) : 96L; }();
+    static const long min_wgs = [] { const char* e = getenv("GCSSL_FIN_WGS"); return e ? atol(e) : 192L; }();
+    const int HW = (p.Hi / 2) * (p.Wi / 2);
+    if (!on || !use_dma() || dma_waves() != 8 || HW > 64 || HW < 4 || p.Cin < 64 || p.Cout < 64) return 0;
+    const long tm128 = (p.M + 127) / 128;
+    const long t128 = tm128 * ((p.Cout + 127) / 128);
+    if ((on & 2) == 0 && p.Cout >= 128 && p.M >= 128 && t128 <= cu_count() && t128 >= ring_min) return 1;
+    // 8x8 maps with clearly more 128 x 64 tiles than resident workgroups: the persistent form (statistics in registers)
+    if ((on & 4) == 0 && HW == 64 && !p.in_mask && !p.in_apre && persist_mode() && tm128 * ((p.Cout + 63) / 64) > 2 * cu_count() + cu_count() / 2 &&
+        p.y_bytes) return 4;
+    if (p.M >= 128 && tm128 * ((p.Cout + 63) / 64) >= min_wgs) return 2;
+    if ((long)((p.M + 63) / 64) * ((p.Cout + 63) / 64) >= min_wgs) return 3;
+    return 0;
+}
+template <typename T>
+int dispatch_fwd_in(ConvParams p, hipStream_t st) {
+    if constexpr (Is16<T>::v) {
+        typedef typename Op16<T>::type O;
+        const int form = fin_form(p);
+        p.ksplit = 1;
+        if (form == 1) {
+            dim3 grid((p.M + 127) / 128, (p.Cout + 127) / 128, 1);
+            hipLaunchKernelGGL((conv_dma_kernel<O, 128, 128, 0, 4, 2, false, 8, 4, false, true>), grid, dim3(1024), 0, st, p);
+        } else if (form == 2) {
+            dim3 grid((p.M + 127) / 128, (p.Cout + 63) / 64, 1);
+            hipLaunchKernelGGL((conv_dma_kernel<O, 128, 64, 0, 4, 2, false, 0, 3, true, true>), grid, dim3(512), 0, st, p);
+        } else if (form == 3) {
+            dim3 grid((p.M + 63) / 64, (p.Cout + 63) / 64, 1);
+            hipLaunchKernelGGL((conv_dma_kernel<O, 64, 64, 0, 2, 2, false, 0, 3, true, true>), grid, dim3(256), 0, st, p);
+        } else if (form == 4) {
+            const int tm = (p.M + 127) / 128, tn = (p.Cout + 63) / 64;
+            hipLaunchKernelGGL((conv_dma_persist_kernel<O, 128, 64, 0, 4, 2, false, true>), dim3(2 * cu_count()), dim3(512), 0, st, p, tm, tn, tm * tn);
+        } else {
+            return GCSSL_EBADSHAPE;
+        }
+        return gcssl_launch_status();
+    }
+    return GCSSL_EBADDTYPE;
+}
 // ------------------------------------------------------------------------------------------
 // data gradient of the first layer (Cin padded to 8, Cout = 64: D.c1 in the gradient-penalty chain; 0.8 GFLOP whose result
 // is 8 channels wide), built like conv_fwd_c8_kernel: a workgroup owns R dy rows of one sample (R * Wo = 32), loads the
@@ -2241,6 +2412,46 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
     hipStream_t st = (hipStream_t)stream;
     if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     GCSSL_DISPATCH(dtype, return dispatch_fwd<T>(p, st));
+    return GCSSL_EBADDTYPE;
+}
+
+// 1 if gcssl_conv4x4s2_in_act_fwd serves these shapes (16-bit dtype, H*W/4 <= 64 output pixels per sample, enough tiles
+// without a K split), 0 if the caller should use the conv -> gcssl_in_act_fwd pair, < 0 on bad geometry
+int gcssl_conv4x4s2_in_act_ok(int dtype, int N, int Hi, int Wi, int Cin, int Cout) {
+    int rc = check_geom(N, Hi, Wi, Cin, Cout);
+    if (rc) return rc;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (dtype == GCSSL_F32) return 0;
+    ConvParams p{}; p.y_bytes = 1;
+    fill_geom(p, N, Hi, Wi, Cin, Cout);
+    return fin_form(p) ? 1 : 0;
+}
+
+int gcssl_conv4x4s2_in_act_fwd(int dtype, const void* x, int ldx, const void* wf, const float* bias, const float* gscale,
+                               int group_n, void* a, int lda, float* mean, float* rstd, const uint8_t* mask, void* apre,
+                               int ld_apre, int apre_n0, int N, int Hi, int Wi, int Cin, int Cout, int act, void* stream) {
+    if (!x || !wf || !a || !mean || !rstd) return GCSSL_ENULL;
+    int rc = check_geom(N, Hi, Wi, Cin, Cout);
+    if (rc) return rc;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (dtype == GCSSL_F32) return GCSSL_EBADDTYPE;                        // the fp32 parity mode keeps the fp32 z and the separate norm
+    if (act != 1) return GCSSL_EBADSHAPE;                                  // LeakyReLU(0.2) only: the backward inverts it
+    if (Cout < 64 || Cin < 64 || ldx < Cin || lda < Cout || (gscale && group_n <= 0)) return GCSSL_EBADSHAPE;
+    if (apre && (ld_apre < Cout || ld_apre % 8 || apre_n0 < 0 || apre_n0 > N)) return GCSSL_EBADSHAPE;
+    if (ldx % 8 || lda % 8 || !aligned16(x) || !aligned16(wf) || !aligned16(a) || (apre && !aligned16(apre)) ||
+        (mask && (((uintptr_t)mask) & 7))) return GCSSL_EALIGN;
+    ConvParams p{}; p.x = x; p.w = wf; p.y = a; p.bias = bias; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
+    p.ldx = ldx; p.ldy = lda; p.act = act;
+    p.in_mean = mean; p.in_rstd = rstd; p.in_mask = mask; p.in_apre = apre; p.ld_apre = ld_apre; p.apre_n0 = apre_n0;
+    p.sib_remap = sib_remap();
+    fill_geom(p, N, Hi, Wi, Cin, Cout);
+    if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)Cout * 16 * Cin, 2)) return GCSSL_EBADSHAPE;
+    {   // output extent for the buffer stores of the persistent form
+        const size_t yb = (((size_t)N * (Hi / 2) * (Wi / 2) - 1) * lda + Cout) * 2;
+        p.y_bytes = (yb < 0x7FFFFFFFull && (size_t)N * Cout * 4 < 0x7FFFFFFFull) ? (unsigned)yb : 0u;
+    }
+    if (!fin_form(p)) return GCSSL_EBADSHAPE;
+    GCSSL_DISPATCH(dtype, return dispatch_fwd_in<T>(p, (hipStream_t)stream));
     return GCSSL_EBADDTYPE;
 }
 

@@ -381,7 +381,7 @@ struct InBwdParams {
     const float* da; int ldda;         // incoming gradient of the activation output, fp32 (nullable if da_bcast)
     const float* da2; int ldda2;       // optional second gradient added to da (skip connection), fp32
     const float* da_bcast;             // optional [N][C] gradient broadcast over H*W (global-avg-pool backward)
-    const float* z; int ldz;           // pre-norm conv output, always fp32
+    const void* z; int ldz;            // pre-norm conv output, fp32 -- or (AZ kernels) the 16-bit LeakyReLU activation it became
     const float* mean; const float* rstd;
     const uint8_t* mask;               // dropout keep mask [N][HW][C], nullable
     const float* zt; int zt_n0;        // optional fp32 double-backward term added to dz of samples n >= zt_n0 ([N-zt_n0][HW][C])
@@ -405,7 +405,9 @@ struct InBwdParams {
 // With per-row `if (p >= HW) continue` / `if (da2p) ...` tests hipcc emitted one exec-mask branch and one vmcnt drain per
 // load -- 4 rows x up to 5 operands of serial round trips at one wave per SIMD (256 VGPRs): D.c2's backward over 768
 // samples took 52 us for 71 MB (1.4 TB/s).  The host refuses tensors of 2 GiB or more (32-bit byte offsets).
-template <typename T, int RG, int MR = MAXR, bool SLAB = false>
+// AZ: q.z is not the fp32 pre-norm tensor but the 16-bit ACTIVATION lrelu(xhat) that gcssl_conv4x4s2_in_act_fwd stored (the
+// fp32 z never went to memory): xhat = a > 0 ? a : 5 a, and z - bias = xhat / rstd + mean - bias for the spectral-norm dot.
+template <typename T, int RG, int MR = MAXR, bool SLAB = false, bool AZ = false>
 __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, int N, int spb, int mixed_groups) {
     __shared__ float sm[2][RGN][CW];
     __shared__ float red[CGN * RGN / 64];
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
     const int c = blockIdx.x * CW + tx * VC;
     const int HW = q.HW, C = q.C;
     const size_t nhw = (size_t)N * HW;
-    const __amdgpu_buffer_rsrc_t zr = make_rsrc(q.z, rsrc_bytes(nhw * q.ldz * 4)),
+    const __amdgpu_buffer_rsrc_t zr = make_rsrc(q.z, rsrc_bytes(nhw * q.ldz * (AZ ? sizeof(T) : 4))),
                                  dar = make_rsrc(q.da, q.da ? rsrc_bytes(nhw * q.ldda * 4) : 0u),
                                  da2r = make_rsrc(q.da2, q.da2 ? rsrc_bytes(nhw * q.ldda2 * 4) : 0u),
                                  mkr = make_rsrc(q.mask, q.mask ? rsrc_bytes(nhw * C) : 0u),
@@ -439,9 +441,18 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
         unsigned pix[MR];                                            // pixel index of row i, or OOB
 #pragma unroll
         for (int i = 0; i < MR; ++i) { const int p = rg + RG * i; pix[i] = (live && p < HW) ? (unsigned)(n * HW + p) : OOB; }
-        float zv[MR][VC], dn[MR][VC];
+        float zv[MR][VC], dn[MR][VC];                                // zv: z (fp32 source) or xhat (AZ)
+        if constexpr (AZ) {
 #pragma unroll
-        for (int i = 0; i < MR; ++i) bld4(zr, pix[i] != OOB ? (pix[i] * q.ldz + c) * 4u : OOB, zv[i]);
+            for (int i = 0; i < MR; ++i) {
+                const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(zr, pix[i] != OOB ? (pix[i] * q.ldz + c) * (unsigned)sizeof(T) : OOB, 0, 0);
+                zv[i][0] = Bits16<T>::dec(w[0]); zv[i][1] = Bits16<T>::dec(w[0] >> 16);
+                zv[i][2] = Bits16<T>::dec(w[1]); zv[i][3] = Bits16<T>::dec(w[1] >> 16);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MR; ++i) bld4(zr, pix[i] != OOB ? (pix[i] * q.ldz + c) * 4u : OOB, zv[i]);
+        }
 #pragma unroll
         for (int i = 0; i < MR; ++i) bld4(dar, pix[i] != OOB ? (pix[i] * q.ldda + c) * 4u : OOB, dn[i]);
         if (q.da2) {
@@ -472,7 +483,8 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
         for (int i = 0; i < MR; ++i)
 #pragma unroll
             for (int j = 0; j < VC; ++j) {
-                const float xh = (zv[i][j] - mu[j]) * r[j];
+                if constexpr (AZ) zv[i][j] = zv[i][j] > 0.f ? zv[i][j] : 5.0f * zv[i][j];   // invert LeakyReLU(0.2): xhat
+                const float xh = AZ ? zv[i][j] : (zv[i][j] - mu[j]) * r[j];
                 dn[i][j] = dn[i][j] * act_grad(xh, q.act);           // (dead rows: dn = 0)
                 s[0][j] += dn[i][j]; s[1][j] += dn[i][j] * xh;
             }
@@ -490,18 +502,21 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
 #pragma unroll
                 for (int j = 0; j < VC; ++j) zt[i][j] = 0.f;
         }
-        float m1[VC], m2[VC];
+        float m1[VC], m2[VC], sdev[VC], mb[VC];
 #pragma unroll
-        for (int j = 0; j < VC; ++j) { m1[j] = s[0][j] / HW; m2[j] = s[1][j] / HW; }
+        for (int j = 0; j < VC; ++j) {
+            m1[j] = s[0][j] / HW; m2[j] = s[1][j] / HW;
+            sdev[j] = (AZ && live) ? 1.0f / r[j] : 0.f; mb[j] = mu[j] - b[j];      // AZ: z - bias = xhat * sdev + (mean - bias)
+        }
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
             float o[VC];
 #pragma unroll
             for (int j = 0; j < VC; ++j) {
-                const float xh = (zv[i][j] - mu[j]) * r[j];
+                const float xh = AZ ? zv[i][j] : (zv[i][j] - mu[j]) * r[j];
                 float dz = r[j] * (dn[i][j] - m1[j] - xh * m2[j]) + zt[i][j];
                 dz = pix[i] != OOB ? dz : 0.f;                       // dead rows add nothing to the bias / SN sums
-                sb[0][j] += dz; sd += dz * gs * (zv[i][j] - b[j]);
+                sb[0][j] += dz; sd += dz * gs * (AZ ? xh * sdev[j] + mb[j] : zv[i][j] - b[j]);
                 o[j] = dz * gs;
             }
             bst4<T>(outr, pix[i] != OOB ? (pix[i] * q.lddz + c) * (unsigned)sizeof(T) : OOB, o);
@@ -534,7 +549,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_kernel(InBwdParams q, float*
     const int tx = threadIdx.x % CGN, ty = threadIdx.x / CGN;
     const int c = blockIdx.x * CW + tx * VC, n = blockIdx.y;
     const int HW = q.HW, C = q.C;
-    const float* zp = q.z + (size_t)n * HW * q.ldz + c;
+    const float* zp = static_cast<const float*>(q.z) + (size_t)n * HW * q.ldz + c;
     const float* dap = q.da ? q.da + (size_t)n * HW * q.ldda + c : nullptr;
     const float* da2p = q.da2 ? q.da2 + (size_t)n * HW * q.ldda2 + c : nullptr;
     const uint8_t* mp = q.mask ? q.mask + (size_t)n * HW * C + c : nullptr;
@@ -635,7 +650,7 @@ struct InDblParams {
     const float* gb_a; int ldgb;       // first-order chain gradient wrt activation output (dn = act' * gb_a), fp32
     const float* qz; int ldq;          // adjoint of the first-order dz (gt_z), fp32
     const void* gb_zs; int ldgz;       // first-order dz * isig (for the spectral-norm dot), nullable
-    const float* z; int ldz;           // always fp32
+    const void* z; int ldz;            // fp32 pre-norm tensor -- or (AZ kernel) the 16-bit LeakyReLU activation
     const float* mean; const float* rstd;
     void* gt_a; int ldga;              // out: act'(xhat) * rstd * (q - mean(q) - xhat mean(q xhat))
     float* zt;                         // out: adjoint wrt z, dense fp32 [N][HW][C]
@@ -652,7 +667,7 @@ __global__ __launch_bounds__(CW * RG) void in_dbl_bwd_kernel(InDblParams q) {
     const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
     const int c = blockIdx.x * CW + tx, n = blockIdx.y;
     const int HW = q.HW, C = q.C;
-    const float* zp = q.z + (size_t)n * HW * q.ldz + c;
+    const float* zp = static_cast<const float*>(q.z) + (size_t)n * HW * q.ldz + c;
     const float* gp = q.gb_a + (size_t)n * HW * q.ldgb + c;
     const float* qp = q.qz + (size_t)n * HW * q.ldq + c;
     const T* gzp = q.gb_zs ? static_cast<const T*>(q.gb_zs) + (size_t)n * HW * q.ldgz + c : nullptr;
@@ -687,7 +702,7 @@ __global__ __launch_bounds__(CW * RG) void in_dbl_bwd_kernel(InDblParams q) {
 }
 
 // small maps, vectorised double backward (same math as in_dbl_bwd_kernel)
-template <typename T, int RG, bool SLAB = false>
+template <typename T, int RG, bool SLAB = false, bool AZ = false>
 __global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, int N, int spb) {
     // (branch-free buffer row accesses, as in in_bwd_small_kernel)
     __shared__ float sm[5][RGN][CW];
@@ -698,7 +713,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, 
     const int c = blockIdx.x * CW + tx * VC;
     const int HW = q.HW, C = q.C;
     const size_t nhw = (size_t)N * HW;
-    const __amdgpu_buffer_rsrc_t zr = make_rsrc(q.z, rsrc_bytes(nhw * q.ldz * 4)), gr = make_rsrc(q.gb_a, rsrc_bytes(nhw * q.ldgb * 4)),
+    const __amdgpu_buffer_rsrc_t zr = make_rsrc(q.z, rsrc_bytes(nhw * q.ldz * (AZ ? sizeof(T) : 4))), gr = make_rsrc(q.gb_a, rsrc_bytes(nhw * q.ldgb * 4)),
                                  qr = make_rsrc(q.qz, rsrc_bytes(nhw * q.ldq * 4)),
                                  gzr = make_rsrc(q.gb_zs, q.gb_zs ? rsrc_bytes(nhw * q.ldgz * sizeof(T)) : 0u),
                                  gar = make_rsrc(q.gt_a, rsrc_bytes(nhw * q.ldga * sizeof(T))), ztr = make_rsrc(q.zt, rsrc_bytes(nhw * C * 4));
@@ -715,8 +730,17 @@ __global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, 
 #pragma unroll
         for (int i = 0; i < MR; ++i) { const int p = rg + RG * i; pix[i] = (live && p < HW) ? (unsigned)(n * HW + p) : OOB; }
         float xh[MR][VC], dn[MR][VC], qq[MR][VC];
+        if constexpr (AZ) {                                           // the 16-bit activation instead of the fp32 z (see in_bwd_small_kernel)
 #pragma unroll
-        for (int i = 0; i < MR; ++i) bld4(zr, pix[i] != OOB ? (pix[i] * q.ldz + c) * 4u : OOB, xh[i]);
+            for (int i = 0; i < MR; ++i) {
+                const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(zr, pix[i] != OOB ? (pix[i] * q.ldz + c) * (unsigned)sizeof(T) : OOB, 0, 0);
+                xh[i][0] = Bits16<T>::dec(w[0]); xh[i][1] = Bits16<T>::dec(w[0] >> 16);
+                xh[i][2] = Bits16<T>::dec(w[1]); xh[i][3] = Bits16<T>::dec(w[1] >> 16);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MR; ++i) bld4(zr, pix[i] != OOB ? (pix[i] * q.ldz + c) * 4u : OOB, xh[i]);
+        }
 #pragma unroll
         for (int i = 0; i < MR; ++i) bld4(gr, pix[i] != OOB ? (pix[i] * q.ldgb + c) * 4u : OOB, dn[i]);
 #pragma unroll
@@ -747,7 +771,8 @@ __global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, 
         for (int i = 0; i < MR; ++i)
 #pragma unroll
             for (int j = 0; j < VC; ++j) {
-                xh[i][j] = pix[i] != OOB ? (xh[i][j] - mu[j]) * r[j] : 0.f;
+                if constexpr (AZ) xh[i][j] = xh[i][j] > 0.f ? xh[i][j] : 5.0f * xh[i][j];       // (dead rows read 0)
+                else xh[i][j] = pix[i] != OOB ? (xh[i][j] - mu[j]) * r[j] : 0.f;
                 dn[i][j] = act_grad(xh[i][j], q.act) * dn[i][j];              // (dead rows: gb_a = q = 0)
                 s[0][j] += dn[i][j]; s[1][j] += dn[i][j] * xh[i][j]; s[2][j] += qq[i][j];
                 s[3][j] += qq[i][j] * xh[i][j]; s[4][j] += qq[i][j] * dn[i][j];
@@ -958,7 +983,7 @@ int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean
 }
 
 int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const float* da_bcast,
-                     const float* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask,
+                     const void* z, int ldz, int z_kind, const float* mean, const float* rstd, const uint8_t* mask,
                      const float* zt, int zt_n0, const float* gscale, int group_n, const float* bias,
                      void* dzs, int lddz, float* dbias, float* cdot, int nrep, int rep_stride, int da_nslab, long da_slab_stride,
                      float* ws, const float* presum_cnt, const float* presum_pos, float presum_pos_scale, int N, int HW, int C,
@@ -970,6 +995,8 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
     if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lddz < C || ldz % 4 || lddz % 4 || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
     if ((da && ldda % 4) || (da2 && ldda2 % 4)) return GCSSL_EBADSHAPE;
     if ((gscale || cdot) && group_n <= 0) return GCSSL_EBADSHAPE;
+    if (z_kind != 0 && z_kind != 1) return GCSSL_EBADSHAPE;
+    if (z_kind == 1 && (dtype == GCSSL_F32 || HW > MID_HW || act != 1 || (((uintptr_t)z) & 7))) return GCSSL_EBADSHAPE;   // the activation form: 16-bit, small maps, LeakyReLU
     if (HW > MID_HW && !ws && !(presum_cnt && presum_pos)) return GCSSL_ENULL;
     InBwdParams q{da, ldda, da2, ldda2, da_bcast, z, ldz, mean, rstd, mask, zt, zt_n0, gscale,
                   group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, nrep, rep_stride, da_nslab, da_slab_stride, HW, C, act};
@@ -979,7 +1006,10 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, cdot ? q.group_n : 0);
         const int mixed = (cdot && q.group_n % spb) ? 1 : 0;
         dim3 grid(C / CW, (N + spb - 1) / spb);
-#define BWD_SMALL(T, RG, MR) do { if (da_nslab > 1) hipLaunchKernelGGL((in_bwd_small_kernel<T, RG, MR, true>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed); \
+#define BWD_SMALL(T, RG, MR) do { if (z_kind == 1) { if constexpr (sizeof(T) == 2) { \
+                                      if (da_nslab > 1) hipLaunchKernelGGL((in_bwd_small_kernel<T, RG, MR, true, true>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed); \
+                                      else hipLaunchKernelGGL((in_bwd_small_kernel<T, RG, MR, false, true>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed); } } \
+                                  else if (da_nslab > 1) hipLaunchKernelGGL((in_bwd_small_kernel<T, RG, MR, true>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed); \
                                   else hipLaunchKernelGGL((in_bwd_small_kernel<T, RG, MR, false>), grid, dim3(CGN * RGN), 0, st, q, N, spb, mixed); } while (0)
         GCSSL_DISPATCH(dtype,
             if (rg == 1) BWD_SMALL(T, 1, MAXR); else if (rg == 4) BWD_SMALL(T, 4, MAXR);
@@ -1002,7 +1032,7 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
 }
 
 int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, int ldq, const void* gb_zs, int ldgz,
-                     const float* z, int ldz, const float* mean, const float* rstd, void* gt_a, int ldga,
+                     const void* z, int ldz, int z_kind, const float* mean, const float* rstd, void* gt_a, int ldga,
                      float* zt, float* cdot, int q_nslab, long q_slab_stride, int N, int HW, int C, int act, void* stream) {
     if (!gb_a || !qz || !z || !mean || !rstd || !gt_a || !zt) return GCSSL_ENULL;
     if (q_nslab < 1 || (q_nslab > 1 && (q_slab_stride <= 0 || q_slab_stride % 4 || HW > SMALL_HW))) return GCSSL_EBADSHAPE;
@@ -1011,12 +1041,17 @@ int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, in
     InDblParams q{gb_a, ldgb, qz, ldq, gb_zs, ldgz, z, ldz, mean, rstd, gt_a, ldga, zt, cdot, HW, C, act, q_nslab, q_slab_stride};
     const bool small = HW <= SMALL_HW && !(ldgb % 4) && !(ldq % 4) && !(ldz % 4) && !(ldga % 4) && (!gb_zs || !(ldgz % 4));
     if (q_nslab > 1 && !small) return GCSSL_EBADSHAPE;      // slabs are summed by the fused small-map kernel only
+    if (z_kind != 0 && z_kind != 1) return GCSSL_EBADSHAPE;
+    if (z_kind == 1 && (!small || dtype == GCSSL_F32 || act != 1 || (((uintptr_t)z) & 7))) return GCSSL_EBADSHAPE;
     if (small) {
         if (!fits_buffer(N, HW, std::max(std::max(ldz, ldgb), std::max(std::max(ldq, ldga), std::max(ldgz, C))))) return GCSSL_EBADSHAPE;
         const int rg = small_rg(HW), spb = small_spb(N, C, rg, 0);
         dim3 sgrid(C / CW, (N + spb - 1) / spb);
         hipStream_t st = (hipStream_t)stream;
-#define DBL_SMALL(T, RG) do { if (q_nslab > 1) hipLaunchKernelGGL((in_dbl_small_kernel<T, RG, true>), sgrid, dim3(CGN * RGN), 0, st, q, N, spb); \
+#define DBL_SMALL(T, RG) do { if (z_kind == 1) { if constexpr (sizeof(T) == 2) { \
+                                  if (q_nslab > 1) hipLaunchKernelGGL((in_dbl_small_kernel<T, RG, true, true>), sgrid, dim3(CGN * RGN), 0, st, q, N, spb); \
+                                  else hipLaunchKernelGGL((in_dbl_small_kernel<T, RG, false, true>), sgrid, dim3(CGN * RGN), 0, st, q, N, spb); } } \
+                              else if (q_nslab > 1) hipLaunchKernelGGL((in_dbl_small_kernel<T, RG, true>), sgrid, dim3(CGN * RGN), 0, st, q, N, spb); \
                               else hipLaunchKernelGGL((in_dbl_small_kernel<T, RG, false>), sgrid, dim3(CGN * RGN), 0, st, q, N, spb); } while (0)
         GCSSL_DISPATCH(dtype, if (rg == 1) DBL_SMALL(T, 1); else if (rg == 4) DBL_SMALL(T, 4); else DBL_SMALL(T, 16));
 #undef DBL_SMALL

@@ -176,6 +176,10 @@ class StepEngine:
         # the generator's up3 / up4 layers as ONE pixel-stationary launch each (transposed conv + InstanceNorm + ReLU + pool
         # sums: csrc/convt_fused.hip) where the shapes allow; bit 0 = up4, bit 1 = up3 (GCSSL_FUSED_UP=0: the unfused pair)
         self.fused_up = int(os.environ.get("GCSSL_FUSED_UP", "3"))
+        # conv + InstanceNorm + LeakyReLU as ONE launch for the layers whose samples fit a GEMM tile whole (D.c2-c4, G.down2-4
+        # at 32x32; csrc/igemm.hip FIN forms): the fp32 pre-norm tensor is never stored, the backward kernels rebuild xhat from
+        # the 16-bit activation.  16-bit modes only; GCSSL_FIN=0 (read by the library too) restores the conv -> norm pairs.
+        self._fin_cache = {}
         self._alloc()
         self.gen = SimpleGenerator(self) if generator_type == "simple" else None
         self._d_dirty = True
@@ -281,6 +285,13 @@ class StepEngine:
             self._splits[key] = (ks, per) if ok else (1, 0)
         return self._splits[key]
 
+    def _fin(self, n: int, hi: int, cin: int, cout: int) -> bool:
+        """does the fused conv + InstanceNorm + LeakyReLU launch serve a forward of these shapes?"""
+        key = (n, hi, cin, cout)
+        if key not in self._fin_cache:
+            self._fin_cache[key] = self.code != _lib.F32 and ops.conv_in_act_ok(self.code, n, hi, cin, cout)
+        return self._fin_cache[key]
+
     # ------------------------------------------------------------------------------------------ buffers
     def _alloc(self):
         B, S, T, dev = self.B, self.S, self.T, self.dev
@@ -320,6 +331,7 @@ class StepEngine:
         # pre-InstanceNorm tensors are fp32 in both modes (z - mean(z) over 4..64 elements cancels a bf16 mantissa)
         # (each holds the K-split slabs of its producing conv when that conv splits: _zbuf)
         self.d_z = [None] + [self._zbuf("fwd", (N3, B), S >> l, D_CH[l][0], D_CH[l][1], N3) for l in (1, 2, 3)]
+        self._d_zsrc = list(self.d_z)          # what the norm backward kernels read per layer: d_z (fp32) or, after a fused forward, d_a
         self.d_mean = [None] + [torch.empty(N3, c, **f32) for _, c in D_CH[1:]]
         self.d_rstd = [None] + [torch.empty(N3, c, **f32) for _, c in D_CH[1:]]
         self.h5 = sizes[3] - 1
@@ -409,6 +421,8 @@ class StepEngine:
         self.g_umean, self.g_urstd, self.g_masks = gf.umean, gf.urstd, gf.masks
         self.g_pooled, self.g_poolsum, self.g_ucnt = gf.pooled, gf.poolsum, gf.ucnt
         self._up4_presums = False                                  # set by a fused up4 forward: cnt / pooled describe g_zu[3]
+        self.g_apre4 = act(B, S // 16, 512)                        # fused down4: its activation WITHOUT dropout, backward samples only
+        self._g_zsrc = list(self.g_zd)                             # per down layer: g_zd (fp32 z) or the 16-bit activation of a fused forward
         self.g_dab = torch.empty(B, 64, **f32)
         # generator backward
         self.g_dzu = [act(B, S // 8, 256), act(B, S // 4, 128), act(B, S // 2, 64), act(B, S, 64)]
@@ -488,12 +502,19 @@ class StepEngine:
             if l == 0:
                 self._conv(f"D.c1.fwd[n={n}]", fl, ops.conv_fwd, x, self.d_wf[0], self.d_a[0][:n], 8, cout, bias=bias,
                            gscale=gscale_of_layer(0), group_n=group_n, act=LRELU)
+            elif self._fin(n, self.S >> l, cin, cout):
+                # conv + InstanceNorm + LeakyReLU in one launch; the backward reads the activation instead of z
+                self._conv(f"D.c{l + 1}.fwd[n={n}]", fl, ops.conv_in_act_fwd, self.d_a[l - 1][:n], self.d_wf[l],
+                           self.d_a[l][:n], self.d_mean[l][:n], self.d_rstd[l][:n], cin, cout, bias=bias,
+                           gscale=gscale_of_layer(l), group_n=group_n)
+                self._d_zsrc[l] = self.d_a[l]
             else:
                 ns, st = self._split("fwd", self.d_z[l], n, self.S >> l, cin, cout)
                 self._conv(f"D.c{l + 1}.fwd[n={n}]", fl, ops.conv_fwd, self.d_a[l - 1][:n], self.d_wf[l],
                            self.d_z[l][:n], cin, cout, bias=bias, gscale=gscale_of_layer(l), group_n=group_n, split_stride=st)
                 ops.in_act_fwd(self.d_z[l][:n], self.d_a[l][:n], self.d_mean[l][:n], self.d_rstd[l][:n], cout, LRELU,
                                nslab=ns, slab_stride=st)
+                self._d_zsrc[l] = self.d_z[l]
         ops.c5_fwd(self.d_a[3][:n], self.d_w5p, self.d_out[:n])
 
     def critic_scores(self, pred: torch.Tensor, other: torch.Tensor, train: bool = True) -> torch.Tensor:
@@ -537,8 +558,22 @@ class StepEngine:
         mk = f.masks if train else [None, None, None]
         self._conv(f"G.down1.fwd{tag}", conv_flops(n, S, 3, 64), ops.conv_fwd, x8, self.gd_wf[0], d1, 8, 64, act=LRELU)
         dins, douts, dmask = [None, d1, d2, d3], [None, d2, d3, f.d4], [None, None, None, mk[0]]
+        bwd_here = f.n == self.B or f is self.gfa                 # does this pass hold the generator step's group (its last B samples)?
         for k in (1, 2, 3):
             cin, cout = G_DOWN[k]
+            if self._fin(n, S >> k, cin, cout):
+                # conv + InstanceNorm + LeakyReLU (+ dropout) in one launch.  down4's output is masked, so the samples that have
+                # a backward pass (the last B of this batch) also store the un-masked activation for it.
+                apre = self.g_apre4 if (k == 3 and dmask[k] is not None and bwd_here) else None
+                self._conv(f"G.down{k + 1}.fwd{tag}", conv_flops(n, S >> k, cin, cout), ops.conv_in_act_fwd, dins[k],
+                           self.gd_wf[k], douts[k], f.dmean[k], f.drstd[k], cin, cout, mask=dmask[k], apre=apre,
+                           apre_n0=n - self.B)
+                if bwd_here:
+                    grp = douts[k][n - self.B:]
+                    self._g_zsrc[k] = self.g_apre4 if apre is not None else grp
+                continue
+            if bwd_here:
+                self._g_zsrc[k] = self.g_zd[k]
             ns, st = self._split("fwd", f.zd[k], n, S >> k, cin, cout)
             self._conv(f"G.down{k + 1}.fwd{tag}", conv_flops(n, S >> k, cin, cout), ops.conv_fwd, dins[k], self.gd_wf[k],
                        f.zd[k], cin, cout, split_stride=st)
@@ -713,7 +748,7 @@ class StepEngine:
         ns, st = 1, 0                                             # K-split slabs of the conv that produced gb_a[l]
         for l in (3, 2, 1):
             cin, cout = D_CH[l]
-            ops.in_act_bwd(self.d_z[l][I], self.d_mean[l][I], self.d_rstd[l][I], self.gb_zs[l], cout, LRELU,
+            ops.in_act_bwd(self._d_zsrc[l][I], self.d_mean[l][I], self.d_rstd[l][I], self.gb_zs[l], cout, LRELU,
                            da=self.gb_a[l], gscale=isig[l, 2:3], group_n=B, ws=self.ws, da_nslab=ns, da_slab_stride=st)
             ns, st = self._split("dgrad", self.gb_a[l - 1], B, S >> l, cin, cout, grad=True) if l > 1 else (1, 0)
             self._conv(f"D.c{l + 1}.gp_dgrad", conv_flops(B, S >> l, cin, cout), ops.conv_dgrad, self.gb_zs[l],
@@ -735,7 +770,7 @@ class StepEngine:
                 ops.dot_accum(self.gb_zs[0], self.gt_z[0], 64, self.cdot[0, 2:3])
                 ops.act_bwd(self.gt_z[0], self.d_a[0][I], self.gt_a[0], 64)
             else:
-                ops.in_dbl_bwd(self.gb_a[l], self.gt_z[l], self.gb_zs[l], self.d_z[l][I], self.d_mean[l][I],
+                ops.in_dbl_bwd(self.gb_a[l], self.gt_z[l], self.gb_zs[l], self._d_zsrc[l][I], self.d_mean[l][I],
                                self.d_rstd[l][I], self.gt_a[l], self.zt[l], cout, LRELU, cdot=self.cdot[l, 2:3],
                                q_nslab=ns, q_slab_stride=st)
             src = self.gt_a[l]
@@ -755,7 +790,7 @@ class StepEngine:
             rb = self.rep[0, self.rep_bias_off[l]:self.rep_bias_off[l] + cout]          # replica 0 of this layer's bias sums
             rc = self.rep[0, 960 + 3 * l:963 + 3 * l]                                    # ... and of its three cdot entries
             if l > 0:
-                ops.in_act_bwd(self.d_z[l], self.d_mean[l], self.d_rstd[l], self.d_dzs[l], cout, LRELU,
+                ops.in_act_bwd(self._d_zsrc[l][:N3], self.d_mean[l], self.d_rstd[l], self.d_dzs[l], cout, LRELU,
                                da=self.d_da[l], zt=self.zt[l], zt_n0=2 * B, gscale=isig[l], group_n=B, bias=bias,
                                dbias=rb, cdot=rc, ws=self.ws, nrep=self.NREP, rep_stride=self.REP_STRIDE)
             else:
@@ -886,10 +921,10 @@ class StepEngine:
             cin, cout = G_DOWN[k]
             cp = _pad8(cin)
             if k == 3:
-                ops.in_act_bwd(self.g_zd[3], self.g_dmean[3], self.g_drstd[3], self.g_dzd[3], 512, LRELU,
+                ops.in_act_bwd(self._g_zsrc[3], self.g_dmean[3], self.g_drstd[3], self.g_dzd[3], 512, LRELU,
                                da=self.g_dd4, mask=self.g_masks[0], ws=self.ws, da_nslab=ns4, da_slab_stride=st4)
             elif k > 0:
-                ops.in_act_bwd(self.g_zd[k], self.g_dmean[k], self.g_drstd[k], self.g_dzd[k], cout, LRELU,
+                ops.in_act_bwd(self._g_zsrc[k], self.g_dmean[k], self.g_drstd[k], self.g_dzd[k], cout, LRELU,
                                da=self.g_dd[k + 1], da2=dskip[k], ws=self.ws, da_nslab=nsd, da_slab_stride=std)
             else:
                 ops.act_bwd(self.g_dd[1], d_act[0], self.g_dzd[0], 64, da2=dskip[0])

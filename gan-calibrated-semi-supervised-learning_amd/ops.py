@@ -87,6 +87,22 @@ def conv_splits(kind, dt, N, Hi, cin, cout, act=0, out_f32=1) -> int:
     return r
 
 
+def conv_in_act_ok(dt, N, Hi, cin, cout) -> bool:
+    """Does the one-launch conv + InstanceNorm + LeakyReLU form serve these shapes (gcssl_conv4x4s2_in_act_ok)?"""
+    r = _lib.call_nostream("gcssl_conv4x4s2_in_act_ok", dt, N, Hi, Hi, cin, cout)
+    if r < 0:
+        raise RuntimeError(f"conv_in_act_ok{(N, Hi, cin, cout)} -> {r}")
+    return bool(r)
+
+
+def conv_in_act_fwd(x, wf, a, mean, rstd, cin, cout, bias=None, gscale=None, group_n=0, mask=None, apre=None, apre_n0=0):
+    """Conv2d(k4,s2,p1) + InstanceNorm + LeakyReLU(0.2) [+ dropout mask] in one launch: a (16-bit, may be a channel slice)
+    and the fp32 statistics; apre: the un-masked activation of samples >= apre_n0 (for the backward of a masked layer)."""
+    N, Hi, Wi, _ = x.shape
+    call("gcssl_conv4x4s2_in_act_fwd", code(x), x, _ld(x), wf, bias, gscale, group_n, a, _ld(a), mean, rstd, mask, apre,
+         _ld(apre) if apre is not None else 0, int(apre_n0), N, Hi, Wi, cin, cout, LRELU)
+
+
 def conv_dgrad(dy, wt, dx, cin, cout, gscale=None, group_n=0, split_stride=0):
     """dx: [N][Hi][Wi][>=cin] (fp32 output allowed whatever dy's dtype), dy: [N][Hi/2][Wi/2][>=cout]."""
     N, Hi, Wi, _ = dx.shape
@@ -201,20 +217,25 @@ def in_act_fwd(z, a, mean, rstd, C, act, mask=None, pool=None, nslab=1, slab_str
 def in_act_bwd(z, mean, rstd, dzs, C, act, da=None, da2=None, da_bcast=None, mask=None, zt=None, zt_n0=0,
                gscale=None, group_n=0, bias=None, dbias=None, cdot=None, ws=None, nrep=1, rep_stride=0, da_nslab=1,
                da_slab_stride=0, presum_cnt=None, presum_pos=None, presum_pos_scale=1.0):
-    """da_nslab > 1: da is the first of that many split-K slabs (da_slab_stride floats apart), added on load.  nrep > 1: dbias / cdot point at replica 0 of nrep replicas rep_stride floats apart (fold with ReplicaSum)."""
+    """da_nslab > 1: da is the first of that many split-K slabs (da_slab_stride floats apart), added on load.  nrep > 1: dbias / cdot point at replica 0 of nrep replicas rep_stride floats apart (fold with ReplicaSum).
+    z: the fp32 pre-norm tensor, or the 16-bit un-masked activation a fused conv_in_act_fwd left (z_kind 1)."""
     N, H, W, _ = z.shape
-    assert z.dtype == torch.float32 and all(t is None or t.dtype == torch.float32 for t in (da, da2, zt))
+    assert all(t is None or t.dtype == torch.float32 for t in (da, da2, zt))
+    z_kind = 0 if z.dtype == torch.float32 else 1
+    assert z_kind == 0 or z.dtype == dzs.dtype
     call("gcssl_in_act_bwd", code(dzs), da, _ld(da) if da is not None else 0, da2, _ld(da2) if da2 is not None else 0,
-         da_bcast, z, _ld(z), mean, rstd, mask, zt, zt_n0, gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot, nrep, rep_stride,
+         da_bcast, z, _ld(z), z_kind, mean, rstd, mask, zt, zt_n0, gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot, nrep, rep_stride,
          da_nslab, int(da_slab_stride), ws, presum_cnt, presum_pos, float(presum_pos_scale), N, H * W, C, act)
 
 
 def in_dbl_bwd(gb_a, qz, gb_zs, z, mean, rstd, gt_a, zt, C, act, cdot=None, q_nslab=1, q_slab_stride=0):
     N, H, W, _ = z.shape
-    assert z.dtype == torch.float32 and gb_a.dtype == torch.float32 and qz.dtype == torch.float32
+    assert gb_a.dtype == torch.float32 and qz.dtype == torch.float32
     assert zt.dtype == torch.float32
+    z_kind = 0 if z.dtype == torch.float32 else 1                  # 1: the 16-bit activation of a fused conv_in_act_fwd
+    assert z_kind == 0 or z.dtype == gt_a.dtype
     call("gcssl_in_dbl_bwd", code(gt_a), gb_a, _ld(gb_a), qz, _ld(qz), gb_zs, _ld(gb_zs) if gb_zs is not None else 0,
-         z, _ld(z), mean, rstd, gt_a, _ld(gt_a), zt, cdot, q_nslab, int(q_slab_stride), N, H * W, C, act)
+         z, _ld(z), z_kind, mean, rstd, gt_a, _ld(gt_a), zt, cdot, q_nslab, int(q_slab_stride), N, H * W, C, act)
 
 
 def act_bwd(da, a, dzs, C, da2=None, gscale=None, group_n=0, bias=None, dbias=None, cdot=None, nrep=1, rep_stride=0):

@@ -77,6 +77,18 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
  * fp32 slabs y + k*split_stride (no memset, no atomics: float atomics run at 1.3 TB/s chip-wide) and the consumer
  * adds them (gcssl_in_act_fwd nslab); with split_stride = 0 they are added atomically into y, which the call zeroes. */
 int gcssl_conv4x4s2_fwd_splits(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int act, int out_f32);
+/* Conv2d(k4,s2,p1) + InstanceNorm2d + LeakyReLU(0.2) [+ Dropout(0.5)] as ONE launch -- the whole `conv_block` of
+ * cgan/models.py:236-242 (D.c2-c4) / `UNetDown` of :54-66 (G.down2-4) -- for 16-bit dtypes and output maps of <= 64 pixels:
+ * a GEMM tile then holds whole samples, the per-(n, c) statistics are taken from the fp32 accumulators inside the conv
+ * epilogue and the fp32 pre-norm tensor never goes to memory.  a [N][Hi/2][Wi/2][lda>=Cout] = act((z - mean) * rstd)
+ * [* 2 * mask]; mean, rstd [N][Cout] fp32.  apre (nullable): the activation without the dropout mask for samples
+ * n >= apre_n0, [N - apre_n0][Hi/2 * Wi/2][ld_apre] -- what gcssl_in_act_bwd(z_kind = 1) rebuilds xhat from when `a` itself is
+ * masked.  act must be 1.  gcssl_conv4x4s2_in_act_ok: 1 if these shapes are served, 0 if the caller should use
+ * gcssl_conv4x4s2_fwd (out_f32) + gcssl_in_act_fwd instead (fp32 dtype, larger maps, too few tiles without a K split). */
+int gcssl_conv4x4s2_in_act_ok(int dtype, int N, int Hi, int Wi, int Cin, int Cout);
+int gcssl_conv4x4s2_in_act_fwd(int dtype, const void* x, int ldx, const void* wf, const float* bias, const float* gscale,
+                               int group_n, void* a, int lda, float* mean, float* rstd, const uint8_t* mask, void* apre,
+                               int ld_apre, int apre_n0, int N, int Hi, int Wi, int Cin, int Cout, int act, void* stream);
 /* data gradient of the conv == ConvTranspose2d(k4,s2,p1) forward (cgan/models.py:72,113):
  * dx[N][Hi][Wi][lddx>=Cin] = gscale * convT(dy[N][Hi/2][Wi/2][lddy>=Cout], W).  out_f32: write fp32 whatever dtype. */
 int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, const float* gscale, int group_n,
@@ -124,12 +136,15 @@ int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean
  * dbias[c] += sum dz; cdot[n/group_n] += sum dzs (z - bias[c]) -- the coefficient <dW_sn, W_orig>/sigma^2 of the
  * spectral-norm quotient rule when gscale = 1/sigma.  Optional args nullable. */
 int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const float* da_bcast,
-                     const float* z, int ldz, const float* mean, const float* rstd, const uint8_t* mask, const float* zt,
+                     const void* z, int ldz, int z_kind, const float* mean, const float* rstd, const uint8_t* mask, const float* zt,
                      int zt_n0, const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias,
                      float* cdot, int nrep, int rep_stride, int da_nslab, long da_slab_stride,
                      float* ws, const float* presum_cnt, const float* presum_pos, float presum_pos_scale,
                      int N, int HW, int C, int act, void* stream);
-/* ws: caller-owned scratch of 2*N*C floats, required when H*W > 256 (two-kernel path), else may be NULL.
+/* z_kind 0: z is the fp32 pre-norm tensor.  z_kind 1 (maps of <= 256 pixels, act = LeakyReLU): z is the 16-bit ACTIVATION
+ * without dropout, in `dtype`, as gcssl_conv4x4s2_in_act_fwd left it (its `a`, or `apre` for a masked layer); xhat is rebuilt as
+ * a > 0 ? a : 5 a and z - bias as xhat / rstd + mean - bias.
+ * ws: caller-owned scratch of 2*N*C floats, required when H*W > 256 (two-kernel path), else may be NULL.
  * presum_cnt / presum_pos (nullable, [N][C] fp32; only with act = ReLU and da_bcast as the sole incoming gradient): the
  * number of positive normalised values and presum_pos_scale * presum_pos = their sum, as the forward pass left them
  * (gcssl_convT4x4s2_in_relu_fwd's cnt, and its pool or the head's pooled mean with scale H*W): maps of more than 256
@@ -137,9 +152,10 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
 /* second-order backward (create_graph=True, cgan/losses.py:213-220): adjoint of dz=IN_bwd(z, act'*gb_a) for an
  * incoming adjoint qz: gt_a = act'(xhat) * d/d(dn), zt = d/dz; cdot += sum gb_zs*qz. */
 int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, int ldq, const void* gb_zs, int ldgz,
-                     const float* z, int ldz, const float* mean, const float* rstd, void* gt_a, int ldga, float* zt,
+                     const void* z, int ldz, int z_kind, const float* mean, const float* rstd, void* gt_a, int ldga, float* zt,
                      float* cdot, int q_nslab, long q_slab_stride, int N, int HW, int C, int act, void* stream);
-/* da_nslab / q_nslab > 1: da / qz is the first of that many split-K partial-sum slabs (stride in floats) written by a
+/* z_kind as in gcssl_in_act_bwd (1: maps of <= 64 pixels).
+ * da_nslab / q_nslab > 1: da / qz is the first of that many split-K partial-sum slabs (stride in floats) written by a
  * gcssl_conv4x4s2_* call with split_stride > 0; the kernel first folds them into slab 0 (maps up to 16x16 / 8x8), so
  * slab 0 holds the total afterwards (gcssl_in_dbl_bwd reads the same da again as gb_a). */
 /* LeakyReLU backward for the norm-less layers (D.c1, G.down1; cgan/models.py:103,246), from the activation OUTPUT a. */

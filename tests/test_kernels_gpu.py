@@ -228,6 +228,100 @@ def test_instance_norm_fwd_bwd_dbl(ops, dt, tol, N, H, C, act):
     assert rel_err(cd2.cpu(), (gzs * qz).sum().view(1)) < max(tol, 1e-4)
 
 
+FIN_CASES = [  # N, Hi, Cin, Cout, masked -- the one-launch conv + InstanceNorm + LeakyReLU forms (16-bit dtypes, maps of <= 64 pixels)
+    (768, 16, 64, 128, False),   # D.c2 / G.down2 at the bench batch: 768 tiles of 128x64, two whole 8x8 samples per tile
+    (768, 8, 128, 256, False),   # D.c3: 192 tiles of 128x128 on the loader / consumer ring, eight 4x4 samples per tile
+    (768, 4, 256, 512, True),    # D.c4 / G.down4 (dropout mask + un-masked copy for the backward): 96 ring tiles, 32 samples each
+    (256, 8, 128, 256, False),   # the B-sample critic forward of the generator step: 64x64 tiles
+    (97, 16, 64, 128, True),     # ragged: 97 samples of 64 pixels -> 194 tiles of 64x64 (the last M tile of the 128-row forms is half empty)
+    (384, 16, 128, 256, False),  # D.c3 at 64x64 inputs, B=128: 8x8 maps, 768 tiles of 128x64
+]
+
+
+@pytest.mark.parametrize("dt,tol", DTS[1:])
+@pytest.mark.parametrize("N,Hi,Cin,Cout,masked", FIN_CASES)
+def test_conv_in_act_fused(ops, dt, tol, N, Hi, Cin, Cout, masked):
+    """gcssl_conv4x4s2_in_act_fwd == conv (fp64, operands pre-rounded) -> InstanceNorm -> LeakyReLU -> dropout mask."""
+    from oracle import manual_step as M
+    assert ops.conv_in_act_ok(ops.code(torch.empty(0, dtype=dt)), N, Hi, Cin, Cout)
+    Ho = Hi // 2
+    x = q(rnd(N, Cin, Hi, Hi, seed=31), dt)
+    w = rnd(Cout, Cin, 4, 4, seed=32, scale=0.05)
+    b = rnd(Cout, seed=33, scale=0.1)
+    group_n = (N + 2) // 3
+    gs = torch.tensor([1.3, 0.7, 2.1])[: (N + group_n - 1) // group_n]
+    wf, _ = packed_weights(ops, w, dt)
+    xd = nhwc(x, dt)
+    wide = torch.zeros(N, Ho, Ho, 2 * Cout, device="cuda", dtype=dt)     # into a channel slice of a concat buffer
+    a = wide[..., Cout:]
+    mean = torch.full((N, Cout), float("nan"), device="cuda"); rstd = torch.full((N, Cout), float("nan"), device="cuda")
+    mask = (rnd(N, Cout, Ho, Ho, seed=34) > 0) if masked else None
+    maskd = mask.permute(0, 2, 3, 1).contiguous().to("cuda", torch.uint8) if masked else None
+    n0 = (2 * N) // 3
+    apre = torch.full((N - n0, Ho, Ho, Cout), float("nan"), device="cuda", dtype=dt) if masked else None
+    ops.conv_in_act_fwd(xd, wf, a, mean, rstd, Cin, Cout, bias=b.cuda(), gscale=gs.cuda(), group_n=group_n, mask=maskd,
+                        apre=apre, apre_n0=n0)
+    torch.cuda.synchronize()
+    z = F.conv2d(x.double(), q(w, dt).double(), None, 2, 1)
+    z = z * gs[torch.arange(N) // group_n].view(-1, 1, 1, 1).double() + b.view(1, -1, 1, 1).double()
+    mu, r = M.in_stats(z)
+    pre = M.lrelu((z - mu) * r)
+    ref = pre * (mask.double() * 2 if masked else 1.0)
+    assert rel_err(mean.cpu(), mu.view(N, Cout)) < TOL_ACC and rel_err(rstd.cpu(), r.view(N, Cout)) < TOL_ACC
+    assert rel_err(nchw(a), ref) < tol
+    assert float(wide[..., :Cout].abs().max()) == 0.0
+    if masked:
+        assert rel_err(nchw(apre), pre[n0:]) < tol
+
+
+@pytest.mark.parametrize("dt,tol", DTS[1:])
+@pytest.mark.parametrize("N,H,C", [(6, 8, 128), (5, 2, 512), (7, 4, 256)])
+def test_instance_norm_bwd_from_activation(ops, dt, tol, N, H, C):
+    """in_act_bwd / in_dbl_bwd with z_kind = 1: xhat rebuilt from the 16-bit LeakyReLU activation (what a fused
+    conv_in_act_fwd leaves) must equal the oracle formulas evaluated at that rebuilt xhat."""
+    from oracle import manual_step as M
+    z = rnd(N, C, H, H, seed=40, scale=2.0) + 0.3
+    da = rnd(N, C, H, H, seed=41)
+    mask = (rnd(N, C, H, H, seed=42) > 0)
+    mu, r = M.in_stats(z)
+    a16 = M.lrelu((z - mu) * r).to(dt)                                  # the stored activation
+    xh = torch.where(a16.float() > 0, a16.float(), 5.0 * a16.float())   # what the kernels rebuild
+    zq = xh / r + mu
+    ad = a16.permute(0, 2, 3, 1).contiguous().cuda()
+    dad = nhwc(da, torch.float32)
+    maskd = mask.permute(0, 2, 3, 1).contiguous().to("cuda", torch.uint8)
+    mean, rstd = mu.view(N, C).cuda().contiguous(), r.view(N, C).cuda().contiguous()
+    bias = rnd(C, seed=43, scale=0.1)
+    gsc = torch.tensor([1.5, 0.5], device="cuda")
+    group_n = (N + 1) // 2
+    dzs = torch.empty(N, H, H, C, device="cuda", dtype=dt)
+    dbias = torch.zeros(C, device="cuda"); cdot = torch.zeros(2, device="cuda")
+    ops.in_act_bwd(ad, mean, rstd, dzs, C, 1, da=dad, mask=maskd, gscale=gsc, group_n=group_n, bias=bias.cuda(),
+                   dbias=dbias, cdot=cdot)
+    torch.cuda.synchronize()
+    ag = torch.where(xh > 0, torch.ones_like(xh), torch.full_like(xh, 0.2))
+    dn = da * mask.float() * 2 * ag
+    dz = M.in_bwd(xh, r, dn)
+    grp = (torch.arange(N) // group_n)
+    assert rel_err(nchw(dzs), dz * gsc.cpu()[grp].view(-1, 1, 1, 1)) < tol
+    terms = dz * gsc.cpu()[grp].view(-1, 1, 1, 1) * (zq - bias.view(1, -1, 1, 1))
+    cd = torch.stack([terms[grp == g].double().sum() for g in range(2)])
+    mag = torch.stack([terms[grp == g].abs().double().sum() for g in range(2)])
+    assert float(((cdot.cpu().double() - cd).abs() / mag).max()) < 1e-5
+    # (xhat rebuilt from a rounded activation no longer sums to zero exactly, so neither does dz: compare with the reference's sum)
+    assert float((dbias.cpu() - dz.sum(dim=(0, 2, 3))).abs().max()) < 1e-5 * float(dz.abs().sum(dim=(0, 2, 3)).max())
+    qz = rnd(N, C, H, H, seed=44)
+    gzs = q(rnd(N, C, H, H, seed=45), dt)
+    gt_a = torch.empty(N, H, H, C, device="cuda", dtype=dt); zt = torch.empty(N, H, H, C, device="cuda")
+    cd2 = torch.zeros(1, device="cuda")
+    ops.in_dbl_bwd(dad, nhwc(qz, torch.float32), nhwc(gzs, dt), ad, mean, rstd, gt_a, zt, C, 1, cdot=cd2)
+    torch.cuda.synchronize()
+    gtn, ztr = M.in_bwd_bwd(xh, r, da * ag, qz)
+    assert rel_err(nchw(gt_a), gtn * ag) < tol
+    assert rel_err(nchw(zt), ztr) < 1e-4
+    assert rel_err(cd2.cpu(), (gzs * qz).sum().view(1)) < 1e-4
+
+
 @pytest.mark.parametrize("dt,tol", DTS)
 def test_act_bwd_and_dot(ops, dt, tol):
     N, H, C = 4, 16, 64
