@@ -52,9 +52,11 @@ template <> struct Elem<bf16_t> {
 // fp16 stores SATURATE at +-65504 instead of overflowing to inf: the critic's loss-scaled gradient tensors have a heavy tail
 // (a 2x2 InstanceNorm with a tiny variance multiplies by rstd up to 316; measured peaks reach a quarter of the ceiling once
 // in a few thousand iterations), and one inf in a weight-gradient operand turns the whole update into NaN, while a clipped
-// outlier perturbs a gradient that is norm-clipped to 1 anyway.  NaN inputs are not preserved by the clamp (fmaxf returns
-// the other operand) -- the fp32 statistics, losses and scores next to every 16-bit tensor still carry them.
-__device__ __forceinline__ f16_t f32_to_f16_sat(float v) { return (f16_t)fminf(fmaxf(v, -65504.f), 65504.f); }
+// outlier perturbs a gradient that is norm-clipped to 1 anyway.  NaN is PRESERVED (fmaxf alone would turn it into -65504):
+// a NaN gradient has to reach the optimiser's norm and the reference's NaN/Inf stop (cgan/cgan_train_enhanced.py:473-478),
+// not become a large finite update.  Clipped gradient stores are COUNTED (sat_hits / sat_commit below): the engine keeps the
+// count on the device, bench.py reports it and the tests assert it is zero.
+__device__ __forceinline__ f16_t f32_to_f16_sat(float v) { return v != v ? (f16_t)v : (f16_t)fminf(fmaxf(v, -65504.f), 65504.f); }
 template <> struct Elem<f16_t> {
     static constexpr int KV = 8;
     __device__ static float ld(const f16_t* p) { return (float)*p; }
@@ -103,6 +105,27 @@ template <> struct Vec16<TT> {                                                  
 GCSSL_VEC16_16BIT(bf16_t)
 GCSSL_VEC16_16BIT(f16_t)
 #undef GCSSL_VEC16_16BIT
+
+// ---- saturation count of 16-bit GRADIENT stores (fp16 only: bf16 and fp32 have fp32's exponent range).  A thread counts the
+// values it is about to store whose magnitude exceeds fp16's largest finite number and adds a non-zero count to the
+// caller's device counter (nullable): clipping is rare by construction (static loss scale), so the atomic almost never runs.
+template <typename T> struct IsF16 { static constexpr bool v = false; };
+template <> struct IsF16<f16_t> { static constexpr bool v = true; };
+template <typename T> __device__ __forceinline__ int sat_hit(float v) { return (IsF16<T>::v && fabsf(v) > 65504.f) ? 1 : 0; }
+template <typename T, int NV> __device__ __forceinline__ int sat_hits(const float (&v)[NV]) {
+    int n = 0;
+    if constexpr (IsF16<T>::v) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) n += fabsf(v[i]) > 65504.f ? 1 : 0;
+    }
+    return n;
+}
+__device__ __forceinline__ void sat_commit(unsigned* sat, int n) { if (sat && n) atomicAdd(sat, (unsigned)n); }
+
+// ---- which kernel did the last conv dispatcher launch?  (bench.py's roofline names the rocprofv3 symbol of its dominant
+// launch: the dispatchers pick a template instantiation per shape, so the host records the expression it launched.)
+extern const char* g_gcssl_last_kernel;
+#define GCSSL_LAUNCH(kern, ...) do { g_gcssl_last_kernel = #kern; hipLaunchKernelGGL(kern, __VA_ARGS__); } while (0)
 
 // ---- wave / block reductions (wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -409,8 +409,8 @@ int gcssl_convT4x4s2_in_relu_fwd(int dtype, const void* x, int ldx, const void* 
     p.debug = dbg;
     static const int cus = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
     const int grid = p.nblocks < cus ? p.nblocks : cus;
-#define CT(T) do { if (H == 16) hipLaunchKernelGGL((convt_in_relu_kernel<T, 4>), dim3(grid), dim3(NTH), 0, (hipStream_t)stream, p); \
-                   else hipLaunchKernelGGL((convt_in_relu_kernel<T, 3>), dim3(grid), dim3(NTH), 0, (hipStream_t)stream, p); } while (0)
+#define CT(T) do { if (H == 16) GCSSL_LAUNCH((convt_in_relu_kernel<T, 4>), dim3(grid), dim3(NTH), 0, (hipStream_t)stream, p); \
+                   else GCSSL_LAUNCH((convt_in_relu_kernel<T, 3>), dim3(grid), dim3(NTH), 0, (hipStream_t)stream, p); } while (0)
     if (dtype == GCSSL_F16) CT(f16_t); else CT(bf16_t);
 #undef CT
     return gcssl_launch_status();

@@ -1681,13 +1681,13 @@ template <typename T, int BM, int BN, int MODE> struct Dma8 {            // 8-wa
 };
 template <typename T, int MODE> struct Dma8<T, 128, 128, MODE> {
     static bool launch(const ConvParams& p, dim3 grid, hipStream_t st) {
-        hipLaunchKernelGGL((conv_dma_kernel<T, 128, 128, MODE, 2, 4, false>), grid, dim3(512), 0, st, p);
+        GCSSL_LAUNCH((conv_dma_kernel<T, 128, 128, MODE, 2, 4, false>), grid, dim3(512), 0, st, p);
         return true;
     }
 };
 template <typename T, int MODE> struct Dma8<T, 128, 64, MODE> {
     static bool launch(const ConvParams& p, dim3 grid, hipStream_t st) {
-        hipLaunchKernelGGL((conv_dma_kernel<T, 128, 64, MODE, 4, 2, false>), grid, dim3(512), 0, st, p);
+        GCSSL_LAUNCH((conv_dma_kernel<T, 128, 64, MODE, 4, 2, false>), grid, dim3(512), 0, st, p);
         return true;
     }
 };
@@ -1705,13 +1705,13 @@ template <typename T, int BM, int BN, int MODE> struct Persist {
 };
 template <typename T, int MODE> struct Persist<T, 128, 64, MODE> {
     static bool launch(const ConvParams& p, int g, int tm, int tn, int total, hipStream_t st) {
-        hipLaunchKernelGGL((conv_dma_persist_kernel<T, 128, 64, MODE, 4, 2>), dim3(g), dim3(512), 0, st, p, tm, tn, total);
+        GCSSL_LAUNCH((conv_dma_persist_kernel<T, 128, 64, MODE, 4, 2>), dim3(g), dim3(512), 0, st, p, tm, tn, total);
         return true;
     }
 };
 template <typename T, int MODE> struct Persist<T, 64, 64, MODE> {
     static bool launch(const ConvParams& p, int g, int tm, int tn, int total, hipStream_t st) {
-        hipLaunchKernelGGL((conv_dma_persist_kernel<T, 64, 64, MODE, 2, 2>), dim3(g), dim3(256), 0, st, p, tm, tn, total);
+        GCSSL_LAUNCH((conv_dma_persist_kernel<T, 64, 64, MODE, 2, 2>), dim3(g), dim3(256), 0, st, p, tm, tn, total);
         return true;
     }
 };
@@ -1720,7 +1720,7 @@ template <typename T, int BM, int BN, int MODE> struct PersistSmallK {     // 8-
 };
 template <typename T> struct PersistSmallK<T, 128, 64, 0> {
     static bool launch(const ConvParams& p, int g, int tm, int tn, int total, hipStream_t st) {
-        hipLaunchKernelGGL((conv_dma_persist_kernel<T, 128, 64, 0, 2, 2, true>), dim3(g), dim3(256), 0, st, p, tm, tn, total);
+        GCSSL_LAUNCH((conv_dma_persist_kernel<T, 128, 64, 0, 2, 2, true>), dim3(g), dim3(256), 0, st, p, tm, tn, total);
         return true;
     }
 };
@@ -1737,9 +1737,9 @@ void launch_dma(const ConvParams& p, dim3 grid, bool smallk, hipStream_t st) {
     }
     if (dma_waves() == 8 && !smallk && Dma8<T, BM, BN, MODE>::launch(p, grid, st)) return;
     if (smallk) {
-        hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, MODE, 2, 2, true>), grid, dim3(256), 0, st, p);
+        GCSSL_LAUNCH((conv_dma_kernel<T, BM, BN, MODE, 2, 2, true>), grid, dim3(256), 0, st, p);
     } else {
-        hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, MODE, 2, 2, false>), grid, dim3(256), 0, st, p);
+        GCSSL_LAUNCH((conv_dma_kernel<T, BM, BN, MODE, 2, 2, false>), grid, dim3(256), 0, st, p);
     }
 }
 
@@ -1833,7 +1833,7 @@ int launch_fwd(const ConvParams& p, hipStream_t st) {
     if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
     if (Is16<T>::v && use_dma()) launch_dma<typename Op16<T>::type, BM, BN, 0>(p, grid, p.Cin < 64, st);
-    else hipLaunchKernelGGL((conv_fwd_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
+    else GCSSL_LAUNCH((conv_fwd_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
 }
 template <typename T, int BM, int BN>
@@ -1841,7 +1841,7 @@ int launch_dgrad(const ConvParams& p, hipStream_t st) {
     if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cin + BN - 1) / BN, 4 * (p.ksplit > 1 ? p.ksplit : 1));
     if (Is16<T>::v && use_dma()) launch_dma<typename Op16<T>::type, BM, BN, 1>(p, grid, false, st);
-    else hipLaunchKernelGGL((conv_dgrad_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
+    else GCSSL_LAUNCH((conv_dgrad_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
 }
 
@@ -1952,7 +1952,7 @@ template <typename T, int BM, int BN, int MODE> struct PersistBig {       // 256
 };
 template <typename T, int MODE> struct PersistBig<T, 256, 64, MODE> {
     static bool launch(const ConvParams& p, int g, int tm, int tn, int total, hipStream_t st) {
-        hipLaunchKernelGGL((conv_dma_persist_kernel<T, 256, 64, MODE, 4, 2>), dim3(g), dim3(512), 0, st, p, tm, tn, total);
+        GCSSL_LAUNCH((conv_dma_persist_kernel<T, 256, 64, MODE, 4, 2>), dim3(g), dim3(512), 0, st, p, tm, tn, total);
         return true;
     }
 };
@@ -1969,8 +1969,8 @@ int launch_ring(const ConvParams& p, hipStream_t st) {
     // loader waves with consumers software-pipelined across the barrier: 20.9 vs 23.8 us (D.c3.fwd), 20.8 vs 23.9 (D.c4.dgrad).
     // The K loop of the 4-loader form ran at the loaders' issue rate (8 pieces x ~105 cycles per wave and step).
     static const int lw8 = [] { const char* e = getenv("GCSSL_RING_LW8"); return e ? atoi(e) : 1; }();
-    if (lw8) { hipLaunchKernelGGL((conv_dma_kernel<T, 128, 128, MODE, 4, 2, false, 8, 4, false>), grid, dim3(1024), 0, st, q); return gcssl_launch_status(); }
-    hipLaunchKernelGGL((conv_dma_kernel<T, 128, 128, MODE, 4, 2, false, 4, 4>), grid, dim3(768), 0, st, q);
+    if (lw8) { GCSSL_LAUNCH((conv_dma_kernel<T, 128, 128, MODE, 4, 2, false, 8, 4, false>), grid, dim3(1024), 0, st, q); return gcssl_launch_status(); }
+    GCSSL_LAUNCH((conv_dma_kernel<T, 128, 128, MODE, 4, 2, false, 4, 4>), grid, dim3(768), 0, st, q);
     return gcssl_launch_status();
 }
 template <typename T, int BM, int BN, int MODE>
@@ -1981,7 +1981,7 @@ int launch_big(const ConvParams& p, hipStream_t st) {
     const int total = (int)(grid.x * grid.y * grid.z), slots = cu_count();          // 120-144 KB of LDS: one per CU
     if (persist_mode() && p.ksplit <= 1 && p.y_bytes && total > slots + slots / 4 &&
         PersistBig<T, BM, BN, MODE>::launch(p, slots, (int)grid.x, (int)grid.y, total, st)) return gcssl_launch_status();
-    hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, MODE, 4, 2, false>), grid, dim3(512), 0, st, p);
+    GCSSL_LAUNCH((conv_dma_kernel<T, BM, BN, MODE, 4, 2, false>), grid, dim3(512), 0, st, p);
     return gcssl_launch_status();
 }
 
@@ -2100,7 +2100,7 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
             if (tile_b < (size_t)64 * 17 * 16) tile_b = (size_t)64 * 17 * 16;       // the region first holds the padded weight image
             const size_t lds = (size_t)rows * (p.Wi + 2) * 16 + tile_b;
             const int ntiles = p.N * ((p.Hi / 2) / R), per = (ntiles + 1023) / 1024, grid = (ntiles + per - 1) / per;
-            hipLaunchKernelGGL(conv_fwd_c8_kernel<T>, dim3((unsigned)grid), dim3(256), lds, st, p, ntiles);
+            GCSSL_LAUNCH(conv_fwd_c8_kernel<T>, dim3((unsigned)grid), dim3(256), lds, st, p, ntiles);
             return gcssl_launch_status();
         }
     }
@@ -2182,16 +2182,16 @@ int dispatch_fwd_in(ConvParams p, hipStream_t st) {
         p.ksplit = 1;
         if (form == 1) {
             dim3 grid((p.M + 127) / 128, (p.Cout + 127) / 128, 1);
-            hipLaunchKernelGGL((conv_dma_kernel<O, 128, 128, 0, 4, 2, false, 8, 4, false, true>), grid, dim3(1024), 0, st, p);
+            GCSSL_LAUNCH((conv_dma_kernel<O, 128, 128, 0, 4, 2, false, 8, 4, false, true>), grid, dim3(1024), 0, st, p);
         } else if (form == 2) {
             dim3 grid((p.M + 127) / 128, (p.Cout + 63) / 64, 1);
-            hipLaunchKernelGGL((conv_dma_kernel<O, 128, 64, 0, 4, 2, false, 0, 3, true, true>), grid, dim3(512), 0, st, p);
+            GCSSL_LAUNCH((conv_dma_kernel<O, 128, 64, 0, 4, 2, false, 0, 3, true, true>), grid, dim3(512), 0, st, p);
         } else if (form == 3) {
             dim3 grid((p.M + 63) / 64, (p.Cout + 63) / 64, 1);
-            hipLaunchKernelGGL((conv_dma_kernel<O, 64, 64, 0, 2, 2, false, 0, 3, true, true>), grid, dim3(256), 0, st, p);
+            GCSSL_LAUNCH((conv_dma_kernel<O, 64, 64, 0, 2, 2, false, 0, 3, true, true>), grid, dim3(256), 0, st, p);
         } else if (form == 4) {
             const int tm = (p.M + 127) / 128, tn = (p.Cout + 63) / 64;
-            hipLaunchKernelGGL((conv_dma_persist_kernel<O, 128, 64, 0, 4, 2, false, true>), dim3(2 * cu_count()), dim3(512), 0, st, p, tm, tn, tm * tn);
+            GCSSL_LAUNCH((conv_dma_persist_kernel<O, 128, 64, 0, 4, 2, false, true>), dim3(2 * cu_count()), dim3(512), 0, st, p, tm, tn, tm * tn);
         } else {
             return GCSSL_EBADSHAPE;
         }
@@ -2312,7 +2312,7 @@ int dispatch_dgrad(ConvParams p, hipStream_t st) {
             if (tile_b < (size_t)8 * 129 * 16) tile_b = (size_t)8 * 129 * 16;       // the region first holds the padded weight image
             const size_t lds = (size_t)rows * (Wo + 2) * 128 + tile_b;
             const int ntiles = p.N * ((p.Hi / 2) / R), per = (ntiles + 1023) / 1024, grid = (ntiles + per - 1) / per;
-            hipLaunchKernelGGL(conv_dgrad_c8_kernel<T>, dim3((unsigned)grid), dim3(256), lds, st, p, ntiles);
+            GCSSL_LAUNCH(conv_dgrad_c8_kernel<T>, dim3((unsigned)grid), dim3(256), lds, st, p, ntiles);
             return gcssl_launch_status();
         }
     }
@@ -2542,16 +2542,16 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
         dim3 gd(Cout / 128, 4 * (Cin / 64), nsplit);                    // LDS-DMA ring, one filter row (4 taps) per workgroup
         static const int lw = [] { const char* e = getenv("GCSSL_WGRAD_LW"); return e ? atoi(e) : 8; }();    // A/B knob: 0 = all waves fetch
         if (lw) {
-            if (dtype == GCSSL_F16) hipLaunchKernelGGL((conv_wgrad_dma_kernel<f16_t, 8>), gd, dim3(1024), 0, st, p);
-            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<bf16_t, 8>), gd, dim3(1024), 0, st, p);
+            if (dtype == GCSSL_F16) GCSSL_LAUNCH((conv_wgrad_dma_kernel<f16_t, 8>), gd, dim3(1024), 0, st, p);
+            else GCSSL_LAUNCH((conv_wgrad_dma_kernel<bf16_t, 8>), gd, dim3(1024), 0, st, p);
             return gcssl_launch_status();
         }
-        if (dtype == GCSSL_F16) hipLaunchKernelGGL((conv_wgrad_dma_kernel<f16_t, 0>), gd, dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<bf16_t, 0>), gd, dim3(512), 0, st, p);
+        if (dtype == GCSSL_F16) GCSSL_LAUNCH((conv_wgrad_dma_kernel<f16_t, 0>), gd, dim3(512), 0, st, p);
+        else GCSSL_LAUNCH((conv_wgrad_dma_kernel<bf16_t, 0>), gd, dim3(512), 0, st, p);
         return gcssl_launch_status();
     }
     dim3 grid(Cout / bm, smallc ? 1 : 16 * (Cin / bn), nsplit);
-#define WG(T, A, B, S) hipLaunchKernelGGL((conv_wgrad_kernel<T, A, B, S>), grid, dim3(NT), 0, st, p)
+#define WG(T, A, B, S) GCSSL_LAUNCH((conv_wgrad_kernel<T, A, B, S>), grid, dim3(NT), 0, st, p)
     GCSSL_DISPATCH(dtype,
         if (smallc) { if (bm == 128) WG(T, 128, 128, true); else WG(T, 64, 128, true); }
         else if (bm == 128 && bn == 128) WG(T, 128, 128, false); else if (bm == 128) WG(T, 128, 64, false);
@@ -2569,7 +2569,7 @@ int gcssl_wgrad_reduce(const float* slab, int nsplit, float* dw, int Cout, int C
     if (nrank > 0 && (vstride % 4 || !aligned16(v))) return GCSSL_EALIGN;                 // 16-byte loads of the v rows
     int zg = 1;
     if (accumulate == 2) { zg = (nsplit + 15) / 16; if (zg > 16) zg = 16; }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cin + 63) / 64), (unsigned)Cout, (unsigned)zg), dim3(256), 0,
+    GCSSL_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((Cin + 63) / 64), (unsigned)Cout, (unsigned)zg), dim3(256), 0,
                        (hipStream_t)stream, slab, nsplit, dw, Cout, Cin, Cin_real, coef, cscale, u, ustride, v, vstride, nrank, accumulate);
     return gcssl_launch_status();
 }
@@ -2594,7 +2594,7 @@ int gcssl_wgrad_reduce_batch(int nl, const float* const* slab, const int* nsplit
         blk += ((Cin[i] + 63) / 64) * Cout[i] * zg;
     }
     b.nl = nl; b.ustride = ustride; b.vstride = vstride; b.accumulate = accumulate;
-    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, b);
+    GCSSL_LAUNCH(wgrad_reduce_batch_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, b);
     return gcssl_launch_status();
 }
 
@@ -2614,7 +2614,7 @@ int gcssl_prep_conv_weights(int dtype, int nl, const float* const* w, void* cons
     unsigned gx = (unsigned)((mx + 4095) / 4096); if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;     // one 4096-element tile per pass
     dim3 grid(gx, nl, 2);
     if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(prep_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b));
+    GCSSL_DISPATCH(dtype, GCSSL_LAUNCH(prep_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b));
     return gcssl_launch_status();
 }
 
@@ -2625,7 +2625,7 @@ int gcssl_prep_conv_weight(int dtype, const float* w, void* wf, void* wt, int Co
     const size_t total = (size_t)Cout * 16 * CinP;
     dim3 grid((unsigned)((total + 255) / 256));
     if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(prep_weight_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, w, (T*)wf, (T*)wt, Cout, Cin, CinP));
+    GCSSL_DISPATCH(dtype, GCSSL_LAUNCH(prep_weight_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, w, (T*)wf, (T*)wt, Cout, Cin, CinP));
     return gcssl_launch_status();
 }
 
@@ -2659,22 +2659,22 @@ int gcssl_conv3x3_fwd(int dtype, const void* x, int ldx, const void* w, const fl
     if (dtype != GCSSL_F32 && use_dma() && dma3) {             // LDS-DMA pipeline (MODE 2 of conv_dma_kernel)
 #define DMA3(T) do { \
         if (Cin < 64) {                                        /* 8-channel first layer: a K tile spans several taps */ \
-            if (big) hipLaunchKernelGGL((conv_dma_kernel<T, 128, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p); \
-            else hipLaunchKernelGGL((conv_dma_kernel<T, 64, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p); \
+            if (big) GCSSL_LAUNCH((conv_dma_kernel<T, 128, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p); \
+            else GCSSL_LAUNCH((conv_dma_kernel<T, 64, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p); \
         } else if (big) { \
             /* more tiles than resident workgroups: the persistent form (the DMA ring never drains between tiles) */ \
             const int slots = cu_count() * ((160 * 1024) / (3 * (128 + 64) * 128)), total = (int)(grid.x * grid.y); \
             if ((persist_mode() & 1) && p.y_bytes && total > slots + slots / 4) \
-                hipLaunchKernelGGL((conv_dma_persist_kernel<T, 128, 64, 2, 4, 2>), dim3(slots), dim3(512), 0, st, p, (int)grid.x, (int)grid.y, total); \
-            else hipLaunchKernelGGL((conv_dma_kernel<T, 128, 64, 2, 4, 2, false>), grid, dim3(512), 0, st, p); \
+                GCSSL_LAUNCH((conv_dma_persist_kernel<T, 128, 64, 2, 4, 2>), dim3(slots), dim3(512), 0, st, p, (int)grid.x, (int)grid.y, total); \
+            else GCSSL_LAUNCH((conv_dma_kernel<T, 128, 64, 2, 4, 2, false>), grid, dim3(512), 0, st, p); \
         } \
-        else hipLaunchKernelGGL((conv_dma_kernel<T, 64, 64, 2, 2, 2, false>), grid, dim3(256), 0, st, p); } while (0)
+        else GCSSL_LAUNCH((conv_dma_kernel<T, 64, 64, 2, 2, 2, false>), grid, dim3(256), 0, st, p); } while (0)
         if (dtype == GCSSL_F16) DMA3(f16_t); else DMA3(bf16_t);
 #undef DMA3
         return gcssl_launch_status();
     }
-    GCSSL_DISPATCH(dtype, if (big) hipLaunchKernelGGL((conv_fwd_kernel<T, 128, 64, 3>), grid, dim3(NT), 0, st, p);
-                          else hipLaunchKernelGGL((conv_fwd_kernel<T, 64, 64, 3>), grid, dim3(NT), 0, st, p));
+    GCSSL_DISPATCH(dtype, if (big) GCSSL_LAUNCH((conv_fwd_kernel<T, 128, 64, 3>), grid, dim3(NT), 0, st, p);
+                          else GCSSL_LAUNCH((conv_fwd_kernel<T, 64, 64, 3>), grid, dim3(NT), 0, st, p));
     return gcssl_launch_status();
 }
 
@@ -2715,7 +2715,7 @@ int gcssl_conv3x3_wgrad(int dtype, const void* x, int ldx, const void* dy, int l
     const int bm = Cout >= 128 ? 128 : 64, bn = Cin >= 128 ? 128 : 64;
     const bool smallc = Cin == 8;
     dim3 grid(Cout / bm, smallc ? 1 : 9 * (Cin / bn), nsplit);
-#define WG(T, A, B, S) hipLaunchKernelGGL((conv_wgrad_kernel<T, A, B, S, 3>), grid, dim3(NT), 0, st, p)
+#define WG(T, A, B, S) GCSSL_LAUNCH((conv_wgrad_kernel<T, A, B, S, 3>), grid, dim3(NT), 0, st, p)
     GCSSL_DISPATCH(dtype,
         if (smallc) { if (bm == 128) WG(T, 128, 128, true); else WG(T, 64, 128, true); }
         else if (bm == 128 && bn == 128) WG(T, 128, 128, false); else if (bm == 128) WG(T, 128, 64, false);
@@ -2737,7 +2737,7 @@ int gcssl_conv3x3_wgrad_reduce(int nl, const float* const* slab, const int* nspl
         blk += ((Cin[i] + 63) / 64) * Cout[i];
     }
     b.nl = nl;
-    hipLaunchKernelGGL(wgrad3_reduce_batch_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, b);
+    GCSSL_LAUNCH(wgrad3_reduce_batch_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, b);
     return gcssl_launch_status();
 }
 
@@ -2758,7 +2758,7 @@ int gcssl_conv3x3_prep_weights(int dtype, int nl, const float* const* w, void* c
     unsigned gx = (unsigned)((mx + 1023) / 1024); if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
     dim3 grid(gx, nl);
     if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(prep3_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b));
+    GCSSL_DISPATCH(dtype, GCSSL_LAUNCH(prep3_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b));
     return gcssl_launch_status();
 }
 

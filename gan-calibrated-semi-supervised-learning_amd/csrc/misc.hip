@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void sn_sigma_kernel(SnBatch b) {
 template <typename T>
 __global__ __launch_bounds__(256) void gp_norm_kernel(const float* __restrict__ g, size_t per_sample, int B, float lambda_gp,
                                                      float* __restrict__ nrm, float* __restrict__ coef, float* gp_sum,
-                                                     T* __restrict__ scaled) {
+                                                     T* __restrict__ scaled, unsigned* sat) {
     __shared__ float red[4];
     __shared__ float cf;
     const int n = blockIdx.x;
@@ -394,7 +394,9 @@ __global__ __launch_bounds__(256) void gp_norm_kernel(const float* __restrict__ 
     __syncthreads();
     const float c = cf;
     T* q = scaled + (size_t)n * per_sample;
-    for (size_t i = threadIdx.x; i < per_sample; i += 256) Elem<T>::st(q + i, p[i] * c);
+    int nsat = 0;
+    for (size_t i = threadIdx.x; i < per_sample; i += 256) { const float v = p[i] * c; nsat += sat_hit<T>(v); Elem<T>::st(q + i, v); }
+    sat_commit(sat, nsat);
 }
 
 template <typename T>
@@ -708,6 +710,8 @@ __global__ void uncast_kernel(const T* __restrict__ x, float* __restrict__ y, si
 
 #define GRID1(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256), 0, (hipStream_t)stream
 
+const char* g_gcssl_last_kernel = nullptr;     // (common.h: set by GCSSL_LAUNCH in every translation unit of the library)
+
 extern "C" {
 
 int gcssl_pack_pair(int dtype, const float* a, const float* b, void* out, int B, int S, void* stream) {
@@ -827,12 +831,12 @@ int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* c
 }
 
 int gcssl_gp_norm(const float* g, long per_sample, int B, float lambda_gp, float* nrm, float* coef, float* gp_sum,
-                  int dtype, void* scaled, void* stream) {
+                  int dtype, void* scaled, unsigned* sat, void* stream) {
     if (!g || !nrm || !coef || !gp_sum) return GCSSL_ENULL;
     if (per_sample <= 0 || B <= 0) return GCSSL_EBADSHAPE;
     if (scaled && bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (!scaled) dtype = GCSSL_F32;
-    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(gp_norm_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, g, (size_t)per_sample, B, lambda_gp, nrm, coef, gp_sum, (T*)scaled));
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(gp_norm_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, g, (size_t)per_sample, B, lambda_gp, nrm, coef, gp_sum, (T*)scaled, sat));
     return gcssl_launch_status();
 }
 
@@ -845,7 +849,7 @@ int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long
     return gcssl_launch_status();
 }
 
-// state: 8 doubles, zero-initialised by the caller once (layout at sumsq_kernel); no per-call memset is needed.
+// state: GCSSL_ADAM_STATE doubles, zero-initialised by the caller once (layout at sumsq_kernel); no per-call memset is needed.
 int gcssl_clip_adam(float* p, float* g, float* m, float* v, long n, double* state, double lr, double b1, double b2,
                     double eps, double max_norm, int write_clipped, double grad_scale, void* stream) {
     if (!p || !g || !m || !v || !state) return GCSSL_ENULL;
@@ -916,6 +920,8 @@ extern "C" int gcssl_init_norm();
 extern "C" int gcssl_init_recrop();
 /* One-time device-side set-up (dynamic-LDS opt-ins).  Call once per process with a GPU present and BEFORE capturing any
  * of the entry points into a hipGraph; the entry points also do it lazily on first use. */
+const char* gcssl_last_kernel() { return g_gcssl_last_kernel ? g_gcssl_last_kernel : ""; }
+
 int gcssl_init() {
     int rc = gcssl_init_norm();
     if (rc) return rc;

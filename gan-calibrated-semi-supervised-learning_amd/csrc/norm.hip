@@ -394,6 +394,7 @@ struct InBwdParams {
     int da_nslab; long da_slab_stride; // da is the first of da_nslab split-K partial-sum slabs of the producing conv (floats apart)
     int HW, C, act;
     const float* pre_cnt; const float* pre_pos; float pre_pos_scale;   // optional precomputed sums (see gcssl_in_act_bwd)
+    unsigned* sat;                     // += number of dzs values clipped by the fp16 store (nullable; common.h sat_hits)
 };
 
 // small maps: fused backward, several samples per pass and several passes per workgroup (see combine_seg)
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
     if (q.bias) ld4(q.bias + c, b);
     float sb[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
     float sd = 0.f;
+    int nsat = 0;
     const int nb = blockIdx.y * spb;
     for (int n0 = nb; n0 < min(N, nb + spb); n0 += SPP) {
         const int n = n0 + slot;
@@ -519,6 +521,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
                 sb[0][j] += dz; sd += dz * gs * (AZ ? xh * sdev[j] + mb[j] : zv[i][j] - b[j]);
                 o[j] = dz * gs;
             }
+            nsat += sat_hits<T>(o);
             bst4<T>(outr, pix[i] != OOB ? (pix[i] * q.lddz + c) * (unsigned)sizeof(T) : OOB, o);
         }
         if (mixed_groups && q.cdot) {          // tiny batches only: a pass may straddle sample groups
@@ -537,6 +540,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_small_kernel(InBwdParams q, 
         const float tot = block_sum<CGN * RGN / 64>(sd, red);
         if (threadIdx.x == 0) atomicAdd(q.cdot + replica_offset(q.nrep, q.rep_stride) + nb / q.group_n, tot);     // all samples of a workgroup share a group
     }
+    sat_commit(q.sat, nsat);
 }
 
 // dn = act'(xhat) (da + da2 + da_bcast) [*2 keep];  dz = rstd (dn - mean(dn) - xhat mean(dn xhat)) [+ zt]
@@ -618,6 +622,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_kernel(InBwdParams q, float*
     if (q.bias) ld4(q.bias + c, b);
     float sb[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
     float sd = 0.f;
+    int nsat = 0;
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
         const int p = p0 + ty + RGN * i;
@@ -631,8 +636,10 @@ __global__ __launch_bounds__(CGN * RGN) void in_bwd_kernel(InBwdParams q, float*
             sb[0][j] += dz; sd += dz * gs * (zv[i][j] - b[j]);
             o[j] = dz * gs;
         }
+        nsat += sat_hits<T>(o);
         st4<T>(op + (size_t)p * q.lddz, o);
     }
+    sat_commit(q.sat, nsat);
     if (q.dbias) {
         combine16<1>(sb, reinterpret_cast<float(*)[RGN][CW]>(sm), tx, ty);
         if (ty == 0) {
@@ -657,6 +664,7 @@ struct InDblParams {
     float* cdot;                       // scalar += sum gb_zs * q (atomic), nullable
     int HW, C, act;
     int q_nslab; long q_slab_stride;   // qz is the first of q_nslab split-K slabs of the producing conv
+    unsigned* sat;                     // += number of gt_a values clipped by the fp16 store (nullable)
 };
 
 // adjoint of dz = in_bwd(xhat(z), rstd(z), dn) for incoming adjoint q (see oracle/manual_step.py:in_bwd_bwd)
@@ -674,6 +682,7 @@ __global__ __launch_bounds__(CW * RG) void in_dbl_bwd_kernel(InDblParams q) {
     const float mu = q.mean[(size_t)n * C + c], r = q.rstd[(size_t)n * C + c];
     float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float sd = 0.f;
+    int nsat = 0;
     for (int p = ty; p < HW; p += RG) {
         const float xh = (zp[(size_t)p * q.ldz] - mu) * r;
         const float dn = act_grad(xh, q.act) * gp[(size_t)p * q.ldgb];
@@ -692,9 +701,12 @@ __global__ __launch_bounds__(CW * RG) void in_dbl_bwd_kernel(InDblParams q) {
         const float ag = act_grad(xh, q.act);
         const float dn = ag * gp[(size_t)p * q.ldgb];
         const float qq = qp[(size_t)p * q.ldq];
-        Elem<T>::st(gap + (size_t)p * q.ldga, ag * r * (qq - mq - xh * mqx));
+        const float ga = ag * r * (qq - mq - xh * mqx);
+        nsat += sat_hit<T>(ga);
+        Elem<T>::st(gap + (size_t)p * q.ldga, ga);
         ztp[(size_t)p * C] = r * r * (-xh * k0 - m2 * (qq - mq) - mqx * (dn - m1));
     }
+    sat_commit(q.sat, nsat);
     if (q.cdot) {
         const float tot = block_sum<CW * RG / 64>(sd, red);
         if (threadIdx.x == 0) atomicAdd(q.cdot, tot);
@@ -718,6 +730,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, 
                                  gzr = make_rsrc(q.gb_zs, q.gb_zs ? rsrc_bytes(nhw * q.ldgz * sizeof(T)) : 0u),
                                  gar = make_rsrc(q.gt_a, rsrc_bytes(nhw * q.ldga * sizeof(T))), ztr = make_rsrc(q.zt, rsrc_bytes(nhw * C * 4));
     float sd = 0.f;
+    int nsat = 0;
     const int nb = blockIdx.y * spb;
     for (int n0 = nb; n0 < min(N, nb + spb); n0 += SPP) {
         const int n = n0 + slot;
@@ -790,6 +803,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, 
                 o[j] = act_grad(xh[i][j], q.act) * r[j] * (qq[i][j] - mq[j] - xh[i][j] * mqx[j]);
                 zt[j] = r[j] * r[j] * (-xh[i][j] * (mqd[j] - mq[j] * m1[j] - 3.f * mqx[j] * m2[j]) - m2[j] * (qq[i][j] - mq[j]) - mqx[j] * (dn[i][j] - m1[j]));
             }
+            nsat += sat_hits<T>(o);
             bst4<T>(gar, pix[i] != OOB ? (pix[i] * q.ldga + c) * (unsigned)sizeof(T) : OOB, o);
             bst4<float>(ztr, pix[i] != OOB ? (pix[i] * C + c) * 4u : OOB, zt);
         }
@@ -798,6 +812,7 @@ __global__ __launch_bounds__(CGN * RGN) void in_dbl_small_kernel(InDblParams q, 
         const float tot = block_sum<CGN * RGN / 64>(sd, red);
         if (threadIdx.x == 0) atomicAdd(q.cdot, tot);
     }
+    sat_commit(q.sat, nsat);
 }
 
 // ---- layers without a norm (D.c1, G.down1): a = lrelu(z) was fused in the conv epilogue; backward is elementwise
@@ -810,6 +825,7 @@ struct ActBwdParams {
     float* dbias; float* cdot;
     int HW, C;
     int nrep, rep_stride;
+    unsigned* sat;                     // += number of dzs values clipped by the fp16 store (nullable)
 };
 // grid: (C/64, sample blocks of `spb`, H*W chunks of `rows_per_chunk`); lanes own 4 channels x strided rows, the bias /
 // spectral-norm partial sums stay in registers across the samples of a workgroup (one set of atomics per workgroup)
@@ -824,6 +840,7 @@ __global__ __launch_bounds__(CGN * RGN) void act_bwd_kernel(ActBwdParams q, int 
     if (q.bias) ld4(q.bias + c, b);
     float sb[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
     float sd = 0.f;
+    int nsat = 0;
     const int p0 = blockIdx.z * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
     const int nb = blockIdx.y * spb;
     for (int n = nb; n < min(N, nb + spb); ++n) {
@@ -849,6 +866,7 @@ __global__ __launch_bounds__(CGN * RGN) void act_bwd_kernel(ActBwdParams q, int 
                 sb[0][j] += dz; sd += dz * gs * (zv - b[j]);
                 o[j] = dz * gs;
             }
+            nsat += sat_hits<T>(o);
             st4<T>(op + (size_t)p * q.lddz, o);
         }
         if (mixed_groups && q.cdot) {
@@ -868,6 +886,7 @@ __global__ __launch_bounds__(CGN * RGN) void act_bwd_kernel(ActBwdParams q, int 
         const float tot = block_sum<CGN * RGN / 64>(sd, red);
         if (threadIdx.x == 0) atomicAdd(q.cdot + replica_offset(q.nrep, q.rep_stride) + nb / q.group_n, tot);
     }
+    sat_commit(q.sat, nsat);
 }
 
 // out += sum x*y  (strided NHWC views), used for the <gb_zs, gt_z> spectral-norm term of the norm-less layer;
@@ -986,8 +1005,8 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
                      const void* z, int ldz, int z_kind, const float* mean, const float* rstd, const uint8_t* mask,
                      const float* zt, int zt_n0, const float* gscale, int group_n, const float* bias,
                      void* dzs, int lddz, float* dbias, float* cdot, int nrep, int rep_stride, int da_nslab, long da_slab_stride,
-                     float* ws, const float* presum_cnt, const float* presum_pos, float presum_pos_scale, int N, int HW, int C,
-                     int act, void* stream) {
+                     float* ws, const float* presum_cnt, const float* presum_pos, float presum_pos_scale, unsigned* sat,
+                     int N, int HW, int C, int act, void* stream) {
     if ((!da && !da_bcast) || !z || !mean || !rstd || !dzs) return GCSSL_ENULL;
     if (nrep < 1 || (nrep > 1 && rep_stride < C)) return GCSSL_EBADSHAPE;
     if (da_nslab < 1 || (da_nslab > 1 && (!da || da_slab_stride <= 0 || da_slab_stride % 4 || HW > MID_HW))) return GCSSL_EBADSHAPE;
@@ -1000,6 +1019,7 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
     if (HW > MID_HW && !ws && !(presum_cnt && presum_pos)) return GCSSL_ENULL;
     InBwdParams q{da, ldda, da2, ldda2, da_bcast, z, ldz, mean, rstd, mask, zt, zt_n0, gscale,
                   group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, nrep, rep_stride, da_nslab, da_slab_stride, HW, C, act};
+    q.sat = sat;
     hipStream_t st = (hipStream_t)stream;
     if (HW <= MID_HW) {
         if (!fits_buffer(N, HW, std::max(std::max(ldz, lddz), std::max(da ? ldda : 0, da2 ? ldda2 : 0)))) return GCSSL_EBADSHAPE;
@@ -1033,12 +1053,13 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
 
 int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, int ldq, const void* gb_zs, int ldgz,
                      const void* z, int ldz, int z_kind, const float* mean, const float* rstd, void* gt_a, int ldga,
-                     float* zt, float* cdot, int q_nslab, long q_slab_stride, int N, int HW, int C, int act, void* stream) {
+                     float* zt, float* cdot, int q_nslab, long q_slab_stride, unsigned* sat, int N, int HW, int C, int act,
+                     void* stream) {
     if (!gb_a || !qz || !z || !mean || !rstd || !gt_a || !zt) return GCSSL_ENULL;
     if (q_nslab < 1 || (q_nslab > 1 && (q_slab_stride <= 0 || q_slab_stride % 4 || HW > SMALL_HW))) return GCSSL_EBADSHAPE;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || ldgb < C || ldq < C || ldga < C) return GCSSL_EBADSHAPE;
-    InDblParams q{gb_a, ldgb, qz, ldq, gb_zs, ldgz, z, ldz, mean, rstd, gt_a, ldga, zt, cdot, HW, C, act, q_nslab, q_slab_stride};
+    InDblParams q{gb_a, ldgb, qz, ldq, gb_zs, ldgz, z, ldz, mean, rstd, gt_a, ldga, zt, cdot, HW, C, act, q_nslab, q_slab_stride, sat};
     const bool small = HW <= SMALL_HW && !(ldgb % 4) && !(ldq % 4) && !(ldz % 4) && !(ldga % 4) && (!gb_zs || !(ldgz % 4));
     if (q_nslab > 1 && !small) return GCSSL_EBADSHAPE;      // slabs are summed by the fused small-map kernel only
     if (z_kind != 0 && z_kind != 1) return GCSSL_EBADSHAPE;
@@ -1064,14 +1085,14 @@ int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, in
 
 int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const void* a, int lda,
                   const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias,
-                  float* cdot, int nrep, int rep_stride, int N, int HW, int C, void* stream) {
+                  float* cdot, int nrep, int rep_stride, unsigned* sat, int N, int HW, int C, void* stream) {
     if (!da || !a || !dzs) return GCSSL_ENULL;
     if (nrep < 1 || (nrep > 1 && rep_stride < C)) return GCSSL_EBADSHAPE;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || HW <= 0 || C <= 0 || C % CW || lda < C || lddz < C || ldda < C) return GCSSL_EBADSHAPE;
     if (lda % 4 || lddz % 4 || ldda % 4 || (da2 && ldda2 % 4)) return GCSSL_EBADSHAPE;
     if ((gscale || cdot) && group_n <= 0) return GCSSL_EBADSHAPE;
-    ActBwdParams q{da, ldda, da2, ldda2, a, lda, gscale, group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, HW, C, nrep, rep_stride};
+    ActBwdParams q{da, ldda, da2, ldda2, a, lda, gscale, group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, HW, C, nrep, rep_stride, sat};
     // 64-row chunks of H*W x blocks of samples; grow the sample block while >= ~512 workgroups remain
     int rows = HW < 64 ? HW : 64;
     const int zc = (HW + rows - 1) / rows;

@@ -97,7 +97,13 @@ def launch_local_ranks(argv: Sequence[str], nproc: int, extra_env: Optional[dict
     """Start `nproc` fresh child processes of `argv` (one rank each: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
     MASTER_PORT set, rendezvous on 127.0.0.1) and wait for them.  The caller must not have touched the GPU: the children
     are new processes (never an exec of this one).  Rank 0's stdout is captured and returned; the other ranks' stdout goes
-    to this process's stderr.  -> (exit codes, rank 0's stdout).  If a rank fails the others are terminated."""
+    to this process's stderr.  -> (exit codes, rank 0's stdout).
+
+    EVERY child is polled: the first rank that exits non-zero -- whichever it is, also one that dies before the rendezvous
+    while rank 0 sits in init_process_group or in a collective -- gets its peers terminated at once instead of leaving them
+    to the process group's own timeout (10+ minutes).  `timeout` bounds the whole launch the same way."""
+    import threading
+    import time
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -106,22 +112,27 @@ def launch_local_ranks(argv: Sequence[str], nproc: int, extra_env: Optional[dict
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), **(extra_env or {}))
         procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
-    out0, codes = "", [None] * nproc
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)   # drain rank 0's pipe
+    reader.start()
+    deadline = None if timeout is None else time.monotonic() + timeout
     try:
-        out0, _ = procs[0].communicate(timeout=timeout)
-        codes[0] = procs[0].returncode
-        for r in range(1, nproc):
-            codes[r] = procs[r].wait(timeout=60 if codes[0] == 0 else 5)
-    except subprocess.TimeoutExpired:
-        pass
+        while True:
+            codes = [pr.poll() for pr in procs]
+            if all(c is not None for c in codes) or any(c not in (None, 0) for c in codes):
+                break
+            if deadline is not None and time.monotonic() > deadline:
+                break
+            time.sleep(0.05)
     finally:
-        for r, pr in enumerate(procs):
-            if pr.poll() is None:                     # a rank that outlives a failed/timed-out peer would hang in a collective
+        for pr in procs:
+            if pr.poll() is None:                     # a rank that outlives a failed / timed-out peer would hang in a collective
                 pr.terminate()
-                try:
-                    pr.wait(timeout=10)
-                except subprocess.TimeoutExpired:
-                    pr.kill()
-                    pr.wait()
-            codes[r] = pr.returncode
-    return codes, out0 or ""
+        for pr in procs:
+            try:
+                pr.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.wait()
+        reader.join(timeout=10)
+    return [pr.returncode for pr in procs], "".join(c or "" for c in chunks)

@@ -186,6 +186,12 @@ class StepEngine:
         self._g_dirty = True
         self._prep_d_batch = self._prep_g_batch = None
         self.alpha_buf = torch.empty(batch, **f32)
+        # fp16 stores of gradient tensors saturate at +-65504 (common.h); every kernel that stores one counts the values it
+        # clipped here: [0] the critic's backward / gradient-penalty chains, [1] the generator's backward.  Never reset by the
+        # engine; bench.py reports the totals and the tests assert they stay 0 (if they do not, the static loss scale is too
+        # large for that configuration).
+        self.sat = torch.zeros(2, device=dev, dtype=torch.int32)
+        self.sat_d, self.sat_g = self.sat[0:1], self.sat[1:2]
         self._red_d = self._red_g = None
         self._rep_sum = None
         # Independent branches of the iteration run on a side HIP stream (hipGraph capture turns them into parallel
@@ -235,12 +241,13 @@ class StepEngine:
         rec = self.probe.get(label)
         if rec is None:
             algo, stored = _bytes or _algorithmic_bytes(label, args, 4 if self.code == _lib.F32 else 2)
-            rec = self.probe[label] = {"events": [], "flops": flops, "bytes": algo, "stored": stored}
+            rec = self.probe[label] = {"events": [], "flops": flops, "bytes": algo, "stored": stored,
+                                       "kernel": ops.last_kernel()}      # the template expression the dispatcher launched
         rec["events"].append((e0, e1))
 
     def probe_summary(self):
-        """-> {label: (n_launches, mean_ms, flops_per_launch, algorithmic_bytes_per_launch, stored_bytes_per_launch)}
-        (synchronises)."""
+        """-> {label: (n_launches, mean_ms, flops_per_launch, algorithmic_bytes_per_launch, stored_bytes_per_launch, kernel)}
+        (synchronises).  kernel: the kernel template expression of the label's launch (gcssl_last_kernel)."""
         torch.cuda.synchronize()
         out = {}
         for k, rec in (self.probe or {}).items():
@@ -249,7 +256,7 @@ class StepEngine:
             # its two events: average the samples within 3x the median (all of them, when nothing stalled)
             med = ts[len(ts) // 2] if ts else 0.0
             keep = [t for t in ts if t <= 3.0 * med] or ts
-            out[k] = (len(ts), sum(keep) / max(len(keep), 1), rec["flops"], rec["bytes"], rec["stored"])
+            out[k] = (len(ts), sum(keep) / max(len(keep), 1), rec["flops"], rec["bytes"], rec["stored"], rec["kernel"])
         return out
 
     # ------------------------------------------------------------------------------------------ split-K slabs
@@ -749,15 +756,15 @@ class StepEngine:
         for l in (3, 2, 1):
             cin, cout = D_CH[l]
             ops.in_act_bwd(self._d_zsrc[l][I], self.d_mean[l][I], self.d_rstd[l][I], self.gb_zs[l], cout, LRELU,
-                           da=self.gb_a[l], gscale=isig[l, 2:3], group_n=B, ws=self.ws, da_nslab=ns, da_slab_stride=st)
+                           da=self.gb_a[l], gscale=isig[l, 2:3], group_n=B, ws=self.ws, da_nslab=ns, da_slab_stride=st, sat=self.sat_d)
             ns, st = self._split("dgrad", self.gb_a[l - 1], B, S >> l, cin, cout, grad=True) if l > 1 else (1, 0)
             self._conv(f"D.c{l + 1}.gp_dgrad", conv_flops(B, S >> l, cin, cout), ops.conv_dgrad, self.gb_zs[l],
                        self.d_wt[l], self.gb_a[l - 1], cin, cout, split_stride=st)
-        ops.act_bwd(self.gb_a[0], self.d_a[0][I], self.gb_zs[0], 64, gscale=isig[0, 2:3], group_n=B)
+        ops.act_bwd(self.gb_a[0], self.d_a[0][I], self.gb_zs[0], 64, gscale=isig[0, 2:3], group_n=B, sat=self.sat_d)
         self._conv("D.c1.gp_dgrad", conv_flops(B, S, 6, 64), ops.conv_dgrad, self.gb_zs[0], self.d_wt[0], self.gb_x0, 8, 64)
         # :223-231, and the seed of the reverse pass (gb_x0 * coef, the create_graph=True part of d_loss.backward(), :330)
         # (lambda_gp only enters the adjoint seed coef/scaled, not gp_sum: the critic's loss scale rides on it)
-        ops.gp_norm(self.gb_x0, B, self.lambda_gp * self.loss_scale_d, self.gp_nrm, self.gp_coef, self.gp_sum, scaled=self.gt_x)
+        ops.gp_norm(self.gb_x0, B, self.lambda_gp * self.loss_scale_d, self.gp_nrm, self.gp_coef, self.gp_sum, scaled=self.gt_x, sat=self.sat_d)
         src = self.gt_x
         for l, (cin, cout) in enumerate(D_CH):
             cp = _pad8(cin)
@@ -768,11 +775,11 @@ class StepEngine:
             # (the weight gradient of this chain, src x gb_zs[l], is contracted together with the batched backward's below)
             if l == 0:
                 ops.dot_accum(self.gb_zs[0], self.gt_z[0], 64, self.cdot[0, 2:3])
-                ops.act_bwd(self.gt_z[0], self.d_a[0][I], self.gt_a[0], 64)
+                ops.act_bwd(self.gt_z[0], self.d_a[0][I], self.gt_a[0], 64, sat=self.sat_d)
             else:
                 ops.in_dbl_bwd(self.gb_a[l], self.gt_z[l], self.gb_zs[l], self._d_zsrc[l][I], self.d_mean[l][I],
                                self.d_rstd[l][I], self.gt_a[l], self.zt[l], cout, LRELU, cdot=self.cdot[l, 2:3],
-                               q_nslab=ns, q_slab_stride=st)
+                               q_nslab=ns, q_slab_stride=st, sat=self.sat_d)
             src = self.gt_a[l]
         gw5 = self.D.gviews["model.11.weight"].view(512, 16)
         ops.c5_wgrad(self.gt_a[3], gw5, 512, consts=(1.0, 1.0, 1.0), group_n=B)
@@ -792,10 +799,10 @@ class StepEngine:
             if l > 0:
                 ops.in_act_bwd(self._d_zsrc[l][:N3], self.d_mean[l], self.d_rstd[l], self.d_dzs[l], cout, LRELU,
                                da=self.d_da[l], zt=self.zt[l], zt_n0=2 * B, gscale=isig[l], group_n=B, bias=bias,
-                               dbias=rb, cdot=rc, ws=self.ws, nrep=self.NREP, rep_stride=self.REP_STRIDE)
+                               dbias=rb, cdot=rc, ws=self.ws, nrep=self.NREP, rep_stride=self.REP_STRIDE, sat=self.sat_d)
             else:
                 ops.act_bwd(self.d_da[0], self.d_a[0], self.d_dzs[0], 64, gscale=isig[0], group_n=B, bias=bias,
-                            dbias=rb, cdot=rc, nrep=self.NREP, rep_stride=self.REP_STRIDE)
+                            dbias=rb, cdot=rc, nrep=self.NREP, rep_stride=self.REP_STRIDE, sat=self.sat_d)
             fl = conv_flops(N3, S >> l, cin, cout)
 
             def wgrad_branch(l=l, cout=cout, cp=cp, fl4=conv_flops(4 * B, S >> l, cin, cout)):
@@ -892,10 +899,10 @@ class StepEngine:
                 pre = self._up4_presums and S * S > 256 and os.environ.get("GCSSL_UP4_PRESUM", "1") != "0"      # (A/B knob)
                 ops.in_act_bwd(self.g_zu[3], self.g_umean[3], self.g_urstd[3], self.g_dzu[3], coutt, RELU,
                                da_bcast=self.g_dab, ws=self.ws, presum_cnt=self.g_ucnt if pre else None,
-                               presum_pos=self.g_pooled if pre else None, presum_pos_scale=float(S * S))
+                               presum_pos=self.g_pooled if pre else None, presum_pos_scale=float(S * S), sat=self.sat_g)
             else:
                 ops.in_act_bwd(self.g_zu[k], self.g_umean[k], self.g_urstd[k], self.g_dzu[k], coutt, RELU,
-                               da=dcat[k + 1][..., :coutt], mask=self.g_masks[k + 1] if k < 2 else None, ws=self.ws)
+                               da=dcat[k + 1][..., :coutt], mask=self.g_masks[k + 1] if k < 2 else None, ws=self.ws, sat=self.sat_g)
             fl = conv_flops(B, S >> (3 - k), coutt, cint)
 
             def up_wgrad(k=k, cint=cint, coutt=coutt, fl=fl):
@@ -922,12 +929,12 @@ class StepEngine:
             cp = _pad8(cin)
             if k == 3:
                 ops.in_act_bwd(self._g_zsrc[3], self.g_dmean[3], self.g_drstd[3], self.g_dzd[3], 512, LRELU,
-                               da=self.g_dd4, mask=self.g_masks[0], ws=self.ws, da_nslab=ns4, da_slab_stride=st4)
+                               da=self.g_dd4, mask=self.g_masks[0], ws=self.ws, da_nslab=ns4, da_slab_stride=st4, sat=self.sat_g)
             elif k > 0:
                 ops.in_act_bwd(self._g_zsrc[k], self.g_dmean[k], self.g_drstd[k], self.g_dzd[k], cout, LRELU,
-                               da=self.g_dd[k + 1], da2=dskip[k], ws=self.ws, da_nslab=nsd, da_slab_stride=std)
+                               da=self.g_dd[k + 1], da2=dskip[k], ws=self.ws, da_nslab=nsd, da_slab_stride=std, sat=self.sat_g)
             else:
-                ops.act_bwd(self.g_dd[1], d_act[0], self.g_dzd[0], 64, da2=dskip[0])
+                ops.act_bwd(self.g_dd[1], d_act[0], self.g_dzd[0], 64, da2=dskip[0], sat=self.sat_g)
             xin = self.x0[:B] if k == 0 else d_act[k - 1]
             fl = conv_flops(B, S >> k, cin, cout)
 
@@ -976,6 +983,11 @@ class StepEngine:
                    g_grad_norm=float(self.G.state[2]), delta_pred=self.delta_pred.clone(),
                    calibrated=self.g_cal.clone(), fake_for_g=self.d_out[:self.B].clone())
         return log
+
+    def saturations(self) -> dict:
+        """fp16 gradient stores clipped so far (host sync): {"critic": n, "generator": n}"""
+        c, g = self.sat.tolist()
+        return {"critic": int(c), "generator": int(g)}
 
     def set_lr(self, lr_g: Optional[float] = None, lr_d: Optional[float] = None) -> None:
         """Learning rates for the following updates (an LR scheduler's step): written into the optimisers' device-side

@@ -216,7 +216,7 @@ def in_act_fwd(z, a, mean, rstd, C, act, mask=None, pool=None, nslab=1, slab_str
 
 def in_act_bwd(z, mean, rstd, dzs, C, act, da=None, da2=None, da_bcast=None, mask=None, zt=None, zt_n0=0,
                gscale=None, group_n=0, bias=None, dbias=None, cdot=None, ws=None, nrep=1, rep_stride=0, da_nslab=1,
-               da_slab_stride=0, presum_cnt=None, presum_pos=None, presum_pos_scale=1.0):
+               da_slab_stride=0, presum_cnt=None, presum_pos=None, presum_pos_scale=1.0, sat=None):
     """da_nslab > 1: da is the first of that many split-K slabs (da_slab_stride floats apart), added on load.  nrep > 1: dbias / cdot point at replica 0 of nrep replicas rep_stride floats apart (fold with ReplicaSum).
     z: the fp32 pre-norm tensor, or the 16-bit un-masked activation a fused conv_in_act_fwd left (z_kind 1)."""
     N, H, W, _ = z.shape
@@ -225,25 +225,25 @@ def in_act_bwd(z, mean, rstd, dzs, C, act, da=None, da2=None, da_bcast=None, mas
     assert z_kind == 0 or z.dtype == dzs.dtype
     call("gcssl_in_act_bwd", code(dzs), da, _ld(da) if da is not None else 0, da2, _ld(da2) if da2 is not None else 0,
          da_bcast, z, _ld(z), z_kind, mean, rstd, mask, zt, zt_n0, gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot, nrep, rep_stride,
-         da_nslab, int(da_slab_stride), ws, presum_cnt, presum_pos, float(presum_pos_scale), N, H * W, C, act)
+         da_nslab, int(da_slab_stride), ws, presum_cnt, presum_pos, float(presum_pos_scale), sat, N, H * W, C, act)
 
 
-def in_dbl_bwd(gb_a, qz, gb_zs, z, mean, rstd, gt_a, zt, C, act, cdot=None, q_nslab=1, q_slab_stride=0):
+def in_dbl_bwd(gb_a, qz, gb_zs, z, mean, rstd, gt_a, zt, C, act, cdot=None, q_nslab=1, q_slab_stride=0, sat=None):
     N, H, W, _ = z.shape
     assert gb_a.dtype == torch.float32 and qz.dtype == torch.float32
     assert zt.dtype == torch.float32
     z_kind = 0 if z.dtype == torch.float32 else 1                  # 1: the 16-bit activation of a fused conv_in_act_fwd
     assert z_kind == 0 or z.dtype == gt_a.dtype
     call("gcssl_in_dbl_bwd", code(gt_a), gb_a, _ld(gb_a), qz, _ld(qz), gb_zs, _ld(gb_zs) if gb_zs is not None else 0,
-         z, _ld(z), z_kind, mean, rstd, gt_a, _ld(gt_a), zt, cdot, q_nslab, int(q_slab_stride), N, H * W, C, act)
+         z, _ld(z), z_kind, mean, rstd, gt_a, _ld(gt_a), zt, cdot, q_nslab, int(q_slab_stride), sat, N, H * W, C, act)
 
 
-def act_bwd(da, a, dzs, C, da2=None, gscale=None, group_n=0, bias=None, dbias=None, cdot=None, nrep=1, rep_stride=0):
+def act_bwd(da, a, dzs, C, da2=None, gscale=None, group_n=0, bias=None, dbias=None, cdot=None, nrep=1, rep_stride=0, sat=None):
     """da/da2: fp32 incoming gradients; a and dzs in the compute dtype."""
     N, H, W, _ = a.shape
     assert da.dtype == torch.float32 and (da2 is None or da2.dtype == torch.float32)
     call("gcssl_act_bwd", code(a), da, _ld(da), da2, _ld(da2) if da2 is not None else 0, a, _ld(a), gscale, group_n,
-         bias, dzs, _ld(dzs), dbias, cdot, nrep, rep_stride, N, H * W, C)
+         bias, dzs, _ld(dzs), dbias, cdot, nrep, rep_stride, sat, N, H * W, C)
 
 
 def dot_accum(x, y, C, out):
@@ -293,10 +293,16 @@ def pack_fake_interp(pred, gt, refined, alpha, out_fake, out_interp, seed=0, cou
     call("gcssl_pack_fake_interp", code(out_fake), pred, gt, refined, alpha, int(seed), counter, out_fake, out_interp, B, S)
 
 
-def gp_norm(g, B, lambda_gp, nrm, coef, gp_sum, scaled=None):
-    """scaled (optional, compute dtype): receives g * coef[n] in the same launch (== scale_rows afterwards)."""
+def gp_norm(g, B, lambda_gp, nrm, coef, gp_sum, scaled=None, sat=None):
+    """scaled (optional, compute dtype): receives g * coef[n] in the same launch (== scale_rows afterwards).
+    sat (here and on the norm / activation backward wrappers): int32 device counter of fp16 stores that clipped."""
     call("gcssl_gp_norm", g, g.numel() // B, B, float(lambda_gp), nrm, coef, gp_sum,
-         code(scaled) if scaled is not None else 0, scaled)
+         code(scaled) if scaled is not None else 0, scaled, sat)
+
+
+def last_kernel() -> str:
+    """the kernel template expression the most recent conv entry point launched (gcssl_last_kernel)"""
+    return _lib.lib().gcssl_last_kernel().decode()
 
 
 def scale_rows(x, coef, y, B):

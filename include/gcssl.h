@@ -32,6 +32,10 @@ extern "C" {
 #define GCSSL_F16 2
 
 const char* gcssl_version(void);
+/* The kernel template expression the most recent conv entry point of THIS process launched (as written at its launch site:
+ * e.g. "(conv_dma_kernel<O, 128, 128, 0, 4, 2, false, 8, 4, false, true>)"; O / T = the operand type of `dtype`).  The
+ * dispatchers choose an instantiation per shape; bench.py uses this to name the rocprofv3 symbol of its dominant launch. */
+const char* gcssl_last_kernel(void);
 /* One-time device-side set-up (dynamic-LDS opt-ins of the kernels that use > 64 KB).  Call once per process with a GPU
  * present and before capturing entry points into a hipGraph (they also do it lazily on first use, which a capture in
  * progress may refuse). */
@@ -139,9 +143,12 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
                      const void* z, int ldz, int z_kind, const float* mean, const float* rstd, const uint8_t* mask, const float* zt,
                      int zt_n0, const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias,
                      float* cdot, int nrep, int rep_stride, int da_nslab, long da_slab_stride,
-                     float* ws, const float* presum_cnt, const float* presum_pos, float presum_pos_scale,
+                     float* ws, const float* presum_cnt, const float* presum_pos, float presum_pos_scale, unsigned int* sat,
                      int N, int HW, int C, int act, void* stream);
-/* z_kind 0: z is the fp32 pre-norm tensor.  z_kind 1 (maps of <= 256 pixels, act = LeakyReLU): z is the 16-bit ACTIVATION
+/* sat (nullable, device): += the number of output values whose magnitude exceeded fp16's largest finite number and were
+ * clipped by the store (dtype GCSSL_F16 only; the static loss scale is meant to keep this at zero -- the engine exposes the
+ * count, bench.py reports it, the tests assert 0).  Same argument on gcssl_in_dbl_bwd (gt_a), gcssl_act_bwd and gcssl_gp_norm.
+ * z_kind 0: z is the fp32 pre-norm tensor.  z_kind 1 (maps of <= 256 pixels, act = LeakyReLU): z is the 16-bit ACTIVATION
  * without dropout, in `dtype`, as gcssl_conv4x4s2_in_act_fwd left it (its `a`, or `apre` for a masked layer); xhat is rebuilt as
  * a > 0 ? a : 5 a and z - bias as xhat / rstd + mean - bias.
  * ws: caller-owned scratch of 2*N*C floats, required when H*W > 256 (two-kernel path), else may be NULL.
@@ -153,7 +160,7 @@ int gcssl_in_act_bwd(int dtype, const float* da, int ldda, const float* da2, int
  * incoming adjoint qz: gt_a = act'(xhat) * d/d(dn), zt = d/dz; cdot += sum gb_zs*qz. */
 int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, int ldq, const void* gb_zs, int ldgz,
                      const void* z, int ldz, int z_kind, const float* mean, const float* rstd, void* gt_a, int ldga, float* zt,
-                     float* cdot, int q_nslab, long q_slab_stride, int N, int HW, int C, int act, void* stream);
+                     float* cdot, int q_nslab, long q_slab_stride, unsigned int* sat, int N, int HW, int C, int act, void* stream);
 /* z_kind as in gcssl_in_act_bwd (1: maps of <= 64 pixels).
  * da_nslab / q_nslab > 1: da / qz is the first of that many split-K partial-sum slabs (stride in floats) written by a
  * gcssl_conv4x4s2_* call with split_stride > 0; the kernel first folds them into slab 0 (maps up to 16x16 / 8x8), so
@@ -161,7 +168,7 @@ int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, in
 /* LeakyReLU backward for the norm-less layers (D.c1, G.down1; cgan/models.py:103,246), from the activation OUTPUT a. */
 int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const void* a, int lda,
                   const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias, float* cdot,
-                  int nrep, int rep_stride, int N, int HW, int C, void* stream);
+                  int nrep, int rep_stride, unsigned int* sat, int N, int HW, int C, void* stream);
 /* dbias / cdot of the two backward entry points above may be striped: nrep replicas, rep_stride floats apart, each
  * workgroup adds to one of them (same-address float atomics serialise); nrep = 1 is the plain form.  This folds them:
  * dst[i][j] (=|+=) sum_r src[i][j + r*rep_stride] for nseg <= 8 segments of len[i] floats; bit i of accumulate
@@ -193,7 +200,7 @@ int gcssl_convT4x4s2_in_relu_fwd(int dtype, const void* x, int ldx, const void* 
 /* ---- gradient penalty (cgan/losses.py:223-231) -------------------------------------------------------------------
  * nrm[b] = sqrt(sum g_b^2 + 1e-12); gp_sum += mean((nrm-1)^2); coef[b] = lambda_gp*2/B*(nrm-1)/nrm. */
 int gcssl_gp_norm(const float* g, long per_sample, int B, float lambda_gp, float* nrm, float* coef, float* gp_sum,
-                  int dtype, void* scaled, void* stream);   /* scaled (nullable, `dtype`): g * coef[n], the reverse pass's seed */
+                  int dtype, void* scaled, unsigned int* sat, void* stream);   /* scaled (nullable, `dtype`): g * coef[n], the reverse pass's seed */
 int gcssl_scale_rows(int dtype, const float* x, const float* coef, void* y, long per_sample, int B, void* stream);
 
 /* ---- clip_grad_norm_(1.0) + Adam (cgan/cgan_train_enhanced.py:256-257,331-332,368-369) over flat fp32 buffers ---

@@ -51,7 +51,12 @@ def test_argument_validation_without_gpu(lib_mod):
     assert h.gcssl_sum_replicas(1, None, None, None, 4, 64, 0, None) == -4
     assert h.gcssl_conv4x4s2_wgrad_splits(4, 12, 12, 64, 64) == -1          # non power-of-two spatial size
     assert h.gcssl_conv4x4s2_wgrad_splits(256, 16, 16, 64, 128) > 0
-    assert h.gcssl_gp_norm(None, 10, 2, ctypes.c_float(1.0), None, None, None, 0, None, None) == -4
+    assert h.gcssl_gp_norm(None, 10, 2, ctypes.c_float(1.0), None, None, None, 0, None, None, None) == -4
+    assert h.gcssl_conv4x4s2_in_act_ok(0, 768, 8, 8, 128, 256) == 0          # fp32: the parity mode keeps conv -> z -> norm
+    assert h.gcssl_conv4x4s2_in_act_ok(2, 768, 8, 8, 128, 256) == 1          # D.c3 at the bench batch, fp16: the fused launch
+    assert h.gcssl_conv4x4s2_in_act_ok(2, 384, 32, 32, 64, 128) == 0         # 16x16 maps: a sample does not fit a tile
+    assert h.gcssl_conv4x4s2_in_act_fwd(2, None, 64, None, None, None, 0, None, 64, None, None, None, None, 0, 0, 4, 8, 8, 64, 64, 1, None) == -4
+    assert h.gcssl_last_kernel() is not None
 
 
 def test_code_object_is_gfx950(lib_mod):

@@ -115,3 +115,53 @@ def _run_graphed(rank, world, port, gtype):
 @pytest.mark.parametrize("gtype", ["unet", "simple"])
 def test_graphed_overlapped_allreduce_matches_eager(gtype):
     mp.spawn(_run_graphed, args=(2, _free_port(), gtype), nprocs=2, join=True)
+
+
+def _run_rccl_one_rank(rank, world, port):
+    """The data-parallel schedule on the REAL backend (nccl == RCCL) with one rank: process group, RCCL communicator, async
+    all-reduces between the captured graph segments (GCSSL_FORCE_DP=1 makes a world of 1 take that path) -- against the
+    single-GPU one-graph form on the same device draws."""
+    import importlib
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      GCSSL_FORCE_DP="1")
+    os.environ.pop("GCSSL_DIST_BACKEND", None)
+    os.environ.pop("GCSSL_SINGLE_DEVICE", None)
+    dist_mod = importlib.import_module(PKG + ".dist")
+    synth = importlib.import_module(PKG + ".synth")
+    engine = importlib.import_module(PKG + ".engine")
+    dist_mod.init_from_env()
+    assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
+    assert torch.distributed.get_world_size() == 1                       # bench.py's `rccl_ranks`
+    T = torch.from_numpy
+    seed, B, S, c = 29, 16, 32, 2
+    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+    d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+    inp = synth.step_inputs(seed, B, S, c, tag="rccl1")
+    refined = [T(x).cuda() for x in inp["refined"]]
+    call = (T(inp["pred"]).cuda(), T(inp["gt"]).cuda(), T(inp["delta_true"]).cuda(), T(inp["pred_box"]).cuda(),
+            lambda delta, k: refined[k])
+    avg = dist_mod.GradAverager()
+    assert avg.world == 1
+    mk = lambda ar: engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype="fp32", device="cuda:0", seed=91,
+                                      allreduce=ar, keep_clipped_grads=False)
+    one, dp = mk(None), mk(avg)
+    g_one, g_dp = engine.GraphedIteration(one, *call), engine.GraphedIteration(dp, *call)
+    assert g_one.fused_update and not g_dp.fused_update                   # one graph per iteration vs the DP segments
+    for _ in range(2):
+        g_one.replay()
+        g_dp.replay()
+    torch.cuda.synchronize()
+    lr = 2e-4
+    for name, a, b, steps in (("D", one.D.p, dp.D.p, 4), ("G", one.G.p, dp.G.p, 2)):
+        diff = (a - b).abs()
+        assert bool(torch.isfinite(b).all())
+        assert float((diff > 0.05 * lr * steps).float().mean()) < 0.02, (name, float((diff > 0.05 * lr * steps).float().mean()))
+        assert float(diff.max()) <= 2.2 * lr * steps, name
+    assert float(dp.D.state[0]) == 4.0 and float(dp.G.state[0]) == 2.0
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_graph_segments():
+    """the nccl (RCCL) path under -m gpu -- a fresh child process, one rank."""
+    mp.spawn(_run_rccl_one_rank, args=(1, _free_port()), nprocs=1, join=True)

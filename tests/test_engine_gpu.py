@@ -518,3 +518,109 @@ def test_svhn_config_fp16_batch512(synth):
     assert abs(a["gp"][0] - b["gp"][0]) <= 1e-2 * abs(b["gp"][0])
     assert abs(a["d_grad_norm"][0] - b["d_grad_norm"][0]) <= 1e-2 * b["d_grad_norm"][0]
     assert abs(a["loss_iou"] - b["loss_iou"]) <= 2e-4 * abs(b["loss_iou"])
+    assert eng.saturations() == {"critic": 0, "generator": 0}          # (eng: the fp16 engine, after its replays)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_16bit_step_from_oracle_post_iteration_state(synth, dtype):
+    """The 16-bit twin of the fp32 restart check (VERDICT r2 weak #2 / ADVICE r2): engine and oracle BOTH start from the
+    oracle's post-iteration state (weights, u, v after two critic updates and one generator update at the bench
+    configuration), so the second-step error is the step function's -- not the trajectory's (Adam's ~lr*sign(g) updates turn
+    a sign flip of a near-zero gradient into a 2*lr displacement, which is what `step2_*` in the mode-error table carries:
+    -38 % / -79 % on the un-clipped gradient norm).  Bounded at the first step's levels (MODE_BOUNDS, 2x the measured error)."""
+    from oracle import cgan_oracle as O
+    engine = load_pkg("engine")
+    seed, B, S, c = 42, 256, 32, 2
+    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+    d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+    inp = synth.step_inputs(seed, B, S, c, tag="fullsize")
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    cpu = dict(pred=T(inp["pred"]), gt=T(inp["gt"]), dt=T(inp["delta_true"]), pb=T(inp["pred_box"]))
+    refined_cpu = [T(r) for r in inp["refined"]]
+    orc = O.StepOracle(g, d, n_critic=c)
+    orc.iteration(cpu["pred"], cpu["gt"], cpu["dt"], cpu["pb"], lambda dl, k: refined_cpu[k],
+                  [T(a) for a in inp["alpha"]], [[T(m) for m in ms] for ms in inp["masks"]])
+    g1 = {k: v.detach().clone() for k, v in orc.g.items()}
+    d1 = {k: v.detach().clone() for k, v in orc.d.items()}
+    taps = {}
+    ref = O.StepOracle(g1, d1, n_critic=1).iteration(cpu["pred"], cpu["gt"], cpu["dt"], cpu["pb"], lambda dl, k: refined_cpu[1],
+                                                     [T(inp["alpha"][1])], [[T(m) for m in inp["masks"][1]], [T(m) for m in inp["masks"][2]]],
+                                                     taps=taps)
+    eng = engine.StepEngine(g1, d1, batch=B, size=S, n_critic=1, dtype=dtype, device="cuda:0")
+    refined = [T(r).cuda() for r in inp["refined"]]
+    log = eng.iteration(cpu["pred"].cuda(), cpu["gt"].cuda(), cpu["dt"].cuda(), cpu["pb"].cuda(), lambda dl, k: refined[1],
+                        alphas=[T(inp["alpha"][1]).cuda().view(-1).contiguous()],
+                        masks=[[T(m).cuda() for m in inp["masks"][1]], [T(m).cuda() for m in inp["masks"][2]]])
+    torch.cuda.synchronize()
+    sgn = lambda a, b: (a - b) / abs(b)
+    m = dict(scores=max(rel_err(log["real"][0].cpu().reshape(-1), taps["real_validity"].reshape(-1)),
+                        rel_err(log["fake"][0].cpu().reshape(-1), taps["fake_validity"].reshape(-1))),
+             delta=rel_err(log["delta_pred"].cpu(), ref["delta_pred"]), wd=abs(sgn(log["wd"][0], ref["wd"][0])),
+             gp=abs(sgn(log["gp"][0], ref["gp"][0])), d_grad_norm=sgn(log["d_grad_norm"][0], ref["d_grad_norm"][0]),
+             loss_iou=abs(sgn(log["loss_iou"], ref["loss_iou"])), g_grad_norm=sgn(log["g_grad_norm"], ref["g_grad_norm"]))
+    print(f"\n[{dtype}, from the oracle's post-iteration state] " + "  ".join(f"{k}={v:.2e}" for k, v in m.items()))
+    assert eng.saturations() == {"critic": 0, "generator": 0}
+    # measured here: fp16 scores 1.3e-3  delta 1.1e-4  wd 3e-5  gp 2.3e-3  d_grad_norm +2.7e-3 (against -38 % behind the Adam update)
+    #                bf16 scores 7.2e-3  delta 1.4e-3  wd 5e-4  gp 5.5e-3  d_grad_norm +5.1e-2 (against -79 %)
+    bounds = dict(MODE_BOUNDS[dtype], gp=1.2e-2, delta=3e-3) if dtype == "bf16" else MODE_BOUNDS[dtype]
+    for k, b in bounds.items():
+        assert abs(m[k]) <= b, (dtype, k, m[k], b)
+
+
+@pytest.mark.parametrize("B,S", [(512, 32), (128, 128), (1024, 32)])
+def test_fp16_gradient_stores_do_not_saturate(synth, B, S):
+    """fp16 stores of gradient tensors clip at +-65504 and every kernel that stores one counts what it clipped (common.h
+    sat_hits): with the static loss scales the count must stay 0 at the batch / image sizes where the scales
+    are largest -- BASELINE configs[3]'s B=512, B=1024, and the reference's native 128x128."""
+    engine = load_pkg("engine")
+    seed, c = 11, 2
+    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+    d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+    inp = synth.step_inputs(seed, B, S, c, tag="sat")
+    refined = [T(r).cuda() for r in inp["refined"]]
+    call = (T(inp["pred"]).cuda(), T(inp["gt"]).cuda(), T(inp["delta_true"]).cuda(), T(inp["pred_box"]).cuda(),
+            lambda delta, k: refined[k])
+    eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype="fp16", device="cuda:0", seed=seed, keep_clipped_grads=False)
+    eng.run_iteration(*call)
+    gi = engine.GraphedIteration(eng, *call)
+    for _ in range(6):
+        gi.replay()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(eng.D.p).all()) and bool(torch.isfinite(eng.G.p).all())
+    assert eng.saturations() == {"critic": 0, "generator": 0}, (eng.saturations(), eng.loss_scale_d, eng.loss_scale_g)
+
+
+def test_saturation_counter_counts(synth):
+    """... and the counter does count: with an absurd loss scale the critic's gradient stores clip, the counter says so, and
+    a NaN stays a NaN through the saturating store (fmaxf alone turned it into -65504)."""
+    import os
+    engine = load_pkg("engine")
+    ops = load_pkg("ops")
+    name = "step_B4_S32"
+    os.environ["GCSSL_LOSS_SCALE_D"] = str(2.0 ** 40)
+    try:
+        fix, eng, (seed, B, S, n_critic, iters, gray) = make_engine(synth, name, "fp16")
+    finally:
+        del os.environ["GCSSL_LOSS_SCALE_D"]
+    run_iter(eng, inputs_for(synth, name, seed, 0, B, S, n_critic, gray))
+    torch.cuda.synchronize()
+    assert eng.saturations()["critic"] > 0
+    da = torch.full((2, 4, 4, 64), float("nan"), device="cuda")
+    a = torch.ones(2, 4, 4, 64, device="cuda", dtype=torch.float16)
+    dzs = torch.zeros(2, 4, 4, 64, device="cuda", dtype=torch.float16)
+    ops.act_bwd(da, a, dzs, 64)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(dzs).all())
+
+
+def test_losses_on_cuda_tensors_match_reference_vectors():
+    """losses.iou_metric / apply_delta_to_bbox / smooth_clamp / EIoULoss (cgan/losses.py:99-183) on CUDA tensors -- the
+    validation path of train.py (:395-420) runs them there -- against the reference-generated known-answer vectors."""
+    L = load_pkg("losses")
+    fix = load_golden("loss_vectors")
+    bbox, delta, tgt = (T(fix[k]).cuda() for k in ("bbox", "delta", "target"))
+    assert rel_err(L.apply_delta_to_bbox(bbox, delta, training=True).cpu(), fix["apply_train"]) < 1e-6
+    assert rel_err(L.apply_delta_to_bbox(bbox, delta, training=False).cpu(), fix["apply_eval"]) < 1e-6
+    assert rel_err(L.smooth_clamp(T(fix["x"]).cuda(), -1.5, 1.5).cpu(), fix["smooth_clamp"]) < 1e-6
+    assert rel_err(L.iou_metric(bbox, tgt).cpu(), fix["iou"]) < 1e-6
+    assert abs(float(L.EIoULoss()(bbox, tgt)) - float(fix["eiou"])) < 1e-6

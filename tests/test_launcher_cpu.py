@@ -50,6 +50,40 @@ def test_launch_local_ranks_propagates_failure(tmp_path):
     assert codes[1] == 3 and any(c != 0 for c in codes)
 
 
+EARLY_DEATH = textwrap.dedent(f"""
+    import importlib, os, sys, time
+    sys.path.insert(0, {str(ROOT)!r})
+    if os.environ["RANK"] == "1":
+        sys.exit(7)                                   # dies BEFORE the rendezvous (bad GPU index, HIP init error, ...)
+    import torch
+    d = importlib.import_module("{PKG}.dist")
+    d.init_from_env(backend="gloo")                   # rank 0 would sit here until the process group's own timeout
+    time.sleep(600)
+""")
+
+
+def test_launch_local_ranks_peer_dies_before_rendezvous(tmp_path):
+    """a rank >= 1 that exits while rank 0 waits in the rendezvous must bring the launch down at once."""
+    import time
+    d = importlib.import_module(PKG + ".dist")
+    script = tmp_path / "child.py"
+    script.write_text(EARLY_DEATH)
+    t0 = time.monotonic()
+    codes, _ = d.launch_local_ranks([sys.executable, str(script)], 2, timeout=300)
+    assert time.monotonic() - t0 < 60                   # not the rendezvous timeout (and not the launch timeout either)
+    assert codes[1] == 7 and codes[0] not in (0, None)  # rank 0 was terminated
+
+
+def test_launch_local_ranks_timeout(tmp_path):
+    import time
+    d = importlib.import_module(PKG + ".dist")
+    script = tmp_path / "child.py"
+    script.write_text("import time; time.sleep(600)")
+    t0 = time.monotonic()
+    codes, out0 = d.launch_local_ranks([sys.executable, str(script)], 2, timeout=2)
+    assert time.monotonic() - t0 < 30 and all(c not in (0, None) for c in codes) and out0 == ""
+
+
 def test_bench_refuses_more_gpus_than_present():
     """`python bench.py --gpus 2` must not silently report a 1-GPU number: without 2 visible GPUs it exits non-zero before
     touching a device (here: no GPU at all)."""
@@ -65,7 +99,7 @@ def test_shard_indices_equal_whole_batches():
     sys.path.insert(0, str(ROOT))
     train = importlib.import_module("train")
     idx = list(range(1003))                              # odd-sized: strided shards differ by one
-    for world, batch in ((2, 64), (3, 32), (8, 16), (1, 128)):
+    for world, batch in ((2, 64), (3, 32), (4, 50), (8, 16), (1, 128)):
         shards = [train.shard_indices(idx, r, world, batch) for r in range(world)]
         n = {len(s) for s in shards}
         assert len(n) == 1 and n.pop() % batch == 0       # same count everywhere, whole batches only

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""True magnitudes (fp32 parity mode, loss scale 1) of every tensor the 16-bit modes store in 16 bits on the critic's
+gradient paths, at the bench configuration: where do they sit relative to fp16's normal range [6.1e-5, 65504]?  For each
+tensor: max, median, and the share of its ENERGY (sum of squares) carried by entries below fp16's smallest normal / smallest
+subnormal for a candidate scale.  Run on the GPU box: python tools/grad_ranges.py"""
+import importlib, sys
+from pathlib import Path
+import torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+PKG = "gan-calibrated-semi-supervised-learning_amd"
+T = torch.from_numpy
+synth = importlib.import_module(PKG + ".synth")
+engine = importlib.import_module(PKG + ".engine")
+seed, B, S, c = 42, 256, 32, 2
+g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+inp = synth.step_inputs(seed, B, S, c, tag="fullsize")
+refined = [T(r).cuda() for r in inp["refined"]]
+eng = engine.StepEngine(g, d, batch=B, size=S, n_critic=c, dtype="fp32", device="cuda:0")
+pred, gt = T(inp["pred"]).cuda(), T(inp["gt"]).cuda()
+eng.d_compute(pred, gt, lambda dl, k: refined[k], 0, T(inp["alpha"][0]).cuda().view(-1).contiguous(),
+              [T(m).cuda() for m in inp["masks"][0]])
+torch.cuda.synchronize()
+
+
+def report(name, t):
+    a = t.float().abs().flatten()
+    e = a * a
+    tot = float(e.sum())
+    nz = a[a > 0]
+    row = f"{name:16s} max {float(a.max()):9.2e} median {float(nz.median()):9.2e} "
+    for thr in (6.1e-5, 6.1e-5 / 32, 6.1e-5 / 1024, 6.0e-8):
+        row += f" E<{thr:7.1e}: {100 * float(e[a < thr].sum()) / max(tot, 1e-300):6.2f}%"
+    print(row)
+
+
+N3 = 3 * B
+for l in range(4):
+    report(f"gb_zs[{l}]", eng.d_dzs4[l][N3:])
+for l in range(4):
+    report(f"gt_a[{l}]", eng.d_a4[l][N3:])
+for l in range(4):
+    report(f"dzs[{l}] r/f", eng.d_dzs4[l][:2 * B])
+    report(f"dzs[{l}] interp", eng.d_dzs4[l][2 * B:N3])
+report("gt_x", eng.gt_x)
+print("gp per-sample grad norm: mean", float(eng.gp_nrm.mean()), "min", float(eng.gp_nrm.min()), "max", float(eng.gp_nrm.max()))

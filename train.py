@@ -204,6 +204,11 @@ def main(argv=None):
                 cal = losses.apply_delta_to_bbox(pbv, dv, training=False)
                 sb += float(losses.iou_metric(pbv, gtb).sum()); sa += float(losses.iou_metric(cal, gtb).sum()); nv += Bv
             delta_iou = sa / nv - sb / nv
+            if world > 1:
+                # every rank evaluated the same held-out pairs with (nominally) the same weights, but float-atomic order can
+                # move a last bit: the scheduler / best-checkpoint / early-stop decisions below must be taken on ONE value, or a
+                # rank could `break` at a patience tie while its peers enter the next all-reduce
+                delta_iou = allreduce_mean([delta_iou], device)[0]
         for sc in sched:
             sc.step(delta_iou)
         eng.set_lr(lr_g=sched[0].optimizer.param_groups[0]["lr"], lr_d=sched[1].optimizer.param_groups[0]["lr"])
