@@ -1502,11 +1502,14 @@ __global__ __launch_bounds__(512 + LW * 64) void conv_wgrad_dma_kernel(ConvParam
 //   dw[co][ci][tap] (+)= sum_s slab[s][co][tap][ci]  - sum_k coef[k]*cscale[k] u_k[co] v_k[ci*16+tap]
 // One workgroup = one co x 64 ci x 16 taps: slab reads are coalesced along ci, the [tap][ci] -> [ci][tap] transpose
 // goes through LDS, and the 4-KB output chunk dw[co][ci0..ci0+63][0..15] is written contiguously.
+// coef_rep (nullable): the coefficients' striped partial sums -- nrep replicas rep_stride floats apart (norm.hip
+// replica_offset) -- which are added to coef[k] here, so that no separate fold launch has to run between the backward kernels
+// that produce them and this reduction.
 __device__ __forceinline__ void wgrad_reduce_body(float (*tile)[65], int co, int cx, int zi, int zn,
                                     const float* __restrict__ slab, int nsplit, float* __restrict__ dw,
                                     int Cout, int Cin, int Cin_real, const float* coef, const float* cscale,
                                     const float* u, int ustride, const float* v, int vstride, int nrank,
-                                    int accumulate) {
+                                    int accumulate, const float* coef_rep = nullptr, int nrep = 0, int rep_stride = 0) {
     const int ci0 = cx * 64;
     const int cw = min(64, Cin - ci0);                       // channels in this chunk (8 for the padded first layer)
     const size_t total = (size_t)Cout * 16 * Cin;
@@ -1518,10 +1521,20 @@ __device__ __forceinline__ void wgrad_reduce_body(float (*tile)[65], int co, int
     const int ocil = threadIdx.x >> 2, otp = (threadIdx.x & 3) * 4, oci = ci0 + ocil;
     float uk[4];
     float4 vk[4];
+    float crep[4] = {0.f, 0.f, 0.f, 0.f};
+    if (coef_rep && zi == 0) {                               // (uniform) lane r of every wave fetches replica r; xor-shuffles sum them
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pv = 0.f;
+            if (k < nrank) for (int r = lane; r < nrep; r += 64) pv += coef_rep[(size_t)r * rep_stride + k];
+            crep[k] = wave_sum(pv);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const bool on = k < nrank && zi == 0;
-        uk[k] = on ? coef[k] * (cscale ? cscale[k] : 1.f) * u[(size_t)k * ustride + co] : 0.f;
+        uk[k] = on ? (coef[k] + crep[k]) * (cscale ? cscale[k] : 1.f) * u[(size_t)k * ustride + co] : 0.f;
         vk[k] = (on && ocil < cw && oci < Cin_real) ? *reinterpret_cast<const float4*>(v + (size_t)k * vstride + oci * 16 + otp)
                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -1576,11 +1589,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // up to 8 layers in one launch: the reductions of a whole backward pass are independent of each other and of the
 // dgrad chain, and the small ones (first layers) ride along with the big ones instead of paying a launch each
 struct RedLayer { const float* slab; float* dw; const float* coef; const float* u; const float* v;
-                  int nsplit, Cout, Cin, Cin_real, nrank, zg, blk0; };
-struct RedBatch { RedLayer l[8]; int nl, ustride, vstride, accumulate; };
+                  int nsplit, Cout, Cin, Cin_real, nrank, zg, blk0;
+                  const float* coef_rep; const float* bias_rep; float* dbias; };   // striped sums (replica 0) of coef / of the bias gradient
+struct RedBatch { RedLayer l[8]; int nl, ustride, vstride, accumulate, nrep, rep_stride, bias_blk0; };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedBatch b) {
     __shared__ float tile[16][65];
+    if (b.bias_blk0 >= 0 && (int)blockIdx.x >= b.bias_blk0) {
+        // tail workgroups: dbias[l][c] = sum over the replicas of the backward kernels' striped bias-gradient sums
+        int j = ((int)blockIdx.x - b.bias_blk0) * 256 + threadIdx.x;
+        for (int i = 0; i < b.nl; ++i) {
+            const RedLayer& L = b.l[i];
+            if (!L.bias_rep) continue;
+            if (j < L.Cout) {
+                float sv = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < b.nrep; ++r) sv += L.bias_rep[(size_t)r * b.rep_stride + j];
+                L.dbias[j] = sv;
+                return;
+            }
+            j -= L.Cout;
+        }
+        return;
+    }
     int li = 0;
 #pragma unroll
     for (int i = 1; i < 8; ++i) if (i < b.nl && (int)blockIdx.x >= b.l[i].blk0) li = i;
@@ -1588,7 +1619,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedBatch b) {
     const int local = blockIdx.x - L.blk0, nch = (L.Cin + 63) / 64;
     const int cx = local % nch, co = (local / nch) % L.Cout, zi = local / (nch * L.Cout);
     wgrad_reduce_body(tile, co, cx, zi, L.zg, L.slab, L.nsplit, L.dw, L.Cout, L.Cin, L.Cin_real, L.coef, nullptr, L.u, b.ustride,
-                      L.v, b.vstride, L.nrank, b.accumulate);
+                      L.v, b.vstride, L.nrank, b.accumulate, L.coef_rep, b.nrep, b.rep_stride);
 }
 
 // fp32 PyTorch-layout weight [Cout][Cin][4][4] -> packed operand layouts in T
@@ -1745,7 +1776,7 @@ void launch_dma(const ConvParams& p, dim3 grid, bool smallk, hipStream_t st) {
 
 // several layers per launch (blockIdx.y = layer): the critic is re-packed after every optimiser step
 struct PrepLayer { const float* w; void* wf; void* wt; int Cout, Cin, CinP; };
-struct PrepBatch { PrepLayer l[8]; };
+struct PrepBatch { PrepLayer l[8]; int nl; const float* w5; float* w5p; int C5; };   // w5: the critic head's [1][C5][4][4] -> fp32 [16][C5] (nullable)
 // 16 consecutive fp32 values of an LDS row -> 16 consecutive T in global memory (32 or 64 bytes, vector stores)
 template <typename T> __device__ __forceinline__ void store16(T* dst, const float* src);
 template <> __device__ __forceinline__ void store16<float>(float* dst, const float* src) {
@@ -1774,6 +1805,12 @@ template <> __device__ __forceinline__ void store16<f16_t>(f16_t* dst, const flo
 // multiples of 64, or padded (the first layers), keep the element-wise form: they are tiny.
 template <typename T>
 __global__ __launch_bounds__(256) void prep_weight_batch_kernel(PrepBatch b) {
+    if ((int)blockIdx.y == b.nl) {                           // the extra grid row: the 512 -> 1 head conv's weight (gcssl_prep_c5_weight)
+        if (blockIdx.z) return;
+        for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 16 * b.C5; idx += gridDim.x * 256)
+            b.w5p[idx] = b.w5[(size_t)(idx % b.C5) * 16 + idx / b.C5];
+        return;
+    }
     const PrepLayer L = b.l[blockIdx.y];
     __shared__ float tile[64 * 65];
     const bool tiled = L.Cin % 64 == 0 && L.Cout % 64 == 0 && L.CinP == L.Cin;
@@ -2576,10 +2613,15 @@ int gcssl_wgrad_reduce(const float* slab, int nsplit, float* dw, int Cout, int C
 
 int gcssl_wgrad_reduce_batch(int nl, const float* const* slab, const int* nsplit, float* const* dw, const int* Cout,
                              const int* Cin, const int* Cin_real, const float* const* coef, const float* const* u,
-                             const float* const* v, int ustride, int vstride, int nrank, int accumulate, void* stream) {
+                             const float* const* v, int ustride, int vstride, int nrank, int accumulate,
+                             const float* const* coef_rep, const float* const* bias_rep, float* const* dbias, int nrep,
+                             int rep_stride, void* stream) {
     if (!slab || !nsplit || !dw || !Cout || !Cin || !Cin_real) return GCSSL_ENULL;
     if (nl < 1 || nl > 8 || nrank < 0 || nrank > 4 || accumulate < 0 || accumulate > 2) return GCSSL_EBADSHAPE;
     if (nrank > 0 && (!coef || !u || !v)) return GCSSL_ENULL;
+    if ((coef_rep || bias_rep) && (nrep < 1 || rep_stride < 1)) return GCSSL_EBADSHAPE;
+    if (coef_rep && !nrank) return GCSSL_EBADSHAPE;
+    if (bias_rep && !dbias) return GCSSL_ENULL;
     RedBatch b{};
     int blk = 0;
     for (int i = 0; i < nl; ++i) {
@@ -2590,19 +2632,29 @@ int gcssl_wgrad_reduce_batch(int nl, const float* const* slab, const int* nsplit
         int zg = 1;
         if (accumulate == 2) { zg = (nsplit[i] + 15) / 16; if (zg > 16) zg = 16; }
         b.l[i] = RedLayer{slab[i], dw[i], nrank ? coef[i] : nullptr, nrank ? u[i] : nullptr, nrank ? v[i] : nullptr,
-                          nsplit[i], Cout[i], Cin[i], Cin_real[i], nrank, zg, blk};
+                          nsplit[i], Cout[i], Cin[i], Cin_real[i], nrank, zg, blk,
+                          coef_rep ? coef_rep[i] : nullptr, bias_rep ? bias_rep[i] : nullptr, (bias_rep && bias_rep[i]) ? dbias[i] : nullptr};
+        if (bias_rep && bias_rep[i] && !dbias[i]) return GCSSL_ENULL;
         blk += ((Cin[i] + 63) / 64) * Cout[i] * zg;
     }
-    b.nl = nl; b.ustride = ustride; b.vstride = vstride; b.accumulate = accumulate;
+    b.nl = nl; b.ustride = ustride; b.vstride = vstride; b.accumulate = accumulate; b.nrep = nrep; b.rep_stride = rep_stride;
+    b.bias_blk0 = -1;
+    if (bias_rep) {
+        int nb = 0;
+        for (int i = 0; i < nl; ++i) if (bias_rep[i]) nb += Cout[i];
+        if (nb > 0) { b.bias_blk0 = blk; blk += (nb + 255) / 256; }
+    }
     GCSSL_LAUNCH(wgrad_reduce_batch_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, b);
     return gcssl_launch_status();
 }
 
 int gcssl_prep_conv_weights(int dtype, int nl, const float* const* w, void* const* wf, void* const* wt, const int* Cout,
-                            const int* Cin, const int* CinP, void* stream) {
+                            const int* Cin, const int* CinP, const float* w5, float* w5p, int C5, void* stream) {
     if (!w || !wf || !wt || !Cout || !Cin || !CinP) return GCSSL_ENULL;
     if (nl < 1 || nl > 8) return GCSSL_EBADSHAPE;
+    if ((w5 != nullptr) != (w5p != nullptr) || (w5 && C5 <= 0)) return GCSSL_EBADSHAPE;
     PrepBatch b{};
+    b.nl = nl; b.w5 = w5; b.w5p = w5p; b.C5 = C5;
     size_t mx = 0;
     for (int i = 0; i < nl; ++i) {
         if (!w[i] || (!wf[i] && !wt[i])) return GCSSL_ENULL;
@@ -2612,7 +2664,7 @@ int gcssl_prep_conv_weights(int dtype, int nl, const float* const* w, void* cons
         if (t > mx) mx = t;
     }
     unsigned gx = (unsigned)((mx + 4095) / 4096); if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;     // one 4096-element tile per pass
-    dim3 grid(gx, nl, 2);
+    dim3 grid(gx, nl + (w5 ? 1 : 0), 2);
     if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     GCSSL_DISPATCH(dtype, GCSSL_LAUNCH(prep_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b));
     return gcssl_launch_status();

@@ -17,7 +17,7 @@ bool bad_dtype(int dt) { return gcssl_bad_dtype(dt); }
 template <typename T>
 __global__ void pack_pair_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                  const float* __restrict__ b2, const float* __restrict__ alpha,
-                                 T* __restrict__ out, int B, int HW) {
+                                 T* __restrict__ out, int B, int HW, int reps) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * HW) return;
     const int n = idx / HW, p = idx % HW;
@@ -34,9 +34,11 @@ __global__ void pack_pair_kernel(const float* __restrict__ a, const float* __res
         } else { v[c] = av; v[3 + c] = bv; }
     }
     v[6] = 0.f; v[7] = 0.f;
-    T* o = out + idx * 8;
+    for (int r = 0; r < reps; ++r) {                     // reps copies, B*HW pixels apart (the batched generator forward's input)
+        T* o = out + ((size_t)r * B * HW + idx) * 8;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) Elem<T>::st(o + c, v[c]);
+        for (int c = 0; c < 8; ++c) Elem<T>::st(o + c, v[c]);
+    }
 }
 
 // NHWC8 fp32 gradient -> two NCHW (B,3,S,S) fp32 tensors (d/d pred, d/d other)
@@ -66,7 +68,7 @@ __global__ void prep_c5_kernel(const float* __restrict__ w, float* __restrict__ 
 // one wave per output element, one channel per lane and load (shapes the vector form below does not take)
 template <typename T>
 __global__ void c5_fwd_scalar_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ wp, float* __restrict__ out,
-                              int N, int Hi, int Wi, int C) {
+                              int N, int Hi, int Wi, int C, float* __restrict__ mean_out, int per_group) {
     const int Ho = Hi - 1, Wo = Wi - 1;
     const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wid >= N * Ho * Wo) return;
@@ -84,19 +86,25 @@ __global__ void c5_fwd_scalar_kernel(const T* __restrict__ x, int ldx, const flo
         }
     }
     s = wave_sum(s);
-    if (lane == 0) out[wid] = s;
+    if (lane == 0) { out[wid] = s; if (mean_out) atomicAdd(mean_out + wid / per_group, s / per_group); }
 }
 
 // one wave per output element; a lane owns 16 bytes of channels per tap, and the 16 taps' loads are issued together as
 // raw buffer loads (taps outside the map: OOB offset, reads 0) -- the scalar form is a chain of dependent 2-byte loads.
 // Needs C and ldx to be multiples of the 16-byte vector and a 16-byte aligned x.
+// mean_out (nullable): mean_out[wid / per_group] += out[wid] / per_group -- the group means of the score map (WGAN terms,
+// cgan/cgan_train_enhanced.py:327,362) without a launch of their own; the caller zeroes mean_out.
 template <typename T>
 __global__ __launch_bounds__(256) void c5_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ wp,
-                                                    float* __restrict__ out, int N, int Hi, int Wi, int C) {
+                                                    float* __restrict__ out, int N, int Hi, int Wi, int C,
+                                                    float* __restrict__ mean_out, int per_group) {
     constexpr int VEC = 16 / sizeof(T);
+    __shared__ float wsum[4];
     const int Ho = Hi - 1, Wo = Wi - 1;
-    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wid >= N * Ho * Wo) return;
+    const int wid0 = (blockIdx.x * blockDim.x) >> 6;
+    const int wraw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const bool live = wraw < N * Ho * Wo;
+    const int wid = live ? wraw : 0;
     const int n = wid / (Ho * Wo), oy = (wid / Wo) % Ho, ox = wid % Wo;
     const size_t xb = (size_t)N * Hi * Wi * ldx * sizeof(T);
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, xb < 0x7fffffffu ? (unsigned)xb : 0x7fffffffu);
@@ -129,12 +137,21 @@ __global__ __launch_bounds__(256) void c5_fwd_kernel(const T* __restrict__ x, in
         }
     }
     s = wave_sum(s);
-    if (lane == 0) out[wid] = s;
+    if (lane == 0 && live) out[wid] = s;
+    if (mean_out) {                                      // (uniform branch: every wave of the block reaches the barrier)
+        if (lane == 0) wsum[threadIdx.x >> 6] = live ? s : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int last = min(wid0 + 3, N * Ho * Wo - 1);
+            if (wid0 / per_group == last / per_group) atomicAdd(mean_out + wid0 / per_group, ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) / per_group);
+            else for (int k = 0; k < 4 && wid0 + k < N * Ho * Wo; ++k) atomicAdd(mean_out + (wid0 + k) / per_group, wsum[k] / per_group);
+        }
+    }
 }
 
 // dx[n,iy,ix,c] = sum_{oy,ox} dout(n,oy,ox) wp[(iy-oy+1)*4 + (ix-ox+1)][c];  dout tensor or per-group constant
 template <typename T>
-__global__ void c5_dgrad_kernel(const float* __restrict__ dout, float g0, float g1, float g2, int group_n,
+__global__ void c5_dgrad_kernel(const float* __restrict__ dout, float g0, float g1, float g2, float g3, int group_n,
                                 const float* __restrict__ wp, T* __restrict__ dx, int lddx, int N, int Hi, int Wi, int C) {
     const int Ho = Hi - 1, Wo = Wi - 1;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,7 +159,7 @@ __global__ void c5_dgrad_kernel(const float* __restrict__ dout, float g0, float 
     const int c = idx % C; const size_t pix = idx / C;
     const int ix = pix % Wi, iy = (pix / Wi) % Hi, n = pix / ((size_t)Wi * Hi);
     float gconst = 0.f;
-    if (!dout) { const int g = n / group_n; gconst = g == 0 ? g0 : (g == 1 ? g1 : g2); }
+    if (!dout) { const int g = n / group_n; gconst = g == 0 ? g0 : (g == 1 ? g1 : (g == 2 ? g2 : g3)); }
     float s = 0.f;
     for (int ky = 0; ky < 4; ++ky) {
         const int oy = iy + 1 - ky;
@@ -162,7 +179,7 @@ __global__ void c5_dgrad_kernel(const float* __restrict__ dout, float g0, float 
 // sample loop so they pipeline), LDS combine, one atomic per (channel, tap, chunk).
 template <typename T>
 __global__ __launch_bounds__(256) void c5_wgrad_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ dout, float g0, float g1,
-                                float g2, int group_n, float* __restrict__ dw, int N, int Hi, int Wi, int C, int per) {
+                                float g2, float g3, int group_n, float* __restrict__ dw, int N, int Hi, int Wi, int C, int per) {
     // block = 64 channels x a chunk of `per` samples; every input pixel is read ONCE and feeds the (<= 16) taps whose
     // output position it touches: dw[c][ky][kx] += d(n, iy+1-ky, ix+1-kx) * x[n, iy, ix, c]
     __shared__ float sm[4][16][64];
@@ -176,7 +193,7 @@ __global__ __launch_bounds__(256) void c5_wgrad_kernel(const T* __restrict__ x, 
     if (c < C) {
         for (int n = nb + ty; n < ne; n += 4) {
             float gconst = 0.f;
-            if (!dout) { const int g = n / group_n; gconst = g == 0 ? g0 : (g == 1 ? g1 : g2); }
+            if (!dout) { const int g = n / group_n; gconst = g == 0 ? g0 : (g == 1 ? g1 : (g == 2 ? g2 : g3)); }
             for (int iy = 0; iy < Hi; ++iy)
                 for (int ix = 0; ix < Wi; ++ix) {
                     const float xv = Elem<T>::ld(x + ((size_t)(n * Hi + iy) * Wi + ix) * ldx + c);
@@ -240,21 +257,52 @@ __global__ void pack_fake_interp_kernel(const float* __restrict__ pred, const fl
 //   v <- normalize(W^T u), u <- normalize(W v)  (eps 1e-12), sigma = u . (W v).   Up to 4 layers per launch.
 // =========================================================================================
 struct SnLayer { const float* w; float* u; float* v; float* t; float* s; int rows, cols; };
-struct SnBatch { SnLayer l[4]; int nl; float* sigma; float* isig; float* u_hist; float* v_hist; int hist_stride_u, hist_stride_v; int slot, nslots; };
+struct SnBatch { SnLayer l[4]; int nl; float* sigma; float* isig; float* u_hist; float* v_hist; int hist_stride_u, hist_stride_v; int slot, nslots;
+                 int par;            // which half of a layer's 2 x cols scratch `t` this iteration accumulates into (chain position & 1)
+                 int fin_prev;       // sn_wtu: the PREVIOUS iteration of the chain has not been closed -- u is still s (= W v), see below
+                 float* zero; long nzero; };   // sn_finish: an extra buffer to clear (the engine's scalar / replica block), nullable
 
 // t += W^T u : block = 256 columns (64 lanes x 4) x 4 row groups over a 32-row slab (blockIdx.z); t is zero on entry.
 // A lane's 8 rows are 8 independent 16-byte loads (row / column overruns are clamped and weighted 0, so no branches sit
 // between them); row slabs give the 512 x 4096 layer 256 workgroups.  Column counts that are not a multiple of 4 take the
 // scalar form (one column per lane).
+//
+// CHAINED iterations (a critic step makes three in a row on the same weights: its real, fake and interpolated forwards):
+// closing iteration k -- u = s / |s|, sigma = |s| with s = W v -- needs |s|^2 over all rows, which used to be a launch of its
+// own (sn_finish_kernel) between W v and the next W^T u.  With fin_prev the next W^T u does it instead: every workgroup
+// recomputes 1 / |s| from the <= 512 floats of s (redundant, tiny), uses u = s / |s| on the fly, and the workgroup (0, layer, 0)
+// publishes u, its history slot and sigma of iteration k.  Only the LAST iteration of a chain is closed by sn_finish_kernel.
+// The scratch t is double-buffered by chain parity: W^T u of iteration k+1 accumulates atomically into the half that W v of
+// iteration k has just cleared, while the other half still holds v_k's unnormalised values.
 constexpr int SN_SLAB = 32;
 __global__ __launch_bounds__(256) void sn_wtu_kernel(SnBatch b) {
     const SnLayer L = b.l[blockIdx.y];
     __shared__ float sm[4][256];
+    __shared__ float red[4];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int r0 = blockIdx.z * SN_SLAB;
     const bool vec = (L.cols & 3) == 0;
     const int cpb = vec ? 256 : 64;
     if ((int)blockIdx.x * cpb >= L.cols || r0 >= L.rows) return;
+    float* tcur = L.t + (b.par ? L.cols : 0);
+    const float* uvec = L.u;
+    float uinv = 1.f;
+    if (b.fin_prev) {                                                      // close iteration slot-1 on the fly (see above)
+        float q2 = 0.f;
+        for (int r = threadIdx.x; r < L.rows; r += 256) { const float sv = L.s[r]; q2 += sv * sv; }
+        const float s2 = block_sum<4>(q2, red);
+        uinv = 1.f / fmaxf(sqrtf(s2), 1e-12f);
+        uvec = L.s;
+        if (blockIdx.x == 0 && blockIdx.z == 0) {
+            float* uh = b.u_hist + ((size_t)blockIdx.y * b.nslots + (b.slot - 1)) * b.hist_stride_u;
+            for (int r = threadIdx.x; r < L.rows; r += 256) { const float uu = L.s[r] * uinv; L.u[r] = uu; uh[r] = uu; }
+            if (threadIdx.x == 0) {
+                const float sg = s2 * uinv;
+                b.sigma[blockIdx.y * b.nslots + b.slot - 1] = sg;
+                b.isig[blockIdx.y * b.nslots + b.slot - 1] = 1.f / sg;
+            }
+        }
+    }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (vec) {
         const int col = (blockIdx.x * 64 + tx) * 4, cc = col < L.cols ? col : 0;
@@ -262,7 +310,7 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(SnBatch b) {
         for (int k = 0; k < SN_SLAB / 4; ++k) {
             const int r = r0 + ty + 4 * k, rc = r < L.rows ? r : L.rows - 1;
             const float4 w = *reinterpret_cast<const float4*>(L.w + (size_t)rc * L.cols + cc);
-            const float u = r < L.rows ? L.u[rc] : 0.f;
+            const float u = r < L.rows ? uvec[rc] * uinv : 0.f;
             acc[0] += w.x * u; acc[1] += w.y * u; acc[2] += w.z * u; acc[3] += w.w * u;
         }
 #pragma unroll
@@ -271,15 +319,15 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(SnBatch b) {
         if (ty == 0 && col < L.cols) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                atomicAdd(L.t + col + j, (sm[0][tx * 4 + j] + sm[1][tx * 4 + j]) + (sm[2][tx * 4 + j] + sm[3][tx * 4 + j]));
+                atomicAdd(tcur + col + j, (sm[0][tx * 4 + j] + sm[1][tx * 4 + j]) + (sm[2][tx * 4 + j] + sm[3][tx * 4 + j]));
         }
     } else {
         const int col = blockIdx.x * 64 + tx;
         if (col < L.cols)
-            for (int r = r0 + ty; r < min(L.rows, r0 + SN_SLAB); r += 4) acc[0] += L.w[(size_t)r * L.cols + col] * L.u[r];
+            for (int r = r0 + ty; r < min(L.rows, r0 + SN_SLAB); r += 4) acc[0] += L.w[(size_t)r * L.cols + col] * (uvec[r] * uinv);
         sm[ty][tx] = acc[0];
         __syncthreads();
-        if (ty == 0 && col < L.cols) atomicAdd(L.t + col, (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]));
+        if (ty == 0 && col < L.cols) atomicAdd(tcur + col, (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]));
     }
 }
 
@@ -306,7 +354,8 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(SnBatch b) {
     const bool rv = row < L.rows;
     const int c4 = (L.cols & 3) ? 0 : L.cols >> 2;          // vector part (all of it for the critic's shapes)
     const int per = (c4 + wpr - 1) / wpr, cbeg = seg * per, cend = min(c4, cbeg + per);
-    const float4* t4 = reinterpret_cast<const float4*>(L.t);
+    const float* tcur = L.t + (b.par ? L.cols : 0);          // this iteration's W^T u; the other half is cleared for the next one
+    const float4* t4 = reinterpret_cast<const float4*>(tcur);
     const float4* w4 = reinterpret_cast<const float4*>(L.w + (size_t)(rv ? row : 0) * L.cols);
     float q = 0.f, s = 0.f;
 #pragma unroll 4
@@ -316,7 +365,7 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(SnBatch b) {
         s += w.x * t.x + w.y * t.y + w.z * t.z + w.w * t.w;
     }
     for (int c = c4 * 4 + lane; c < L.cols; c += 64) {       // (columns not a multiple of 4: wpr == 1)
-        const float t = L.t[c]; q += t * t; s += L.w[(size_t)(rv ? row : 0) * L.cols + c] * t;
+        const float t = tcur[c]; q += t * t; s += L.w[(size_t)(rv ? row : 0) * L.cols + c] * t;
     }
     q = wave_sum(q); s = wave_sum(s);
     if (lane == 0) { part[0][wave] = q; part[1][wave] = s; }
@@ -327,7 +376,8 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(SnBatch b) {
     if (rv && seg == 0 && lane == 0) L.s[row] = ss * inv;
     if (blockIdx.x == 0) {
         float* vh = b.v_hist + ((size_t)blockIdx.y * b.nslots + b.slot) * b.hist_stride_v;
-        for (int c = threadIdx.x; c < L.cols; c += 256) { const float vv = L.t[c] * inv; L.v[c] = vv; vh[c] = vv; }
+        float* toth = L.t + (b.par ? 0 : L.cols);
+        for (int c = threadIdx.x; c < L.cols; c += 256) { const float vv = tcur[c] * inv; L.v[c] = vv; vh[c] = vv; toth[c] = 0.f; }
     }
 }
 // one block per layer: u = s / max(|s|, eps), sigma = u . s, and t is zeroed again for the next iteration
@@ -340,12 +390,15 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(SnBatch b) {
     const float uinv = 1.f / fmaxf(sqrtf(s2), 1e-12f);
     float* uh = b.u_hist + ((size_t)blockIdx.x * b.nslots + b.slot) * b.hist_stride_u;
     for (int r = threadIdx.x; r < L.rows; r += 256) { const float uu = L.s[r] * uinv; L.u[r] = uu; uh[r] = uu; }
-    for (int c = threadIdx.x; c < L.cols; c += 256) L.t[c] = 0.f;
+    float* tcur = L.t + (b.par ? L.cols : 0);
+    for (int c = threadIdx.x; c < L.cols; c += 256) tcur[c] = 0.f;            // (the other half was cleared by sn_wv_kernel)
     if (threadIdx.x == 0) {
         const float sg = s2 * uinv;
         b.sigma[blockIdx.x * b.nslots + b.slot] = sg;
         b.isig[blockIdx.x * b.nslots + b.slot] = 1.f / sg;
     }
+    // an extra fill for the caller (the engine's scalar / striped-sum block, cleared once per critic step): nl workgroups share it
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < b.nzero; i += (long)gridDim.x * 256) b.zero[i] = 0.f;
 }
 __global__ __launch_bounds__(256) void sn_sigma_kernel(SnBatch b) {
     const SnLayer L = b.l[blockIdx.x];
@@ -593,8 +646,11 @@ __device__ __forceinline__ float selmin(float a, float b) { return a < b ? 1.f :
 
 __global__ void eiou_kernel(const float* __restrict__ pred_box, const float* __restrict__ delta, const float* __restrict__ delta_true,
                             int B, float lambda_iou, float* __restrict__ g_delta, float* __restrict__ cal, float* loss_acc) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= B) return;
+    // ONE workgroup walks the batch (a few hundred boxes of a few dozen flops each) and STORES the loss: no same-address
+    // atomics (256 of them cost ~3 us), no zero fill in front, and a deterministic sum
+    __shared__ float red[4];
+    float lsum = 0.f;
+    for (int n = threadIdx.x; n < B; n += 256) {
     const float eps = 1e-6f;
     float p[4], t[4], jac[4];
     apply_delta_train(pred_box + n * 4, delta + n * 4, p, jac);
@@ -613,7 +669,7 @@ __global__ void eiou_kernel(const float* __restrict__ pred_box, const float* __r
     const float dw2 = (p[2] - t[2]) * (p[2] - t[2]), dh2 = (p[3] - t[3]) * (p[3] - t[3]);
     const float cw = ew * ew + eps, chh = eh * eh + eps;
     const float eiou = iou - rho2 / c2 - dw2 / cw - dh2 / chh;
-    atomicAdd(loss_acc, -eiou / B);
+    lsum += -eiou / B;
     for (int k = 0; k < 4; ++k) cal[n * 4 + k] = p[k];
     // gradient of eiou wrt the corners
     const float g_iw = ih * (iwr >= 0.f ? 1.f : 0.f), g_ih = iw * (ihr >= 0.f ? 1.f : 0.f);
@@ -632,6 +688,9 @@ __global__ void eiou_kernel(const float* __restrict__ pred_box, const float* __r
     gb[2] = 0.5f * (gx2 - gx1) - 2.f * (p[2] - t[2]) / cw;
     gb[3] = 0.5f * (gy2 - gy1) - 2.f * (p[3] - t[3]) / chh;
     for (int k = 0; k < 4; ++k) g_delta[n * 4 + k] = lambda_iou * gb[k] * (-1.0f / B) * jac[k];
+    }
+    const float tot = block_sum<4>(lsum, red);
+    if (threadIdx.x == 0) *loss_acc = tot;
 }
 
 // =========================================================================================
@@ -714,12 +773,12 @@ const char* g_gcssl_last_kernel = nullptr;     // (common.h: set by GCSSL_LAUNCH
 
 extern "C" {
 
-int gcssl_pack_pair(int dtype, const float* a, const float* b, void* out, int B, int S, void* stream) {
+int gcssl_pack_pair(int dtype, const float* a, const float* b, void* out, int B, int S, int reps, void* stream) {
     if (!a || !out) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    if (B <= 0 || S <= 0) return GCSSL_EBADSHAPE;
+    if (B <= 0 || S <= 0 || reps < 1) return GCSSL_EBADSHAPE;
     const size_t n = (size_t)B * S * S;
-    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(pack_pair_kernel<T>, GRID1(n), a, b, nullptr, nullptr, (T*)out, B, S * S));
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(pack_pair_kernel<T>, GRID1(n), a, b, nullptr, nullptr, (T*)out, B, S * S, reps));
     return gcssl_launch_status();
 }
 
@@ -729,7 +788,7 @@ int gcssl_pack_interp(int dtype, const float* pred, const float* gt, const float
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (B <= 0 || S <= 0) return GCSSL_EBADSHAPE;
     const size_t n = (size_t)B * S * S;
-    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(pack_pair_kernel<T>, GRID1(n), pred, gt, refined, alpha, (T*)out, B, S * S));
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(pack_pair_kernel<T>, GRID1(n), pred, gt, refined, alpha, (T*)out, B, S * S, 1));
     return gcssl_launch_status();
 }
 
@@ -758,32 +817,34 @@ int gcssl_prep_c5_weight(const float* w, float* wp, int C, void* stream) {
     return gcssl_launch_status();
 }
 
-int gcssl_conv4x4s1_c1_fwd(int dtype, const void* x, int ldx, const float* wp, float* out, int N, int Hi, int Wi,
-                           int C, void* stream) {
+int gcssl_conv4x4s1_c1_fwd(int dtype, const void* x, int ldx, const float* wp, float* out, float* group_mean, int groups,
+                           int N, int Hi, int Wi, int C, void* stream) {
     if (!x || !wp || !out) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || ldx < C) return GCSSL_EBADSHAPE;
+    if (group_mean && (groups <= 0 || ((size_t)N * (Hi - 1) * (Wi - 1)) % groups)) return GCSSL_EBADSHAPE;
+    const int per_group = group_mean ? (int)((size_t)N * (Hi - 1) * (Wi - 1) / groups) : 1;
     const size_t threads = (size_t)N * (Hi - 1) * (Wi - 1) * 64;
     const int vec = dtype == GCSSL_F32 ? 4 : 8;
     const bool vec_ok = C % vec == 0 && ldx % vec == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)wp) & 15) == 0 &&
                         (size_t)N * Hi * Wi * ldx * (dtype == GCSSL_F32 ? 4 : 2) < 0x80000000ull;
     GCSSL_DISPATCH(dtype,
-        if (vec_ok) hipLaunchKernelGGL(c5_fwd_kernel<T>, GRID1(threads), (const T*)x, ldx, wp, out, N, Hi, Wi, C);
-        else hipLaunchKernelGGL(c5_fwd_scalar_kernel<T>, GRID1(threads), (const T*)x, ldx, wp, out, N, Hi, Wi, C));
+        if (vec_ok) hipLaunchKernelGGL(c5_fwd_kernel<T>, GRID1(threads), (const T*)x, ldx, wp, out, N, Hi, Wi, C, group_mean, per_group);
+        else hipLaunchKernelGGL(c5_fwd_scalar_kernel<T>, GRID1(threads), (const T*)x, ldx, wp, out, N, Hi, Wi, C, group_mean, per_group));
     return gcssl_launch_status();
 }
 
-int gcssl_conv4x4s1_c1_dgrad(int dtype, const float* dout, float g0, float g1, float g2, int group_n, const float* wp,
+int gcssl_conv4x4s1_c1_dgrad(int dtype, const float* dout, float g0, float g1, float g2, float g3, int group_n, const float* wp,
                              void* dx, int lddx, int N, int Hi, int Wi, int C, void* stream) {
     if (!wp || !dx) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || lddx < C || (!dout && group_n <= 0)) return GCSSL_EBADSHAPE;
     const size_t n = (size_t)N * Hi * Wi * C;
-    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(c5_dgrad_kernel<T>, GRID1(n), dout, g0, g1, g2, group_n, wp, (T*)dx, lddx, N, Hi, Wi, C));
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(c5_dgrad_kernel<T>, GRID1(n), dout, g0, g1, g2, g3, group_n, wp, (T*)dx, lddx, N, Hi, Wi, C));
     return gcssl_launch_status();
 }
 
-int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dout, float g0, float g1, float g2,
+int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dout, float g0, float g1, float g2, float g3,
                              int group_n, float* dw, int N, int Hi, int Wi, int C, void* stream) {
     if (!x || !dw) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
@@ -792,18 +853,20 @@ int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dou
     int zs = N * zcap / 768; if (zs < 1) zs = 1; if (zs > zcap) zs = zcap;
     const int per = (N + zs - 1) / zs;
     dim3 grid((C + 63) / 64, zs);
-    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(c5_wgrad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, dout, g0, g1, g2, group_n, dw, N, Hi, Wi, C, per));
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(c5_wgrad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, dout, g0, g1, g2, g3, group_n, dw, N, Hi, Wi, C, per));
     return gcssl_launch_status();
 }
 
-// One power iteration (or, with iterate=0, just sigma from the stored u,v) for nl <= 4 layers.
-// w[i]: [rows[i]][cols[i]] fp32; u/v updated in place; t/s: scratch (cols / rows floats).
-// sigma/isig: [nl][nslots]; u_hist: [nl][nslots][hist_stride_u]; v_hist likewise; this call fills slot `slot`.
+// `iterate` chained power iterations (or, with iterate=0, just sigma from the stored u,v) for nl <= 4 layers.
+// w[i]: [rows[i]][cols[i]] fp32; u/v updated in place; t: scratch of 2 * cols floats (zero on entry, left zero), s: rows floats.
+// sigma/isig: [nl][nslots]; u_hist: [nl][nslots][hist_stride_u]; v_hist likewise; the call fills slots slot .. slot+iterate-1.
 int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* const* v, float* const* t, float* const* s,
                         const int* rows, const int* cols, float* sigma, float* isig, float* u_hist, float* v_hist,
-                        int hist_stride_u, int hist_stride_v, int slot, int nslots, int iterate, void* stream) {
+                        int hist_stride_u, int hist_stride_v, int slot, int nslots, int iterate, float* zero, long nzero,
+                        void* stream) {
     if (!w || !u || !v || !t || !s || !rows || !cols || !sigma || !isig || !u_hist || !v_hist) return GCSSL_ENULL;
-    if (nl < 1 || nl > 4 || slot < 0 || slot >= nslots) return GCSSL_EBADSHAPE;
+    if (nl < 1 || nl > 4 || slot < 0 || slot >= nslots || iterate < 0 || slot + (iterate > 1 ? iterate : 1) > nslots) return GCSSL_EBADSHAPE;
+    if (nzero < 0 || (nzero > 0 && !zero)) return GCSSL_EBADSHAPE;
     SnBatch b{};
     int maxcb = 0, maxr = 0, maxblk = 0;
     for (int i = 0; i < nl; ++i) {
@@ -820,12 +883,17 @@ int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* c
     b.hist_stride_u = hist_stride_u; b.hist_stride_v = hist_stride_v; b.slot = slot; b.nslots = nslots;
     hipStream_t st = (hipStream_t)stream;
     if (iterate) {
-        // t is zero on entry (caller allocates it zeroed) and sn_finish_kernel leaves it zero again
-        hipLaunchKernelGGL(sn_wtu_kernel, dim3(maxcb, nl, (maxr + SN_SLAB - 1) / SN_SLAB), dim3(256), 0, st, b);
-        hipLaunchKernelGGL(sn_wv_kernel, dim3(maxblk, nl), dim3(256), 0, st, b);
+        // both halves of t are zero on entry (the caller allocates them zeroed) and the chain leaves them zero again
+        for (int k = 0; k < iterate; ++k) {
+            b.slot = slot + k; b.par = k & 1; b.fin_prev = k > 0;
+            hipLaunchKernelGGL(sn_wtu_kernel, dim3(maxcb, nl, (maxr + SN_SLAB - 1) / SN_SLAB), dim3(256), 0, st, b);
+            hipLaunchKernelGGL(sn_wv_kernel, dim3(maxblk, nl), dim3(256), 0, st, b);
+        }
+        b.zero = zero; b.nzero = nzero;
         hipLaunchKernelGGL(sn_finish_kernel, dim3(nl), dim3(256), 0, st, b);
     } else {
         hipLaunchKernelGGL(sn_sigma_kernel, dim3(nl), dim3(256), 0, st, b);
+        if (nzero > 0) gcssl_zero_async(zero, (size_t)nzero, st);
     }
     return gcssl_launch_status();
 }
@@ -888,7 +956,7 @@ int gcssl_eiou_fwd_bwd(const float* pred_box, const float* delta, const float* d
                        float* g_delta, float* calibrated, float* loss_acc, void* stream) {
     if (!pred_box || !delta || !delta_true || !g_delta || !calibrated || !loss_acc) return GCSSL_ENULL;
     if (B <= 0) return GCSSL_EBADSHAPE;
-    hipLaunchKernelGGL(eiou_kernel, GRID1(B), pred_box, delta, delta_true, B, lambda_iou, g_delta, calibrated, loss_acc);
+    hipLaunchKernelGGL(eiou_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred_box, delta, delta_true, B, lambda_iou, g_delta, calibrated, loss_acc);
     return gcssl_launch_status();
 }
 

@@ -826,6 +826,8 @@ struct ActBwdParams {
     int HW, C;
     int nrep, rep_stride;
     unsigned* sat;                     // += number of dzs values clipped by the fp16 store (nullable)
+    const void* dotx; int lddot; float* dot_out;   // optional: dot_out += sum dotx * da (dotx in the compute dtype): gcssl_dot_accum
+                                                   // folded in for the reverse GP chain's norm-less layer (<gb_zs, gt_z>)
 };
 // grid: (C/64, sample blocks of `spb`, H*W chunks of `rows_per_chunk`); lanes own 4 channels x strided rows, the bias /
 // spectral-norm partial sums stay in registers across the samples of a workgroup (one set of atomics per workgroup)
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(CGN * RGN) void act_bwd_kernel(ActBwdParams q, int 
     float b[VC] = {0.f, 0.f, 0.f, 0.f};
     if (q.bias) ld4(q.bias + c, b);
     float sb[1][VC] = {{0.f, 0.f, 0.f, 0.f}};
-    float sd = 0.f;
+    float sd = 0.f, sdot = 0.f;
     int nsat = 0;
     const int p0 = blockIdx.z * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
     const int nb = blockIdx.y * spb;
@@ -848,12 +850,17 @@ __global__ __launch_bounds__(CGN * RGN) void act_bwd_kernel(ActBwdParams q, int 
         const float* dap = q.da + (size_t)n * HW * q.ldda + c;
         const float* da2p = q.da2 ? q.da2 + (size_t)n * HW * q.ldda2 + c : nullptr;
         T* op = static_cast<T*>(q.dzs) + (size_t)n * HW * q.lddz + c;
+        const T* xp = q.dotx ? static_cast<const T*>(q.dotx) + (size_t)n * HW * q.lddot + c : nullptr;
         const float gs = q.gscale ? q.gscale[n / q.group_n] : 1.f;
 #pragma unroll 4
         for (int p = p0 + ty; p < p1; p += RGN) {           // unrolled: four rows' loads in flight per lane
             float av[VC], d[VC], o[VC];
             ldT4<T>(ap + (size_t)p * q.lda, av);
             ld4(dap + (size_t)p * q.ldda, d);
+            if (xp) {
+                float xv[VC]; ldT4<T>(xp + (size_t)p * q.lddot, xv);
+                sdot += (xv[0] * d[0] + xv[1] * d[1]) + (xv[2] * d[2] + xv[3] * d[3]);
+            }
             if (da2p) {
                 float t[VC]; ld4(da2p + (size_t)p * q.ldda2, t);
 #pragma unroll
@@ -887,6 +894,10 @@ __global__ __launch_bounds__(CGN * RGN) void act_bwd_kernel(ActBwdParams q, int 
         if (threadIdx.x == 0) atomicAdd(q.cdot + replica_offset(q.nrep, q.rep_stride) + nb / q.group_n, tot);
     }
     sat_commit(q.sat, nsat);
+    if (q.dot_out) {
+        const float tot = block_sum<CGN * RGN / 64>(sdot, red);
+        if (threadIdx.x == 0) atomicAdd(q.dot_out, tot);
+    }
 }
 
 // out += sum x*y  (strided NHWC views), used for the <gb_zs, gt_z> spectral-norm term of the norm-less layer;
@@ -1085,14 +1096,16 @@ int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, in
 
 int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const void* a, int lda,
                   const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias,
-                  float* cdot, int nrep, int rep_stride, unsigned* sat, int N, int HW, int C, void* stream) {
+                  float* cdot, int nrep, int rep_stride, unsigned* sat, const void* dotx, int lddot, float* dot_out,
+                  int N, int HW, int C, void* stream) {
     if (!da || !a || !dzs) return GCSSL_ENULL;
+    if ((dotx != nullptr) != (dot_out != nullptr) || (dotx && (lddot < C || lddot % 4 || da2))) return GCSSL_EBADSHAPE;
     if (nrep < 1 || (nrep > 1 && rep_stride < C)) return GCSSL_EBADSHAPE;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || HW <= 0 || C <= 0 || C % CW || lda < C || lddz < C || ldda < C) return GCSSL_EBADSHAPE;
     if (lda % 4 || lddz % 4 || ldda % 4 || (da2 && ldda2 % 4)) return GCSSL_EBADSHAPE;
     if ((gscale || cdot) && group_n <= 0) return GCSSL_EBADSHAPE;
-    ActBwdParams q{da, ldda, da2, ldda2, a, lda, gscale, group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, HW, C, nrep, rep_stride, sat};
+    ActBwdParams q{da, ldda, da2, ldda2, a, lda, gscale, group_n > 0 ? group_n : N, bias, dzs, lddz, dbias, cdot, HW, C, nrep, rep_stride, sat, dotx, lddot, dot_out};
     // 64-row chunks of H*W x blocks of samples; grow the sample block while >= ~512 workgroups remain
     int rows = HW < 64 ? HW : 64;
     const int zc = (HW + rows - 1) / rows;

@@ -361,6 +361,10 @@ class StepEngine:
         self.zt = [None] + [act(B, s, c, F32) for s, (_, c) in zip(sizes[1:], D_CH[1:])]
         # backward of the 3B forward
         self.d_da = [act(N3, s, c, F32) for s, (_, c) in zip(sizes, D_CH)]
+        # the head conv's data gradient is a constant per sample group (its seeds) times the weights: the backward's (3B samples)
+        # and the GP chain's (B samples, seed 1) come from ONE launch into a 4B-sample buffer
+        self.d_da4_3 = act(N4, sizes[3], 512, F32)
+        self.d_da[3], self.gb_a[3] = self.d_da4_3[:N3], self.d_da4_3[N3:]
         self.d_dzs = [t[:N3] for t in self.d_dzs4]
         # scalars: [0:12] cdot[layer][group] = <dW_sn_k, W_orig>/sigma_k^2 (spectral-norm quotient rule), [12] gp_sum, [13] eiou acc, [14:17] group means, [17] wgan-G mean
         # ... followed by NREP replicas of the critic backward's striped sums (bias gradients of the four layers + the 12
@@ -457,8 +461,10 @@ class StepEngine:
         if self._red_d is None:
             self._red_d = ops.ReduceBatch(
                 [dict(slab=self.d_slab[l], nsplit=sum(self.d_ns[l]), dw=self.D.gviews[f"model.{i}.weight_orig"], cout=cout,
-                      cin=_pad8(cin), cin_real=cin, coef=self.cdot[l], u=self.sn.u_hist[l], v=self.sn.v_hist[l])
-                 for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX))], nrank=3)
+                      cin=_pad8(cin), cin_real=cin, coef=self.cdot[l], u=self.sn.u_hist[l], v=self.sn.v_hist[l],
+                      coef_rep=self.rep[0, 960 + 3 * l:963 + 3 * l],
+                      bias_rep=self.rep[0, self.rep_bias_off[l]:self.rep_bias_off[l] + cout], dbias=self.D.gviews[f"model.{i}.bias"])
+                 for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX))], nrank=3, nrep=self.NREP, rep_stride=self.REP_STRIDE)
             if self.gen is not None:                               # the simple generator reduces its own 3x3 slabs
                 return self._red_d, None
             gW = self.G.gviews
@@ -477,9 +483,9 @@ class StepEngine:
         if self._prep_d_batch is None:
             self._prep_d_batch = ops.PrepBatch(
                 [(self.D.views[f"model.{i}.weight_orig"], self.d_wf[l], self.d_wt[l], cout, cin, _pad8(cin))
-                 for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX))], self.code)
+                 for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX))], self.code,
+                c5=(self.D.views["model.11.weight"], self.d_w5p))         # the head's fp32 re-pack rides on the same launch
         self._prep_d_batch.run()
-        ops.prep_c5_weight(self.D.views["model.11.weight"], self.d_w5p)
         self._d_dirty = False
 
     def _prep_g(self):
@@ -500,8 +506,9 @@ class StepEngine:
         self._g_dirty = False
 
     # ------------------------------------------------------------------------------------------ critic forward
-    def _d_forward(self, n: int, gscale_of_layer, group_n: int, x: Optional[torch.Tensor] = None):
-        """conv stack over the first n rows of the 3B buffers (input: x, default the first n rows of x0)."""
+    def _d_forward(self, n: int, gscale_of_layer, group_n: int, x: Optional[torch.Tensor] = None, means=None, groups=0):
+        """conv stack over the first n rows of the 3B buffers (input: x, default the first n rows of x0).  means (zeroed by
+        the caller): += the mean score of each of `groups` equal sample groups, from the head conv's own launch."""
         x = self.x0[:n] if x is None else x
         for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX)):
             bias = self.D.views[f"model.{i}.bias"]
@@ -522,7 +529,7 @@ class StepEngine:
                 ops.in_act_fwd(self.d_z[l][:n], self.d_a[l][:n], self.d_mean[l][:n], self.d_rstd[l][:n], cout, LRELU,
                                nslab=ns, slab_stride=st)
                 self._d_zsrc[l] = self.d_z[l]
-        ops.c5_fwd(self.d_a[3][:n], self.d_w5p, self.d_out[:n])
+        ops.c5_fwd(self.d_a[3][:n], self.d_w5p, self.d_out[:n], group_mean=means, groups=groups)
 
     def critic_scores(self, pred: torch.Tensor, other: torch.Tensor, train: bool = True) -> torch.Tensor:
         """Discriminator.forward(pred, other) (cgan/models.py:255-258) for one (B,3,S,S) pair -> (B,1,h,w).
@@ -629,8 +636,7 @@ class StepEngine:
             self.gen.forward_all(pred, masks)
             self._gall_valid = True
             return
-        ops.pack_pair(pred, None, fa.x8[:B])
-        fa.x8.view(self.c + 1, -1)[1:].copy_(fa.x8.view(self.c + 1, -1)[0])       # the same input for every call
+        ops.pack_pair(pred, None, fa.x8, reps=self.c + 1)          # the same input for every call
         if masks is None:
             ops.dropout_mask_gen(fa.maskbuf, self.seed * 131 + 20, self.G.state)
         else:
@@ -732,8 +738,9 @@ class StepEngine:
                              counter=self.G.state)
 
     def _sn_and_prep(self) -> None:
-        for slot in range(3):                                     # real, fake, interp forwards each iterate once
-            self.sn.iterate(slot, True)
+        # real, fake, interp forwards each iterate once: three chained power iterations (slots 0..2), whose closing launch also
+        # clears the per-step scalars + striped-sum replicas (zero_blk) -- no fill launch of its own
+        self.sn.iterate(0, 3, zero=self.zero_blk)
         self._prep_d()
 
     def d_main(self, sn_done: bool = False) -> None:
@@ -746,12 +753,14 @@ class StepEngine:
         if not self.D.grads_zero:                                 # optimizer.zero_grad() (:305) unless the last update did it
             self.D.g.zero_()
         self.D.grads_zero = False
-        self.zero_blk.zero_()                                      # scalars + the striped-sum replicas
-        self._join_side()                                         # sigma, u/v history and packed weights are ready
-        self._d_forward(N3, lambda l: isig[l], B)
-        ops.group_mean(self.d_out, 3, self.means)
-        # ---- GP first-order chain on the interpolated group (cgan/losses.py:213-220)
-        ops.c5_dgrad(self.gb_a[3], self.d_w5p, consts=(1.0, 1.0, 1.0), group_n=B)
+        self._join_side()                                         # sigma, u/v history, packed weights ready; zero_blk cleared
+        self._d_forward(N3, lambda l: isig[l], B, means=self.means, groups=3)      # (+ the three batch means, :327)
+        # ---- GP first-order chain on the interpolated group (cgan/losses.py:213-220); its seed (1 per score) and the seeds of
+        # the batched backward of the three forwards, -1/(B hw), +1/(B hw), 0 (:327-330), leave the head conv in one launch
+        hw = self.h5 * self.h5
+        ls = self.loss_scale_d
+        seeds = (-ls / (B * hw), ls / (B * hw), 0.0)
+        ops.c5_dgrad(self.d_da4_3, self.d_w5p, consts=(seeds[0], seeds[1], seeds[2], 1.0), group_n=B)
         ns, st = 1, 0                                             # K-split slabs of the conv that produced gb_a[l]
         for l in (3, 2, 1):
             cin, cout = D_CH[l]
@@ -773,22 +782,18 @@ class StepEngine:
             self._conv(f"D.c{l + 1}.gp_rev_fwd", fl, ops.conv_fwd, src, self.d_wf[l], self.gt_z[l], cp, cout,
                        gscale=isig[l, 2:3], group_n=B, split_stride=st)
             # (the weight gradient of this chain, src x gb_zs[l], is contracted together with the batched backward's below)
-            if l == 0:
-                ops.dot_accum(self.gb_zs[0], self.gt_z[0], 64, self.cdot[0, 2:3])
-                ops.act_bwd(self.gt_z[0], self.d_a[0][I], self.gt_a[0], 64, sat=self.sat_d)
+            if l == 0:          # (+ the <gb_zs, gt_z> spectral-norm term of this norm-less layer, in the same pass)
+                ops.act_bwd(self.gt_z[0], self.d_a[0][I], self.gt_a[0], 64, sat=self.sat_d, dotx=self.gb_zs[0], dot_out=self.cdot[0, 2:3])
             else:
                 ops.in_dbl_bwd(self.gb_a[l], self.gt_z[l], self.gb_zs[l], self._d_zsrc[l][I], self.d_mean[l][I],
                                self.d_rstd[l][I], self.gt_a[l], self.zt[l], cout, LRELU, cdot=self.cdot[l, 2:3],
                                q_nslab=ns, q_slab_stride=st, sat=self.sat_d)
             src = self.gt_a[l]
         gw5 = self.D.gviews["model.11.weight"].view(512, 16)
-        ops.c5_wgrad(self.gt_a[3], gw5, 512, consts=(1.0, 1.0, 1.0), group_n=B)
         # ---- backward of the three forwards, batched: seeds -1/(B hw), +1/(B hw), 0  (:327-330)
-        hw = self.h5 * self.h5
-        ls = self.loss_scale_d
-        seeds = (-ls / (B * hw), ls / (B * hw), 0.0)
-        ops.c5_wgrad(self.d_a[3], gw5, 512, consts=seeds, group_n=B)
-        ops.c5_dgrad(self.d_da[3], self.d_w5p, consts=seeds, group_n=B)
+        # the head's weight gradient of both parts in one launch over the 4B-sample buffer: seeds of the three forwards, and 1 for
+        # the reverse GP chain's adjoint activations gt_a (the derivative of the first-order seed w5 * 1)
+        ops.c5_wgrad(self.d_a4[3], gw5, 512, consts=(seeds[0], seeds[1], seeds[2], 1.0), group_n=B)
         for l in (3, 2, 1, 0):
             cin, cout = D_CH[l]
             cp = _pad8(cin)
@@ -811,14 +816,8 @@ class StepEngine:
             if l > 0:
                 self._conv(f"D.c{l + 1}.dgrad", fl, ops.conv_dgrad, self.d_dzs[l], self.d_wt[l], self.d_da[l - 1], cin, cout)
         self._join_side()                                         # all gradient branches are in before the segment ends
-        # fold the striped sums: bias gradients -> flat gradient, cdot += (the GP-chain part is already there)
-        if self._rep_sum is None:
-            segs = [(self.rep[0, o:o + c], self.D.gviews[f"model.{i}.bias"], c, False)
-                    for o, (_, c), i in zip(self.rep_bias_off, D_CH, D_IDX)]
-            segs.append((self.rep[0, 960:972], self.scal[0:12], 12, True))
-            self._rep_sum = ops.ReplicaSum(segs, self.NREP, self.REP_STRIDE)
-        self._rep_sum.run()
-        # dW_orig = sum_k G_k / sigma_k - sum_k c_k u_k v_k^T for the four spectrally-normalised layers, one launch
+        # dW_orig = sum_k G_k / sigma_k - sum_k c_k u_k v_k^T for the four spectrally-normalised layers, one launch -- which also
+        # folds the striped sums (bias gradients -> flat gradient; c_k = its GP-chain part in `cdot` + the replicas)
         self._reduce_batches()[0].run()
 
     # ------------------------------------------------------------------------------------------ G step
@@ -852,11 +851,10 @@ class StepEngine:
     def g_critic(self, pred) -> None:
         """D forward on (pred, refined_G): value only (zero gradient to G) but it advances u,v (:361)."""
         B = self.B
-        self.sn.iterate(0, True)
+        self.sn.iterate(0, True, zero=self.wgan_mean)              # (the closing launch clears the mean the head conv adds to)
         self._prep_d()
         ops.pack_pair(pred, self._refined_g, self.x0[B:2 * B])     # x0[:B] stays G's input (down1's wgrad operand)
-        self._d_forward(B, lambda l: self.sn.isig[l, 0:1], B, x=self.x0[B:2 * B])
-        ops.group_mean(self.d_out[:B], 1, self.wgan_mean)                              # loss_WGAN_G = -mean (:362)
+        self._d_forward(B, lambda l: self.sn.isig[l, 0:1], B, x=self.x0[B:2 * B], means=self.wgan_mean, groups=1)   # loss_WGAN_G = -mean (:362)
 
     def g_main(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
         """The generator step's forward, loss and backward (:345-366, without the value-only critic forward).  Two halves so
@@ -868,7 +866,6 @@ class StepEngine:
         """forward (unless the iteration's batched forward already ran), EIoU + its gradient, the re-crop for the critic's
         value forward, and the backward through the head and the up path"""
         B, S = self.B, self.S
-        self.eiou_acc.zero_()
         if not self._gall_valid:           # (else: forward done with the iteration's batch; group n_critic = these very buffers)
             self._prep_g()
             ops.pack_pair(pred, None, self.x0[:B])

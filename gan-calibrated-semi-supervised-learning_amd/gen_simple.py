@@ -132,8 +132,7 @@ class SimpleGenerator:
         """All n_critic + 1 generator calls of an iteration as one batch (see StepEngine.g_forward_all)."""
         eng, fa, B = self.eng, self.fa, self.eng.B
         ng = fa.n // B
-        ops.pack_pair(pred, None, fa.x8[:B])
-        fa.x8.view(ng, -1)[1:].copy_(fa.x8.view(ng, -1)[0])
+        ops.pack_pair(pred, None, fa.x8, reps=ng)          # the same input for every call
         if masks is None:
             ops.dropout_mask_gen(self.maskbuf, eng.seed * 131 + 20, eng.G.state)
         else:

@@ -27,9 +27,10 @@ def code(t: torch.Tensor) -> int:
 
 
 # ---- boundary
-def pack_pair(a, b, out):
+def pack_pair(a, b, out, reps=1):
+    """reps > 1: out holds reps copies of the packed batch back to back ([reps * B][S][S][8])"""
     B, _, S, _ = a.shape
-    call("gcssl_pack_pair", code(out), a, b, out, B, S)
+    call("gcssl_pack_pair", code(out), a, b, out, B, S, int(reps))
 
 
 def pack_interp(pred, gt, refined, alpha, out):
@@ -50,16 +51,18 @@ def prep_conv_weight(w, wf, wt, cout, cin, cinp, dt):
 class PrepBatch:
     """Argument block for gcssl_prep_conv_weights: layers = [(w, wf, wt, cout, cin, cinp), ...] (<= 8)."""
 
-    def __init__(self, layers, dt):
+    def __init__(self, layers, dt, c5=None):
+        """c5 = (w5 [1][C][4][4], w5p [16][C]): the critic head's fp32 re-pack rides along (prep_c5_weight)"""
         self.n, self.dt = len(layers), dt
-        self._keep = layers
+        self._keep = (layers, c5)
         self._w = _lib.ptr_array([l[0] for l in layers])
         self._wf = _lib.ptr_array([l[1] for l in layers])
         self._wt = _lib.ptr_array([l[2] for l in layers])
         self._co, self._ci, self._cp = (_lib.int_array([l[k] for l in layers]) for k in (3, 4, 5))
+        self._c5 = (c5[0], c5[1], c5[1].shape[1]) if c5 is not None else (None, None, 0)
 
     def run(self):
-        call("gcssl_prep_conv_weights", self.dt, self.n, self._w, self._wf, self._wt, self._co, self._ci, self._cp)
+        call("gcssl_prep_conv_weights", self.dt, self.n, self._w, self._wf, self._wt, self._co, self._ci, self._cp, *self._c5)
 
 
 def prep_c5_weight(w, wp):
@@ -165,8 +168,14 @@ class ReduceBatch:
     """Argument block for gcssl_wgrad_reduce_batch: layers = [dict(slab, nsplit, dw, cout, cin, cin_real[, coef, u, v])]
     (<= 8); u, v are 2-D history tensors that share row strides."""
 
-    def __init__(self, layers, nrank=0, accumulate="zeroed"):
+    def __init__(self, layers, nrank=0, accumulate="zeroed", nrep=0, rep_stride=0):
+        """optional per layer: coef_rep (replica 0 of the striped coefficient sums, added to coef), bias_rep + dbias (the
+        striped bias-gradient sums and where their total goes): the fold of ReplicaSum, nrep replicas rep_stride floats apart"""
         self.n, self.nrank = len(layers), nrank
+        self.nrep, self.rep_stride = nrep, rep_stride
+        opt = lambda key: (ctypes.c_void_p * len(layers))(*[l[key].data_ptr() if l.get(key) is not None else None for l in layers]) \
+            if any(l.get(key) is not None for l in layers) else None
+        self._crep, self._brep, self._dbias = opt("coef_rep"), opt("bias_rep"), opt("dbias")
         self._keep = layers
         self._slab = _lib.ptr_array([l["slab"] for l in layers])
         self._dw = _lib.ptr_array([l["dw"] for l in layers])
@@ -183,26 +192,32 @@ class ReduceBatch:
 
     def run(self):
         call("gcssl_wgrad_reduce_batch", self.n, self._slab, self._ns, self._dw, self._co, self._ci, self._cr, self._coef,
-             self._u, self._v, self.su, self.sv, self.nrank, self.acc)
+             self._u, self._v, self.su, self.sv, self.nrank, self.acc, self._crep, self._brep, self._dbias, self.nrep,
+             self.rep_stride)
 
 
 # ---- critic head
-def c5_fwd(x, wp, out):
+def c5_fwd(x, wp, out, group_mean=None, groups=0):
+    """group_mean (zeroed by the caller): += the means of `groups` equal chunks of out (== group_mean(out, groups, ...))"""
     N, Hi, Wi, _ = x.shape
-    call("gcssl_conv4x4s1_c1_fwd", code(x), x, _ld(x), wp, out, N, Hi, Wi, wp.shape[1])
+    call("gcssl_conv4x4s1_c1_fwd", code(x), x, _ld(x), wp, out, group_mean, int(groups), N, Hi, Wi, wp.shape[1])
+
+
+def _c4(consts):
+    c = [float(v) for v in consts] + [0.0] * (4 - len(consts))
+    return c[:4]
 
 
 def c5_dgrad(dx, wp, dout=None, consts=(0.0, 0.0, 0.0), group_n=1):
+    """consts: up to four per-sample-group constants standing in for dout"""
     N, Hi, Wi, _ = dx.shape
-    call("gcssl_conv4x4s1_c1_dgrad", code(dx), dout, float(consts[0]), float(consts[1]), float(consts[2]), group_n,
-         wp, dx, _ld(dx), N, Hi, Wi, wp.shape[1])
+    call("gcssl_conv4x4s1_c1_dgrad", code(dx), dout, *_c4(consts), group_n, wp, dx, _ld(dx), N, Hi, Wi, wp.shape[1])
 
 
 def c5_wgrad(x, dw, C, dout=None, consts=(0.0, 0.0, 0.0), group_n=1):
     """dw: fp32 [C][16] (PyTorch layout of the [1][C][4][4] weight), accumulated atomically."""
     N, Hi, Wi, _ = x.shape
-    call("gcssl_conv4x4s1_c1_wgrad", code(x), x, _ld(x), dout, float(consts[0]), float(consts[1]), float(consts[2]),
-         group_n, dw, N, Hi, Wi, C)
+    call("gcssl_conv4x4s1_c1_wgrad", code(x), x, _ld(x), dout, *_c4(consts), group_n, dw, N, Hi, Wi, C)
 
 
 # ---- norm / activation
@@ -238,12 +253,13 @@ def in_dbl_bwd(gb_a, qz, gb_zs, z, mean, rstd, gt_a, zt, C, act, cdot=None, q_ns
          z, _ld(z), z_kind, mean, rstd, gt_a, _ld(gt_a), zt, cdot, q_nslab, int(q_slab_stride), sat, N, H * W, C, act)
 
 
-def act_bwd(da, a, dzs, C, da2=None, gscale=None, group_n=0, bias=None, dbias=None, cdot=None, nrep=1, rep_stride=0, sat=None):
-    """da/da2: fp32 incoming gradients; a and dzs in the compute dtype."""
+def act_bwd(da, a, dzs, C, da2=None, gscale=None, group_n=0, bias=None, dbias=None, cdot=None, nrep=1, rep_stride=0, sat=None,
+            dotx=None, dot_out=None):
+    """da/da2: fp32 incoming gradients; a and dzs in the compute dtype.  dotx (compute dtype) + dot_out: dot_out += sum dotx*da."""
     N, H, W, _ = a.shape
     assert da.dtype == torch.float32 and (da2 is None or da2.dtype == torch.float32)
     call("gcssl_act_bwd", code(a), da, _ld(da), da2, _ld(da2) if da2 is not None else 0, a, _ld(a), gscale, group_n,
-         bias, dzs, _ld(dzs), dbias, cdot, nrep, rep_stride, sat, N, H * W, C)
+         bias, dzs, _ld(dzs), dbias, cdot, nrep, rep_stride, sat, dotx, _ld(dotx) if dotx is not None else 0, dot_out, N, H * W, C)
 
 
 def dot_accum(x, y, C, out):
@@ -262,10 +278,10 @@ class SnState:
         self.rows = [w.shape[0] for w in ws]
         self.cols = [w[0].numel() for w in ws]
         self.ws, self.us, self.vs = ws, us, vs
-        tbuf = torch.zeros(sum(self.cols), device=device)          # zero on entry, left zero by every iteration
+        tbuf = torch.zeros(2 * sum(self.cols), device=device)      # two halves per layer (chain parity): zero on entry, left zero
         self.t, off = [], 0
         for c in self.cols:
-            self.t.append(tbuf[off:off + c]); off += c
+            self.t.append(tbuf[off:off + 2 * c]); off += 2 * c
         self._tbuf = tbuf
         self.s = [torch.empty(r, device=device) for r in self.rows]
         self.nslots = nslots
@@ -281,9 +297,12 @@ class SnState:
         self._w, self._u, self._v = _lib.ptr_array(self.ws), _lib.ptr_array(self.us), _lib.ptr_array(self.vs)
         self._t, self._s = _lib.ptr_array(self.t), _lib.ptr_array(self.s)
 
-    def iterate(self, slot: int, iterate: bool = True):
+    def iterate(self, slot: int, iterate=True, zero=None):
+        """iterate: True / k = that many chained power iterations filling slots slot.., False / 0 = sigma only.
+        zero: a float tensor the closing launch also clears."""
         call("gcssl_sn_power_iter", self.n, self._w, self._u, self._v, self._t, self._s, self._rows, self._cols,
-             self.sigma, self.isig, self.u_hist, self.v_hist, self.su, self.sv, slot, self.nslots, int(iterate))
+             self.sigma, self.isig, self.u_hist, self.v_hist, self.su, self.sv, slot, self.nslots, int(iterate),
+             zero, zero.numel() if zero is not None else 0)
 
 
 # ---- GP, optimiser, heads

@@ -46,7 +46,9 @@ int gcssl_init_recrop(void);
 /* ---- boundary packing ------------------------------------------------------------------------------------
  * torch.cat([pred_patch, other_patch], 1) (cgan/models.py:257): two NCHW fp32 (B,3,S,S) tensors -> NHWC
  * [B][S*S][8] (channels 0-2 = a, 3-5 = b (zeros if b==NULL), 6-7 = 0). */
-int gcssl_pack_pair(int dtype, const float* a, const float* b, void* out, int B, int S, void* stream);
+int gcssl_pack_pair(int dtype, const float* a, const float* b, void* out, int B, int S, int reps, void* stream);
+/* reps >= 1: the packed batch is written reps times, B*S*S pixels apart (the generator's input for the n_critic + 1
+ * forwards of an iteration run as one batch: cgan/cgan_train_enhanced.py:311-312 and :348 read the same pred_patch). */
 /* interpolation alpha*real + (1-alpha)*fake of both halves (cgan/losses.py:203-204), alpha: [B]. */
 int gcssl_pack_interp(int dtype, const float* pred, const float* gt, const float* refined, const float* alpha,
                       void* out, int B, int S, void* stream);
@@ -65,7 +67,8 @@ int gcssl_unpack_grad(const float* g, float* ga, float* gb, int B, int S, void* 
 int gcssl_prep_conv_weight(int dtype, const float* w, void* wf, void* wt, int Cout, int Cin, int CinP, void* stream);
 /* the same for nl <= 8 layers in ONE launch (host arrays of device pointers / sizes). */
 int gcssl_prep_conv_weights(int dtype, int nl, const float* const* w, void* const* wf, void* const* wt, const int* Cout,
-                            const int* Cin, const int* CinP, void* stream);
+                            const int* Cin, const int* CinP, const float* w5, float* w5p, int C5, void* stream);
+/* w5 / w5p (both or neither): the critic head's weight rides along (== gcssl_prep_c5_weight(w5, w5p, C5)). */
 /* critic head weight [1][C][4][4] -> fp32 [16][C]. */
 int gcssl_prep_c5_weight(const float* w, float* wp, int C, void* stream);
 
@@ -116,15 +119,24 @@ int gcssl_wgrad_reduce(const float* slab, int nsplit, float* dw, int Cout, int C
  * cgan/cgan_train_enhanced.py:330,366); arrays are indexed by layer, nrank/strides/accumulate are shared. */
 int gcssl_wgrad_reduce_batch(int nl, const float* const* slab, const int* nsplit, float* const* dw, const int* Cout,
                              const int* Cin, const int* Cin_real, const float* const* coef, const float* const* u,
-                             const float* const* v, int ustride, int vstride, int nrank, int accumulate, void* stream);
+                             const float* const* v, int ustride, int vstride, int nrank, int accumulate,
+                             const float* const* coef_rep, const float* const* bias_rep, float* const* dbias, int nrep,
+                             int rep_stride, void* stream);
+/* coef_rep / bias_rep (nullable arrays of nullable pointers): replica 0 of the striped partial sums the backward kernels
+ * left (gcssl_in_act_bwd / gcssl_act_bwd with nrep > 1): coef[i][k] + sum_r coef_rep[i][k + r*rep_stride] is the coefficient
+ * used, and dbias[i][c] = sum_r bias_rep[i][c + r*rep_stride] (c < Cout[i]) is stored by tail workgroups -- the fold of
+ * gcssl_sum_replicas without a launch of its own. */
 
 /* ---- critic head Conv2d(512,1,k4,s1,p1,bias=False): cgan/models.py:252 ------------------------------------------
  * out [N][Hi-1][Wi-1] fp32.  dgrad/wgrad take either a dout tensor or per-group constants g0,g1,g2 (dout==NULL):
  * the WGAN seeds -1/(B hw), +1/(B hw) of cgan/cgan_train_enhanced.py:327-328 and the ones of cgan/losses.py:216. */
-int gcssl_conv4x4s1_c1_fwd(int dtype, const void* x, int ldx, const float* wp, float* out, int N, int Hi, int Wi, int C, void* stream);
-int gcssl_conv4x4s1_c1_dgrad(int dtype, const float* dout, float g0, float g1, float g2, int group_n, const float* wp,
+int gcssl_conv4x4s1_c1_fwd(int dtype, const void* x, int ldx, const float* wp, float* out, float* group_mean, int groups,
+                           int N, int Hi, int Wi, int C, void* stream);
+/* group_mean (nullable, `groups` floats, zeroed by the caller): += the mean of each of `groups` equal chunks of `out` -- the
+ * batch means of cgan/cgan_train_enhanced.py:327 / :362 without a launch of their own (== gcssl_group_mean afterwards). */
+int gcssl_conv4x4s1_c1_dgrad(int dtype, const float* dout, float g0, float g1, float g2, float g3, int group_n, const float* wp,
                              void* dx, int lddx, int N, int Hi, int Wi, int C, void* stream);
-int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dout, float g0, float g1, float g2, int group_n,
+int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dout, float g0, float g1, float g2, float g3, int group_n,
                              float* dw, int N, int Hi, int Wi, int C, void* stream);   /* dw[C][16] += (atomic) */
 
 /* ---- InstanceNorm2d(affine=False, eps=1e-5) + activation (+Dropout): cgan/models.py:59-63,73-76,114,241-242 -----
@@ -168,7 +180,10 @@ int gcssl_in_dbl_bwd(int dtype, const float* gb_a, int ldgb, const float* qz, in
 /* LeakyReLU backward for the norm-less layers (D.c1, G.down1; cgan/models.py:103,246), from the activation OUTPUT a. */
 int gcssl_act_bwd(int dtype, const float* da, int ldda, const float* da2, int ldda2, const void* a, int lda,
                   const float* gscale, int group_n, const float* bias, void* dzs, int lddz, float* dbias, float* cdot,
-                  int nrep, int rep_stride, unsigned int* sat, int N, int HW, int C, void* stream);
+                  int nrep, int rep_stride, unsigned int* sat, const void* dotx, int lddot, float* dot_out,
+                  int N, int HW, int C, void* stream);
+/* dotx / dot_out (both or neither; not with da2): dot_out += sum dotx * da with dotx [N][HW][lddot>=C] in `dtype` -- gcssl_dot_accum
+ * of the same operands folded into this pass (the <gb_zs, gt_z> spectral-norm term of the norm-less first layer). */
 /* dbias / cdot of the two backward entry points above may be striped: nrep replicas, rep_stride floats apart, each
  * workgroup adds to one of them (same-address float atomics serialise); nrep = 1 is the plain form.  This folds them:
  * dst[i][j] (=|+=) sum_r src[i][j + r*rep_stride] for nseg <= 8 segments of len[i] floats; bit i of accumulate
@@ -178,13 +193,16 @@ int gcssl_sum_replicas(int nseg, const float* const* src, float* const* dst, con
 int gcssl_dot_accum(int dtype, const void* x, int ldx, const float* y, int ldy, long pixels, int C, float* out, void* stream);
 
 /* ---- spectral norm power iteration (torch.nn.utils.spectral_norm, cgan/models.py:237-238) -----------------------
- * v <- normalize(W^T u), u <- normalize(W v), eps 1e-12; sigma = u.(W v).  nl <= 4 layers per call; iterate=0 only
- * evaluates sigma (eval mode).  History slot `slot` of u_hist/v_hist/sigma/isig receives this iteration's values.
- * t[i] (cols[i] floats) must be ZERO on entry and is left zero on exit; s[i] is rows[i] floats of scratch.  One
- * iteration may be in flight per process at a time (device-side completion counters). */
+ * v <- normalize(W^T u), u <- normalize(W v), eps 1e-12; sigma = u.(W v).  nl <= 4 layers per call.  iterate = k >= 1 runs k
+ * iterations back to back on the same weights (a critic step's real, fake and interpolated forwards each make one: :308,
+ * :316, cgan/losses.py:210) and fills history slots slot .. slot+k-1 of u_hist/v_hist/sigma/isig; iterate = 0 only evaluates
+ * sigma into `slot` (eval mode).  t[i] (2 * cols[i] floats) must be ZERO on entry and is left zero on exit; s[i] is rows[i]
+ * floats of scratch.  zero / nzero (nullable): nzero floats the call also clears -- the engine's per-step scalar block rides
+ * on the closing launch instead of a fill of its own. */
 int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* const* v, float* const* t, float* const* s,
                         const int* rows, const int* cols, float* sigma, float* isig, float* u_hist, float* v_hist,
-                        int hist_stride_u, int hist_stride_v, int slot, int nslots, int iterate, void* stream);
+                        int hist_stride_u, int hist_stride_v, int slot, int nslots, int iterate, float* zero, long nzero,
+                        void* stream);
 
 /* ---- fused generator up-path layer (cgan/models.py:72-74,112-118) ---------------------------------------------------------
  * ConvTranspose2d(K -> 64, k4 s2 p1, bias=False) + InstanceNorm2d + ReLU (+ the sums AdaptiveAvgPool2d(1) needs) as ONE
@@ -224,6 +242,9 @@ int gcssl_pool_fc_tanh_fwd(int dtype, const void* x, int ldx, float* pool_sum, c
 /* dw [4][64] and db [4] are accumulated atomically (caller zeroes them). */
 int gcssl_head_bwd(const float* g_delta, const float* traw, const float* pooled, const float* w, float scale, int B,
                    int HW, float* dw, float* db, float* da_bcast, void* stream);
+/* EIoU of apply_delta_to_bbox(pred_box, delta) against apply_delta_to_bbox(pred_box, delta_true) (training form): *loss_acc =
+ * -mean(eiou) (STORED: one workgroup walks the batch, no atomics, no fill in front), calibrated = the boxes,
+ * g_delta = lambda_iou * d(1 - mean eiou)/d delta. */
 int gcssl_eiou_fwd_bwd(const float* pred_box, const float* delta, const float* delta_true, int B, float lambda_iou,
                        float* g_delta, float* calibrated, float* loss_acc, void* stream);
 

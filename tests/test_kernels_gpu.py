@@ -374,11 +374,12 @@ def test_critic_head(ops, dt, tol, N, H, C):
     assert rel_err(dw.cpu().view(1, C, 4, 4), conv2d_weight(x, w.shape, dconst.contiguous(), 1, 1)) < max(tol, 1e-4)
 
 
+@pytest.mark.parametrize("chained", [False, True])
 @pytest.mark.parametrize("shapes", [
     [(64, 6 * 16), (128, 64 * 16), (256, 128 * 16), (512, 256 * 16)],     # the critic's layers
     [(6, 18), (33, 130), (70, 1027), (67, 4100)],   # ragged rows; columns that are not a multiple of 4 (scalar forms) / of 1024
 ])
-def test_spectral_norm_power_iteration(ops, shapes):
+def test_spectral_norm_power_iteration(ops, shapes, chained):
     from oracle import manual_step as M
     ws = [rnd(r, c, seed=40 + i, scale=0.05) for i, (r, c) in enumerate(shapes)]
     us = [F.normalize(rnd(r, seed=50 + i), dim=0) for i, (r, _) in enumerate(shapes)]
@@ -390,9 +391,15 @@ def test_spectral_norm_power_iteration(ops, shapes):
     for i in range(4):
         s0 = torch.dot(us[i], ws[i] @ vs[i])
         assert abs(float(sn.sigma[i, 0]) - float(s0)) < 1e-5 * abs(float(s0)) + 1e-7
-    for k in range(3):
-        sn.iterate(k)
+    extra = torch.full((1000,), 3.0, device="cuda")
+    if chained:       # three iterations as ONE chain: each W^T u closes its predecessor, one closing launch (+ the caller's fill)
+        sn.iterate(0, 3, zero=extra)
+    else:
+        for k in range(3):
+            sn.iterate(k)
     torch.cuda.synchronize()
+    assert float(extra.abs().max()) == (0.0 if chained else 3.0)
+    assert all(float(t.abs().max()) == 0.0 for t in sn.t)          # both halves of the scratch are left zero
     for i in range(4):
         u, v = us[i], vs[i]
         for k in range(3):
@@ -403,6 +410,64 @@ def test_spectral_norm_power_iteration(ops, shapes):
             assert abs(float(sn.sigma[i, k]) - float(s)) < 2e-5 * float(s)
             assert abs(float(sn.isig[i, k]) * float(s) - 1) < 2e-5
         assert rel_err(ud[i].cpu(), u) < 2e-5 and rel_err(vd[i].cpu(), v) < 2e-5
+
+
+def test_launch_folds(ops):
+    """The bookkeeping that rides on neighbouring launches (round 3): group means from the head conv, four group constants
+    of the head's weight gradient, replicated input packing, <x, da> inside act_bwd, the critic head's re-pack inside the
+    batched weight re-pack, the striped-sum fold inside the batched split-K reduction."""
+    dt = torch.float16
+    # ---- c5_fwd + group means; c5_wgrad with four group constants == two launches with three
+    N, H, C = 12, 4, 512
+    x = q(rnd(N, C, H, H, seed=90), dt); w5 = rnd(1, C, 4, 4, seed=91, scale=0.05)
+    wp = torch.empty(16, C, device="cuda"); ops.prep_c5_weight(w5.cuda(), wp)
+    xd = nhwc(x, dt)
+    out = torch.empty(N, H - 1, H - 1, device="cuda"); means = torch.zeros(3, device="cuda")
+    ops.c5_fwd(xd, wp, out, group_mean=means, groups=3)
+    ref = F.conv2d(x.double(), w5.double(), None, 1, 1)[:, 0]
+    assert rel_err(out.cpu(), ref) < 1e-5
+    assert rel_err(means.cpu(), ref.reshape(3, -1).mean(1)) < 1e-5
+    dw_a = torch.zeros(C, 16, device="cuda"); dw_b = torch.zeros(C, 16, device="cuda")
+    ops.c5_wgrad(xd, dw_a, C, consts=(-0.5, 0.25, 0.0, 1.0), group_n=3)
+    ops.c5_wgrad(xd[:9], dw_b, C, consts=(-0.5, 0.25, 0.0), group_n=3)
+    ops.c5_wgrad(xd[9:], dw_b, C, consts=(1.0, 1.0, 1.0), group_n=3)
+    assert rel_err(dw_a.cpu(), dw_b.cpu()) < 1e-5
+    # ---- pack_pair with repetitions
+    a = rnd(3, 3, 32, 32, seed=92)
+    one = torch.empty(3, 32, 32, 8, device="cuda", dtype=dt); rep = torch.empty(9, 32, 32, 8, device="cuda", dtype=dt)
+    ops.pack_pair(a.cuda(), None, one); ops.pack_pair(a.cuda(), None, rep, reps=3)
+    assert all(torch.equal(rep[3 * r:3 * r + 3], one) for r in range(3))
+    # ---- act_bwd with the folded dot product
+    av = q(F.leaky_relu(rnd(4, 64, 16, 16, seed=93), 0.2), dt); da = rnd(4, 64, 16, 16, seed=94); xv = q(rnd(4, 64, 16, 16, seed=95), dt)
+    dz1 = torch.empty(4, 16, 16, 64, device="cuda", dtype=dt); dz2 = torch.empty_like(dz1)
+    d1 = torch.zeros(1, device="cuda"); d2 = torch.zeros(1, device="cuda")
+    ops.act_bwd(nhwc(da, torch.float32), nhwc(av, dt), dz1, 64, dotx=nhwc(xv, dt), dot_out=d1)
+    ops.act_bwd(nhwc(da, torch.float32), nhwc(av, dt), dz2, 64)
+    ops.dot_accum(nhwc(xv, dt), nhwc(da, torch.float32), 64, d2)
+    assert torch.equal(dz1, dz2) and abs(float(d1) - float(d2)) < 1e-4 * abs(float((xv * da).abs().sum()))
+    assert abs(float(d1) - float((xv.double() * da.double()).sum())) < 1e-4 * float((xv * da).abs().sum())
+    # ---- the head's re-pack inside the batched conv-weight re-pack
+    w = rnd(128, 64, 4, 4, seed=96, scale=0.05).cuda()
+    wf = torch.empty(128, 16, 64, device="cuda", dtype=dt); wt = torch.empty(64, 16, 128, device="cuda", dtype=dt)
+    wp2 = torch.full((16, C), float("nan"), device="cuda")
+    ops.PrepBatch([(w, wf, wt, 128, 64, 64)], ops.code(wf), c5=(w5.cuda(), wp2)).run()
+    assert torch.equal(wp2, wp)
+    wf1, wt1 = packed_weights(ops, w.cpu(), dt)
+    assert torch.equal(wf, wf1) and torch.equal(wt, wt1)
+    # ---- striped coefficient / bias sums folded into the batched reduction == ReplicaSum + plain batched reduction
+    Cout, Cin, ns, nrep, stride = 128, 64, 5, 8, 256
+    slab = rnd(ns, Cout, 16, Cin, seed=97).cuda()
+    u = rnd(3, Cout, seed=98).cuda(); v = rnd(3, Cin * 16, seed=99).cuda()
+    coef = rnd(3, seed=100).cuda(); reps = rnd(nrep, stride, seed=101).cuda()
+    dw1 = torch.zeros(Cout, Cin, 4, 4, device="cuda"); dw2 = torch.zeros_like(dw1)
+    db1 = torch.full((Cout,), float("nan"), device="cuda"); db2 = torch.empty(Cout, device="cuda")
+    coef2 = coef.clone()
+    ops.ReduceBatch([dict(slab=slab, nsplit=ns, dw=dw1, cout=Cout, cin=Cin, cin_real=Cin, coef=coef, u=u, v=v,
+                          coef_rep=reps[0, 200:203], bias_rep=reps[0, :Cout], dbias=db1)], nrank=3, nrep=nrep, rep_stride=stride).run()
+    ops.ReplicaSum([(reps[0, :Cout], db2, Cout, False), (reps[0, 200:203], coef2, 3, True)], nrep, stride).run()
+    ops.ReduceBatch([dict(slab=slab, nsplit=ns, dw=dw2, cout=Cout, cin=Cin, cin_real=Cin, coef=coef2, u=u, v=v)], nrank=3).run()
+    torch.cuda.synchronize()
+    assert rel_err(dw1.cpu(), dw2.cpu()) < 1e-5 and rel_err(db1.cpu(), db2.cpu()) < 1e-6
 
 
 def test_pack_interp_gp_norm_unpack(ops):
@@ -512,7 +577,7 @@ def test_generator_head_and_eiou(ops):
     fix = load_golden("loss_vectors")
     bbox, dl = torch.from_numpy(fix["bbox"]), torch.from_numpy(fix["delta"])
     dtrue = torch.from_numpy(load_pkg("synth").normal("kv.dt", 7, (16, 4), 0.1))
-    g = torch.empty(16, 4, device="cuda"); cal = torch.empty(16, 4, device="cuda"); acc = torch.zeros(1, device="cuda")
+    g = torch.empty(16, 4, device="cuda"); cal = torch.empty(16, 4, device="cuda"); acc = torch.full((1,), 7.0, device="cuda")   # (the loss is STORED)
     ops.eiou_fwd_bwd(bbox.cuda(), dl.cuda(), dtrue.cuda(), 1.0, g, cal, acc)
     assert abs(1.0 + float(acc) - float(fix["hybrid_total"])) < 1e-5
     assert rel_err(cal.cpu(), fix["apply_train"]) < 1e-5
