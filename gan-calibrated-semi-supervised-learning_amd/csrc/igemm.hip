@@ -236,6 +236,8 @@ struct ConvParams {
     // (pixel stride ldy); the whole H*W map of a sample lies inside one M tile, so the statistics need no second pass.
     float* in_mean; float* in_rstd;       // [N][Cout] fp32 outputs
     const uint8_t* in_mask;               // dropout keep mask [N][Ho*Wo][Cout] or null (kept values x 2)
+    int kcap;                             // timing experiment (GCSSL_KCAP, 3x3 persistent form only; results are garbage): walk only the
+                                          // first kcap K steps of every tile -- the K volume a Winograd F(2x2,3x3) GEMM stage would have
     void* in_apre; int ld_apre, apre_n0;  // optional second output: the activation WITHOUT dropout for samples n >= apre_n0
                                           // ([N - apre_n0][Ho*Wo][ld_apre]): what the backward rebuilds xhat from
 };
@@ -1083,7 +1085,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
     const int Ho = MODE == 2 ? p.Hi : p.Hi >> 1, Wo = MODE == 2 ? p.Wi : p.Wi >> 1;
     const int K = MODE == 0 ? 16 * p.Cin : MODE == 2 ? p.wk : 4 * p.Cout;
-    const int nk = K / BK;
+    const int nk = (MODE == 2 && p.kcap >= 2 && p.kcap < K / BK) ? p.kcap : K / BK;
     const int ncols = MODE != 1 ? p.Cout : p.Cin;
     const int row_t = tid / CH;
     const int lc = (tid % CH) ^ ((row_t >> 1) & 7);
@@ -2697,6 +2699,8 @@ int gcssl_conv3x3_fwd(int dtype, const void* x, int ldx, const void* w, const fl
     if (ldx % kv || !aligned16(x) || !aligned16(w)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = x; p.w = w; p.y = y; p.bias = bias; p.ldx = ldx; p.ldy = ldy; p.out_f32 = out_f32;
     p.N = N; p.Hi = H; p.Wi = W; p.Cin = Cin; p.Cout = Cout; p.wk = wk3(Cin);
+    static const int kcap = [] { const char* e = getenv("GCSSL_KCAP"); return e ? atoi(e) : 0; }();
+    p.kcap = kcap;
     p.lgWo = ilog2(W); p.lgHoWo = ilog2(H * W); p.lgCin = ilog2(Cin); p.lgCout = ilog2(Cout);
     p.M = N * H * W;
     if (!fill_bytes(p, (size_t)N * H * W * ldx, (size_t)Cout * p.wk, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;

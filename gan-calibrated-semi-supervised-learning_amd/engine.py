@@ -91,6 +91,21 @@ class FlatParams:
         raise KeyError(k)
 
 
+class _NoSpectralNorm:
+    """Stand-in for ops.SnState when the critic is built with spectral_norm=False (cgan/models.py:228-238, config.yaml
+    `spectral_norm: false`): sigma = 1 for every layer and forward, nothing to iterate; only the fill that rides on the
+    closing launch of a power-iteration chain is left to do."""
+
+    def __init__(self, n, nslots, device):
+        self.isig = torch.ones(n, nslots, device=device)
+        self.sigma = torch.ones(n, nslots, device=device)
+        self.u_hist = self.v_hist = None
+
+    def iterate(self, slot, iterate=True, zero=None):
+        if zero is not None:
+            zero.zero_()
+
+
 class GFwd:
     """Forward-pass buffers of the U-Net generator for a batch of n samples (activations, pre-norm tensors with their
     split-K slab room, statistics, dropout masks, head)."""
@@ -131,7 +146,7 @@ class StepEngine:
                  n_critic: int = 2, dtype="bf16", device="cuda", lr: float = 2e-4, betas=(0.5, 0.999),
                  delta_scale: float = 0.3, lambda_gp: float = 1.0, lambda_iou: float = 1.0, seed: int = 42,
                  allreduce: Optional[Callable[[torch.Tensor], None]] = None, keep_clipped_grads: bool = True,
-                 overlap: int = 0, generator_type: str = "unet"):
+                 overlap: int = 0, generator_type: str = "unet", spectral_norm: bool = True):
         if generator_type not in ("unet", "simple"):
             raise ValueError(f"generator_type must be 'unet' or 'simple' (cgan/cgan_train_enhanced.py:26-31), got {generator_type!r}")
         self.generator_type = generator_type
@@ -163,12 +178,20 @@ class StepEngine:
         _lib.call_nostream("gcssl_init")                            # dynamic-LDS opt-ins, before any graph capture
         dev = self.dev
         f32 = dict(device=dev, dtype=torch.float32)
-        self.D = FlatParams({k: sd_d[k].to(dev, torch.float32) for k in D_PARAM_KEYS}, D_PARAM_KEYS, dev)
+        # spectral_norm=False: Discriminator(spectral_norm=False) -- plain convs under the keys model.N.weight, sigma = 1
+        self.spectral_norm = bool(spectral_norm)
+        self.d_wkey = (lambda i: f"model.{i}.weight_orig") if self.spectral_norm else (lambda i: f"model.{i}.weight")
+        self.d_keys = D_PARAM_KEYS if self.spectral_norm else [k.replace("weight_orig", "weight") for k in D_PARAM_KEYS]
+        self.D = FlatParams({k: sd_d[k].to(dev, torch.float32) for k in self.d_keys}, self.d_keys, dev)
         g_keys = GS_PARAM_KEYS if generator_type == "simple" else G_PARAM_KEYS
         self.G = FlatParams({k: sd_g[k].to(dev, torch.float32) for k in g_keys}, g_keys, dev)
-        self.u = [sd_d[f"model.{i}.weight_u"].to(dev, torch.float32).clone() for i in D_IDX]
-        self.v = [sd_d[f"model.{i}.weight_v"].to(dev, torch.float32).clone() for i in D_IDX]
-        self.sn = ops.SnState([self.D.views[f"model.{i}.weight_orig"] for i in D_IDX], self.u, self.v, 3, dev)
+        if self.spectral_norm:
+            self.u = [sd_d[f"model.{i}.weight_u"].to(dev, torch.float32).clone() for i in D_IDX]
+            self.v = [sd_d[f"model.{i}.weight_v"].to(dev, torch.float32).clone() for i in D_IDX]
+            self.sn = ops.SnState([self.D.views[self.d_wkey(i)] for i in D_IDX], self.u, self.v, 3, dev)
+        else:
+            self.u, self.v = [], []
+            self.sn = _NoSpectralNorm(len(D_IDX), 3, dev)
         self._zcap, self._zkeep, self._splits = {}, [], {}
         self.grad_slabs = os.environ.get("GCSSL_GRAD_SLABS", "1") != "0"
         # one batched generator forward per iteration (g_forward_all); GCSSL_BATCH_G=0: one forward per call, for A/B runs
@@ -459,12 +482,13 @@ class StepEngine:
     def _reduce_batches(self):
         """One launch reduces the split-K slabs of every layer of a backward pass (+ the spectral-norm rank-1 terms)."""
         if self._red_d is None:
+            sn = self.spectral_norm           # (without it: no quotient rule, only the slabs and the striped bias sums)
             self._red_d = ops.ReduceBatch(
-                [dict(slab=self.d_slab[l], nsplit=sum(self.d_ns[l]), dw=self.D.gviews[f"model.{i}.weight_orig"], cout=cout,
-                      cin=_pad8(cin), cin_real=cin, coef=self.cdot[l], u=self.sn.u_hist[l], v=self.sn.v_hist[l],
-                      coef_rep=self.rep[0, 960 + 3 * l:963 + 3 * l],
+                [dict(slab=self.d_slab[l], nsplit=sum(self.d_ns[l]), dw=self.D.gviews[self.d_wkey(i)], cout=cout,
+                      cin=_pad8(cin), cin_real=cin, coef=self.cdot[l] if sn else None, u=self.sn.u_hist[l] if sn else None,
+                      v=self.sn.v_hist[l] if sn else None, coef_rep=self.rep[0, 960 + 3 * l:963 + 3 * l] if sn else None,
                       bias_rep=self.rep[0, self.rep_bias_off[l]:self.rep_bias_off[l] + cout], dbias=self.D.gviews[f"model.{i}.bias"])
-                 for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX))], nrank=3, nrep=self.NREP, rep_stride=self.REP_STRIDE)
+                 for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX))], nrank=3 if sn else 0, nrep=self.NREP, rep_stride=self.REP_STRIDE)
             if self.gen is not None:                               # the simple generator reduces its own 3x3 slabs
                 return self._red_d, None
             gW = self.G.gviews
@@ -482,7 +506,7 @@ class StepEngine:
             return
         if self._prep_d_batch is None:
             self._prep_d_batch = ops.PrepBatch(
-                [(self.D.views[f"model.{i}.weight_orig"], self.d_wf[l], self.d_wt[l], cout, cin, _pad8(cin))
+                [(self.D.views[self.d_wkey(i)], self.d_wf[l], self.d_wt[l], cout, cin, _pad8(cin))
                  for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX))], self.code,
                 c5=(self.D.views["model.11.weight"], self.d_w5p))         # the head's fp32 re-pack rides on the same launch
         self._prep_d_batch.run()
@@ -999,9 +1023,10 @@ class StepEngine:
         """(generator_state_dict, discriminator_state_dict) keyed like the reference."""
         g = {k: v.detach().clone() for k, v in self.G.views.items()}
         d = {k: v.detach().clone() for k, v in self.D.views.items()}
-        for l, i in enumerate(D_IDX):
-            d[f"model.{i}.weight_u"] = self.u[l].clone()
-            d[f"model.{i}.weight_v"] = self.v[l].clone()
+        if self.spectral_norm:
+            for l, i in enumerate(D_IDX):
+                d[f"model.{i}.weight_u"] = self.u[l].clone()
+                d[f"model.{i}.weight_v"] = self.v[l].clone()
         return g, d
 
 

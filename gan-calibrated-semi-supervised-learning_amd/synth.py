@@ -72,8 +72,9 @@ G_DOWN = [(3, 64), (64, 128), (128, 256), (256, 512)]         # Conv2d weight [C
 G_UP = [(512, 256), (512, 128), (256, 64), (128, 64)]         # ConvTranspose2d weight [Cin,Cout,4,4]
 
 
-def discriminator_state(seed: int) -> dict:
-    """state_dict-shaped numpy arrays for Discriminator(spectral_norm=True).
+def discriminator_state(seed: int, spectral_norm: bool = True) -> dict:
+    """state_dict-shaped numpy arrays for Discriminator(spectral_norm=True); with spectral_norm=False the same values under the
+    plain-conv keys ``model.N.weight`` (no u, v): ``conv_block`` without the hook (cgan/models.py:235-243).
 
     Conv weights ~N(0,0.02) and zero biases as ``weights_init_normal`` leaves them
     (cgan/models.py:37-48); u,v are unit vectors as ``spectral_norm`` initialises them.
@@ -88,6 +89,8 @@ def discriminator_state(seed: int) -> dict:
         sd[f"model.{i}.weight_u"] = (u / np.sqrt((u * u).sum())).astype(np.float32)
         sd[f"model.{i}.weight_v"] = (v / np.sqrt((v * v).sum())).astype(np.float32)
     sd["model.11.weight"] = normal("D.11.w", seed, (1, 512, 4, 4), 0.02)
+    if not spectral_norm:
+        sd = {k.replace("weight_orig", "weight"): v for k, v in sd.items() if not k.endswith(("weight_u", "weight_v"))}
     return sd
 
 

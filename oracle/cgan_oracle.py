@@ -267,18 +267,22 @@ class StepOracle:
 
     def __init__(self, sd_g: Dict[str, Tensor], sd_d: Dict[str, Tensor], lr: float = 2e-4,
                  betas=(0.5, 0.999), delta_scale: float = 0.3, lambda_gp: float = 1.0,
-                 lambda_iou: float = 1.0, n_critic: int = 2, generator_type: str = "unet"):
+                 lambda_iou: float = 1.0, n_critic: int = 2, generator_type: str = "unet", spectral_norm: bool = True):
         # generator_type: get_generator(), cgan/cgan_train_enhanced.py:26-31
+        # spectral_norm: Discriminator(spectral_norm=...), cgan/models.py:228-238 (config.yaml `spectral_norm`): plain convs
+        # under the keys model.N.weight when off
+        self.sn = spectral_norm
+        self.d_keys = D_PARAM_KEYS if spectral_norm else [k.replace("weight_orig", "weight") for k in D_PARAM_KEYS]
         self.g_keys = GS_PARAM_KEYS if generator_type == "simple" else G_PARAM_KEYS
         self.g_fwd = g_simple_forward if generator_type == "simple" else g_forward
         self.g = {k: v.clone().float() for k, v in sd_g.items()}
         self.d = {k: v.clone().float() for k, v in sd_d.items()}
         for k in self.g_keys:
             self.g[k].requires_grad_(True)
-        for k in D_PARAM_KEYS:
+        for k in self.d_keys:
             self.d[k].requires_grad_(True)
         self.opt_g = Adam([self.g[k] for k in self.g_keys], lr, betas)
-        self.opt_d = Adam([self.d[k] for k in D_PARAM_KEYS], lr, betas)
+        self.opt_d = Adam([self.d[k] for k in self.d_keys], lr, betas)
         self.delta_scale, self.lambda_gp, self.lambda_iou, self.n_critic = \
             delta_scale, lambda_gp, lambda_iou, n_critic
 
@@ -288,21 +292,21 @@ class StepOracle:
         log = {"d_loss": [], "gp": [], "wd": [], "d_grad_norm": []}
         for c in range(self.n_critic):                                       # :304
             tp = taps if (taps is not None and c == 0) else None
-            for k in D_PARAM_KEYS:                                           # :305 zero_grad
+            for k in self.d_keys:                                            # :305 zero_grad
                 self.d[k].grad = None
-            real = d_forward(self.d, pred, gt, True)                         # :308
+            real = d_forward(self.d, pred, gt, True, self.sn)                # :308
             with torch.no_grad():                                            # :311-315
                 delta_det = self.g_fwd(self.g, pred, self.delta_scale, masks[c])
                 refined = refine_fn(delta_det, c)
-            fake = d_forward(self.d, pred, refined, True)                    # :316
-            gp = gradient_penalty(self.d, (pred, gt), (pred, refined), alphas[c], taps=tp)  # :319-324
+            fake = d_forward(self.d, pred, refined, True, self.sn)           # :316
+            gp = gradient_penalty(self.d, (pred, gt), (pred, refined), alphas[c], self.sn, taps=tp)  # :319-324
             wd = real.mean() - fake.mean()                                   # :327
             d_loss = -wd + self.lambda_gp * gp                               # :328
-            grads = list(torch.autograd.grad(d_loss, [self.d[k] for k in D_PARAM_KEYS]))  # :330
+            grads = list(torch.autograd.grad(d_loss, [self.d[k] for k in self.d_keys]))  # :330
             if tp is not None:
                 tp["real_validity"], tp["fake_validity"] = real.detach().clone(), fake.detach().clone()
                 tp["delta_detached"] = delta_det.detach().clone()
-                for k, g in zip(D_PARAM_KEYS, grads):
+                for k, g in zip(self.d_keys, grads):
                     tp[f"d.grad.{k}"] = g.detach().clone()
             total = clip_grad_norm_(grads, 1.0)                              # :331
             self.opt_d.step(grads)                                           # :332
@@ -318,7 +322,7 @@ class StepOracle:
         loss_reg = self.lambda_iou * loss_iou
         refined_g = refine_fn(delta_pred.detach(), self.n_critic)            # :358-360 (no edge)
         with torch.no_grad():                                                # value only
-            fake_g = d_forward(self.d, pred, refined_g, True)                # :361 (advances u,v)
+            fake_g = d_forward(self.d, pred, refined_g, True, self.sn)       # :361 (advances u,v)
         loss_wgan = -fake_g.mean()                                           # :362
         grads = list(torch.autograd.grad(loss_reg, [self.g[k] for k in self.g_keys]))         # :366
         if taps is not None:

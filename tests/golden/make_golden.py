@@ -58,9 +58,9 @@ def g_state(seed: int, generator_type: str):
     return synth.simple_generator_state(seed) if generator_type == "simple" else synth.generator_state(seed)
 
 
-def build_nets(seed: int, generator_type: str = "unet"):
-    D = ref_models.Discriminator(spectral_norm=True)
-    D.load_state_dict({k: T(v) for k, v in synth.discriminator_state(seed).items()})
+def build_nets(seed: int, generator_type: str = "unet", spectral_norm: bool = True):
+    D = ref_models.Discriminator(spectral_norm=spectral_norm)
+    D.load_state_dict({k: T(v) for k, v in synth.discriminator_state(seed, spectral_norm).items()})
     if generator_type == "simple":                       # get_generator(), cgan/cgan_train_enhanced.py:26-31
         G = ref_models.GeneratorSimpleRegressor(delta_scale=0.3)
         G.load_state_dict({k: T(v) for k, v in synth.simple_generator_state(seed).items()})
@@ -98,15 +98,15 @@ def pin(out: dict, name: str, t: torch.Tensor, full_limit: int = 70000):
 
 
 def run_case(name: str, seed: int, B: int, S: int, n_critic: int, iters: int, taps_full: bool,
-             gray28: bool = False, generator_type: str = "unet"):
-    G, D, drops = build_nets(seed, generator_type)
+             gray28: bool = False, generator_type: str = "unet", spectral_norm: bool = True):
+    G, D, drops = build_nets(seed, generator_type, spectral_norm)
     G.train(); D.train()
     opt_g = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
     opt_d = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
     crit = ref_losses.HybridLoss(lambda_iou=1.0)
     out = {"meta": np.array([seed, B, S, n_critic, iters, int(gray28)]),
            "wsum_g": checksum(g_state(seed, generator_type)),
-           "wsum_d": checksum(synth.discriminator_state(seed))}
+           "wsum_d": checksum(synth.discriminator_state(seed, spectral_norm))}
     lambda_gp = 1.0
     orig_rand = torch.rand
     for it in range(iters):
@@ -123,7 +123,7 @@ def run_case(name: str, seed: int, B: int, S: int, n_critic: int, iters: int, ta
             Pc = f"{P}c{c}."
             opt_d.zero_grad()
             real_validity = D(pred, gt)
-            if it == 0 and c == 0:
+            if it == 0 and c == 0 and spectral_norm:
                 for i in (0, 2, 5, 8):
                     out[f"{Pc}u_after_real.{i}"] = D.model[i].weight_u.numpy().copy()
             for d, m in zip(drops, inp["masks"][c]):
@@ -193,9 +193,10 @@ def run_case(name: str, seed: int, B: int, S: int, n_critic: int, iters: int, ta
         for k, v in G.state_dict().items():
             pin(out, f"{P}G.{k}", v, full_limit=5000)
     # Adam moments of two representative tensors after the last iteration
-    st = opt_d.state[D.model[2].weight_orig]
-    pin(out, "final.adam_m.D.model.2.weight_orig", st["exp_avg"], 5000)
-    pin(out, "final.adam_v.D.model.2.weight_orig", st["exp_avg_sq"], 5000)
+    wkey = "weight_orig" if spectral_norm else "weight"
+    st = opt_d.state[getattr(D.model[2], wkey)]
+    pin(out, f"final.adam_m.D.model.2.{wkey}", st["exp_avg"], 5000)
+    pin(out, f"final.adam_v.D.model.2.{wkey}", st["exp_avg_sq"], 5000)
     gkey, gparam = ("features.24.weight", G.features[24].weight) if generator_type == "simple" else ("up4.0.weight", G.up4[0].weight)
     st = opt_g.state[gparam]
     pin(out, f"final.adam_m.G.{gkey}", st["exp_avg"], 5000)
@@ -281,6 +282,9 @@ if __name__ == "__main__":
         forward_case("fwd_simple_B2_S32", 42, 2, 32, generator_type="simple")
         run_case("step_simple_B4_S32", 46, 4, 32, n_critic=2, iters=2, taps_full=True, generator_type="simple")
         run_case("step_simple_B2_S64", 47, 2, 64, n_critic=1, iters=1, taps_full=False, generator_type="simple")
+        sys.exit(0)
+    if sys.argv[1:] == ["nosn"]:            # only the Discriminator(spectral_norm=False) fixture (config.yaml `spectral_norm: false`)
+        run_case("step_nosn_B4_S32", 48, 4, 32, n_critic=2, iters=1, taps_full=True, spectral_norm=False)
         sys.exit(0)
     loss_vectors()
     forward_case("fwd_B2_S32", 42, 2, 32)

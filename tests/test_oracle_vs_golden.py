@@ -19,9 +19,13 @@ def _gstate(synth, seed, gtype="unet"):
     return synth.simple_generator_state(seed) if gtype == "simple" else synth.generator_state(seed)
 
 
-def _state(synth, seed, gtype="unet"):
+def _sn(name):
+    return "nosn" not in name                             # Discriminator(spectral_norm=False): config.yaml `spectral_norm: false`
+
+
+def _state(synth, seed, gtype="unet", spectral_norm=True):
     g = {k: T(v) for k, v in _gstate(synth, seed, gtype).items()}
-    d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+    d = {k: T(v) for k, v in synth.discriminator_state(seed, spectral_norm).items()}
     return g, d
 
 
@@ -30,12 +34,13 @@ def _wsum(sd):
                     + [float(np.abs(np.asarray(v, dtype=np.float64)).sum()) for _, v in sorted(sd.items())])
 
 
-@pytest.mark.parametrize("name", ["fwd_B2_S32", "fwd_B2_S64", "step_B4_S32", "fwd_simple_B2_S32", "step_simple_B4_S32"])
+@pytest.mark.parametrize("name", ["fwd_B2_S32", "fwd_B2_S64", "step_B4_S32", "fwd_simple_B2_S32", "step_simple_B4_S32",
+                                  "step_nosn_B4_S32"])
 def test_deterministic_weights_regenerate_bit_exact(synth, name):
     fix = load_golden(name)
     seed = int(fix["meta"][0])
     assert np.array_equal(_wsum(_gstate(synth, seed, _gtype(name))), fix["wsum_g"])
-    assert np.array_equal(_wsum(synth.discriminator_state(seed)), fix["wsum_d"])
+    assert np.array_equal(_wsum(synth.discriminator_state(seed, _sn(name))), fix["wsum_d"])
 
 
 def test_loss_known_answers():
@@ -103,8 +108,8 @@ def run_oracle_case(synth, name):
     fix = load_golden(name)
     seed, B, S, n_critic, iters, gray = (int(v) for v in fix["meta"])
     gtype = _gtype(name)
-    g, d = _state(synth, seed, gtype)
-    orc = O.StepOracle(g, d, n_critic=n_critic, generator_type=gtype)
+    g, d = _state(synth, seed, gtype, _sn(name))
+    orc = O.StepOracle(g, d, n_critic=n_critic, generator_type=gtype, spectral_norm=_sn(name))
     logs, taps0 = [], {}
     for it in range(iters):
         inp = synth.step_inputs(seed + 1000 * it, B, S, n_critic, tag=name, generator_type=gtype)
@@ -121,7 +126,7 @@ def run_oracle_case(synth, name):
 
 
 @pytest.mark.parametrize("name", ["step_B4_S32", "step_B2_S64", "step_B2_S128", "step_mnist_B4_S32",
-                                  "step_simple_B4_S32", "step_simple_B2_S64"])
+                                  "step_simple_B4_S32", "step_simple_B2_S64", "step_nosn_B4_S32"])
 def test_training_step(synth, name):
     fix, orc, logs, taps = run_oracle_case(synth, name)
     n_critic, iters = int(fix["meta"][3]), int(fix["meta"][4])
@@ -135,7 +140,9 @@ def test_training_step(synth, name):
         for c in range(n_critic):
             sc = fix[f"it{it}.c{c}.scalars"]
             got = np.array([lg["d_loss"][c], lg["gp"][c], lg["wd"][c], lg["d_grad_norm"][c]])
-            assert rel_err(got, sc) < tol, (it, c, got, sc)
+            # (without the spectral norm the critic's weights are 1/sigma ~ 7x larger in effect: the second critic step, behind
+            #  one Adam update, measured 5.7e-5 on the gradient norm)
+            assert rel_err(got, sc) < (tol if (c == 0 or _sn(name)) else max(tol, 2e-4)), (it, c, got, sc)
         gs = fix[f"it{it}.gscalars"]
         got = np.array([lg["loss_g"], lg["loss_iou"], lg["loss_wgan"], lg["g_grad_norm"]])
         assert rel_err(got, gs) < tol, (it, got, gs)
@@ -146,7 +153,7 @@ def test_training_step(synth, name):
         check_pinned(fix, "it0.c0.gp_grad_other", taps["gp_grad_other"], 5e-5, synth)
         assert rel_err(taps["real_validity"], fix["it0.c0.real_validity"]) < TOL
         assert rel_err(taps["fake_validity"], fix["it0.c0.fake_validity"]) < TOL
-        for k in O.D_PARAM_KEYS:
+        for k in orc.d_keys:
             if k in ("model.2.bias", "model.5.bias", "model.8.bias"):
                 continue   # exactly-zero gradient (bias cancelled by InstanceNorm): rounding noise only
             check_pinned(fix, f"it0.c0.dgrad.{k}", taps[f"d.grad.{k}"], 2e-4, synth)

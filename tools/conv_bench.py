@@ -1,5 +1,6 @@
 """Standalone launcher of ONE conv configuration (for rocprofv3 --pmc / timing experiments).
-usage: python tools/conv_bench.py {fwd|dgrad|wgrad} N Hi Cin Cout [dtype] [reps]"""
+usage: python tools/conv_bench.py {fwd|fwd_in|dgrad|wgrad} N Hi Cin Cout [dtype] [reps]
+(fwd_in: the one-launch conv + InstanceNorm + LeakyReLU form, 16-bit activation + fp32 statistics out)"""
 import importlib, sys, time, torch
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -16,8 +17,11 @@ y = torch.empty(N, Hi // 2, Hi // 2, Cout, device="cuda", dtype=torch.float32)
 dx = torch.empty(N, Hi, Hi, Cin, device="cuda", dtype=torch.float32)
 ns = ops.wgrad_splits(N, Hi, Hi, Cin, Cout)
 slab = torch.empty(ns, Cout, 16, Cin, device="cuda")
+a16 = torch.empty(N, Hi // 2, Hi // 2, Cout, device="cuda", dtype=dt)
+mean = torch.empty(N, Cout, device="cuda"); rstd = torch.empty(N, Cout, device="cuda")
 def run():
     if kind == "fwd": ops.conv_fwd(x, wf, y, Cin, Cout)
+    elif kind == "fwd_in": ops.conv_in_act_fwd(x, wf, a16, mean, rstd, Cin, Cout)
     elif kind == "dgrad": ops.conv_dgrad(dy, wt, dx, Cin, Cout)
     else: ops.conv_wgrad(x, dy, slab, Cin, Cout)
 for _ in range(3): run()

@@ -2,11 +2,13 @@
 """Fold tools/pmc_round2.sh's passes into one JSON: per engine label the HBM bytes of one launch (FETCH_SIZE doubled per
 MI355X_MICROARCH.md 'HBM', + WRITE_SIZE; both KiB), its duration under the profiler, and the SQ counters with the MFMA-busy
 fraction (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CYCLES per CU ...) is left to the reader: raw sums are stored).
-usage: python tools/pmc_round2_summary.py gpurun_out/pmc_r2 fp16"""
+usage: python tools/pmc_round2_summary.py gpurun_out/pmc_r2 fp16 [out.json] [script name]   (round 3: tools/pmc_round3.sh)"""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
 out_dir, dt = sys.argv[1], sys.argv[2]
+out_name = sys.argv[3] if len(sys.argv) > 3 else "round2_pmc_dominant.json"
+script = sys.argv[4] if len(sys.argv) > 4 else "tools/pmc_round2.sh"
 CASES = {"D.c2.fwd[n=768]": "conv_dma", "D.c3.fwd[n=768]": "conv_dma", "D.c4.fwd[n=768]": "conv_dma", "D.c2.wgrad": "conv_wgrad",
          "D.c3.wgrad": "conv_wgrad", "D.c4.wgrad": "conv_wgrad", "D.c2.dgrad": "conv_dma", "D.c3.dgrad": "conv_dma", "D.c4.dgrad": "conv_dma", "D.c1.fwd[n=768]": "conv_",
          "D.c1.gp_dgrad": "conv_", "G.up4.fwd[n=768]": "convt_in_relu"}
@@ -45,12 +47,12 @@ for tag, flt in CASES.items():
         rec["mfma_busy_frac_of_simd_time"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
     labels[tag] = rec
 res = dict(config=[256, 32, 2, dt, "unet"],
-           command="tools/pmc_round2.sh (rocprofv3 --kernel-trace --pmc <set>, separate passes, tools/conv_bench.py / tools/convt_bench.py "
+           command=script + " (rocprofv3 --kernel-trace --pmc <set>, separate passes, tools/conv_bench.py / tools/convt_bench.py "
                    "launching the label's shape stand-alone)",
            note="FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md). The stand-alone "
                 "launch re-reads the same operands each repetition, so Infinity-Cache hits are counted as the guide says; wgrad bytes "
                 "include the fp32 slabs.",
            labels=labels)
-json.dump(res, open(os.path.join(out_dir, "round2_pmc_dominant.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out_dir, out_name), "w"), indent=1)
 for k, v in labels.items():
     print(k, {kk: (round(vv, 1) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk not in ("counters_avg_per_launch", "kernel", "kernel_filter")})

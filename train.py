@@ -113,8 +113,6 @@ def main(argv=None):
     args = build_parser(config).parse_args(argv)
     if args.generator_type not in ("unet", "simple"):
         raise SystemExit(f"unknown generator_type {args.generator_type!r} (cgan/cgan_train_enhanced.py:26-31: 'unet' or 'simple')")
-    if not args.spectral_norm:
-        raise SystemExit("the step engine implements the reference default spectral_norm=true")
     torch.manual_seed(args.seed)
     if not torch.cuda.is_available():
         raise SystemExit("train.py needs an MI355X (the HIP path has no CPU fallback)")
@@ -139,7 +137,8 @@ def main(argv=None):
                             n_critic=args.n_critic, dtype=args.compute_dtype, device=device, lr=args.lr,
                             betas=(args.beta1, args.beta2), delta_scale=args.delta_scale, lambda_gp=args.lambda_gp,
                             lambda_iou=args.lambda_iou, seed=args.seed + rank,
-                            allreduce=dist_mod.GradAverager() if world > 1 else None, generator_type=args.generator_type)
+                            allreduce=dist_mod.GradAverager() if world > 1 else None, generator_type=args.generator_type,
+                            spectral_norm=args.spectral_norm)            # (config.yaml `spectral_norm`, cgan/models.py:228-238)
     if world > 1:
         dist_mod.broadcast_state([eng.D.p, eng.G.p] + eng.u + eng.v)
     train_idx, val_idx = None, []
