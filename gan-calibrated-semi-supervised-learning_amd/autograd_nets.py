@@ -102,7 +102,7 @@ class DTape:
         self.h = (S >> 4) - 1
         out = torch.empty(B, self.h, self.h, device=dev, dtype=F32)
         ops.c5_fwd(self.a[3], self.w5p, out)
-        self.ws = torch.empty(2 * B * 512, device=dev, dtype=F32)
+        self.ws = self.ws_g = torch.empty(2 * B * 512, device=dev, dtype=F32)    # (the step engine keeps a separate one for the generator)
         return out.view(B, 1, self.h, self.h)
 
     def _backward_chain(self, da3, zt=None, keep=False):
@@ -403,7 +403,7 @@ class _SimpleHost:
         self.B, self.S, self.code, self.T, self.dev = B, S, code, _lib.torch_dtype(code), dev
         self.delta_scale, self.seed = scale, 0
         self.G = FlatParams(params, list(params.keys()), dev)
-        self.ws = torch.empty(2 * B * 512, device=dev, dtype=F32)
+        self.ws = self.ws_g = torch.empty(2 * B * 512, device=dev, dtype=F32)    # (the step engine keeps a separate one for the generator)
         self.g_traw = torch.empty(B, 4, device=dev, dtype=F32)
         self.g_delta = torch.empty(B, 4, device=dev, dtype=F32)
         self.x8 = torch.empty(B, S, S, 8, device=dev, dtype=self.T)

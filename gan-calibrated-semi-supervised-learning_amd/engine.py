@@ -223,6 +223,14 @@ class StepEngine:
         # fills 256 CUs on its own.
         self.overlap = int(overlap)
         self.side = [torch.cuda.Stream(device=dev) for _ in range(2)] if overlap else []
+        # ONE coarse branch (round 3): the generator step's own work -- EIoU, backward through the head, the up and the down
+        # path, its split-K reduction: ~45 launches, 0.45 ms, none of which fills the chip -- does not depend on the critic
+        # (the WGAN term gives G no gradient) once the iteration's batched generator forward has run, and nothing
+        # in the critic steps reads what it writes.  It runs on a second stream beside the critic steps (one fork, one join
+        # per iteration; captured as a parallel graph branch).  Single-GPU schedule only: with data parallelism the same work
+        # already sits under the critic's all-reduces.  GCSSL_OVERLAP_G=0 restores the serial order.
+        self.overlap_g = int(os.environ.get("GCSSL_OVERLAP_G", "1")) and allreduce is None
+        self.side_g = torch.cuda.Stream(device=dev) if self.overlap_g else None
         self.probe = None          # {label: {"events": [(start, stop)...], "flops": f}} when profiling is enabled
 
     # ------------------------------------------------------------------------------------------ side-stream branches
@@ -424,6 +432,7 @@ class StepEngine:
         self.g_traw, self.g_delta = ga.traw[self.c * B:], ga.delta[self.c * B:]
         self._gall_valid = False
         self.ws = torch.empty(2 * N3 * 512, **f32)                 # scratch of the large-map InstanceNorm backward
+        self.ws_g = torch.empty(2 * B * 512, **f32)                # ... the generator's own (its backward may run beside the critic's)
         self.g_gdelta = torch.empty(B, 4, **f32)
         self.g_cal = torch.empty(B, 4, **f32)
         if not unet:
@@ -919,11 +928,11 @@ class StepEngine:
                 #  are its `cnt` output and the head's pooled mean x H*W: maps of > 256 pixels skip their pass over z)
                 pre = self._up4_presums and S * S > 256 and os.environ.get("GCSSL_UP4_PRESUM", "1") != "0"      # (A/B knob)
                 ops.in_act_bwd(self.g_zu[3], self.g_umean[3], self.g_urstd[3], self.g_dzu[3], coutt, RELU,
-                               da_bcast=self.g_dab, ws=self.ws, presum_cnt=self.g_ucnt if pre else None,
+                               da_bcast=self.g_dab, ws=self.ws_g, presum_cnt=self.g_ucnt if pre else None,
                                presum_pos=self.g_pooled if pre else None, presum_pos_scale=float(S * S), sat=self.sat_g)
             else:
                 ops.in_act_bwd(self.g_zu[k], self.g_umean[k], self.g_urstd[k], self.g_dzu[k], coutt, RELU,
-                               da=dcat[k + 1][..., :coutt], mask=self.g_masks[k + 1] if k < 2 else None, ws=self.ws, sat=self.sat_g)
+                               da=dcat[k + 1][..., :coutt], mask=self.g_masks[k + 1] if k < 2 else None, ws=self.ws_g, sat=self.sat_g)
             fl = conv_flops(B, S >> (3 - k), coutt, cint)
 
             def up_wgrad(k=k, cint=cint, coutt=coutt, fl=fl):
@@ -950,13 +959,15 @@ class StepEngine:
             cp = _pad8(cin)
             if k == 3:
                 ops.in_act_bwd(self._g_zsrc[3], self.g_dmean[3], self.g_drstd[3], self.g_dzd[3], 512, LRELU,
-                               da=self.g_dd4, mask=self.g_masks[0], ws=self.ws, da_nslab=ns4, da_slab_stride=st4, sat=self.sat_g)
+                               da=self.g_dd4, mask=self.g_masks[0], ws=self.ws_g, da_nslab=ns4, da_slab_stride=st4, sat=self.sat_g)
             elif k > 0:
                 ops.in_act_bwd(self._g_zsrc[k], self.g_dmean[k], self.g_drstd[k], self.g_dzd[k], cout, LRELU,
-                               da=self.g_dd[k + 1], da2=dskip[k], ws=self.ws, da_nslab=nsd, da_slab_stride=std, sat=self.sat_g)
+                               da=self.g_dd[k + 1], da2=dskip[k], ws=self.ws_g, da_nslab=nsd, da_slab_stride=std, sat=self.sat_g)
             else:
                 ops.act_bwd(self.g_dd[1], d_act[0], self.g_dzd[0], 64, da2=dskip[0], sat=self.sat_g)
-            xin = self.x0[:B] if k == 0 else d_act[k - 1]
+            # (down1's input: the generator's own packed copy when the batched forward ran -- x0[:B] belongs to the critic steps,
+            #  which may be re-packing it while this branch runs beside them)
+            xin = (self.gfa.x8[self.c * B:] if self._gall_valid else self.x0[:B]) if k == 0 else d_act[k - 1]
             fl = conv_flops(B, S >> k, cin, cout)
 
             def down_wgrad(k=k, cout=cout, cp=cp, xin=xin, fl=fl):
@@ -977,12 +988,43 @@ class StepEngine:
         """Enqueue one full iteration (n_critic D steps + 1 G step); no host sync, nothing read back."""
         if self.batch_g:
             self.g_forward_all(pred, masks)
+        branch = self.overlap_g and self.batch_g and self.probe is None and self.allreduce is None
+        if branch:
+            # the generator step's gradient work (everything of :345-366 but the value-only critic forward) as a parallel
+            # branch: it starts behind the batched forward and is joined in front of the generator update
+            main = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.side_g.wait_event(ev)
+            with torch.cuda.stream(self.side_g):
+                self.g_main(pred, delta_true, pred_box, refine_fn, None if masks is None else masks[self.c])
+        ev_pre = None
         for k in range(self.c):
-            self.d_step(pred, gt, refine_fn, k, None if alphas is None else alphas[k],
-                        None if masks is None else masks[k])
+            if branch:
+                self.d_pre(pred, gt, refine_fn, k, None if alphas is None else alphas[k], None if masks is None else masks[k])
+                if k == self.c - 1:                               # the critic steps' last read of the generator's step counter
+                    ev_pre = torch.cuda.Event()                   # (alpha is drawn keyed by it: d_pre, pack_fake_interp)
+                    ev_pre.record(torch.cuda.current_stream())
+                self.d_main()
+                self.d_update()
+            else:
+                self.d_step(pred, gt, refine_fn, k, None if alphas is None else alphas[k],
+                            None if masks is None else masks[k])
             if on_critic is not None:
                 on_critic(k)
-        self.g_step(pred, delta_true, pred_box, refine_fn, None if masks is None else masks[self.c])
+        if branch:
+            # the generator's clip + Adam goes to the branch too: in STREAM order it follows the backward (it needs nothing
+            # from the critic) -- but not before the last d_pre, which reads the step counter this update advances; in host
+            # order it comes after the critic steps, whose d_pre still read the host flags of the batched forward it resets
+            with torch.cuda.stream(self.side_g):
+                self.side_g.wait_event(ev_pre)
+                self.g_update()
+            ev = torch.cuda.Event()
+            ev.record(self.side_g)
+            torch.cuda.current_stream().wait_event(ev)
+            self.g_critic(pred)                                   # :361-362, with the critic's final weights of the iteration
+        else:
+            self.g_step(pred, delta_true, pred_box, refine_fn, None if masks is None else masks[self.c])
 
     def iteration(self, pred, gt, delta_true, pred_box, refine_fn, alphas=None, masks=None) -> dict:
         """run_iteration + the scalars the reference logs (.item() syncs at :335-337,372-374)."""
@@ -1061,6 +1103,14 @@ class GraphedIteration:
             pool = g.pool()
             return g
 
+        if self.fused_update and eng.overlap_g and eng.batch_g and os.environ.get("GCSSL_ONE_GRAPH", "1") != "0":
+            # single GPU, ONE graph per iteration with the generator step's gradient work as a parallel branch beside the critic
+            # steps (StepEngine.run_iteration: one fork behind the batched generator forward, one join in front of the updates)
+            def whole():
+                eng._d_dirty = eng._g_dirty = True                # (capture-time host state must not skip the re-packs)
+                eng.run_iteration(pred, gt, delta_true, pred_box, refine_fn)
+            self.graphs = [capture(whole)]
+            return
         if self.fused_update:
             # single GPU: the whole iteration (critic steps, generator step, all three updates) is ONE graph
             # (GCSSL_ONE_GRAPH=0: one graph per step, for A/B runs)

@@ -183,7 +183,7 @@ class SimpleGenerator:
                 ops.maxpool2_bwd(self.a[j], self.dp[j // 2], self.da[j], cout)
             # (no dbias: the conv bias sits in front of InstanceNorm, its true gradient is exactly zero -- sum_p dz = 0 --
             #  and the engine leaves it at the zero the gradient buffer was cleared to; autograd's value is rounding noise)
-            ops.in_act_bwd(self.z[j], self.mean[j], self.rstd[j], self.dz[j], cout, RELU, da=self.da[j], ws=eng.ws)
+            ops.in_act_bwd(self.z[j], self.mean[j], self.rstd[j], self.dz[j], cout, RELU, da=self.da[j], ws=eng.ws_g)
             src = self.x8 if j == 0 else (self.p[j // 2 - 1] if not (j & 1) else self.a[j - 1])
             fl = conv3_flops(B, r, cin, cout)
             eng._conv(f"GS.c{j + 1}.wgrad", fl, ops.conv3_wgrad, src, self.dz[j], self.slab[j], self.cinp[j], cout)
