@@ -222,14 +222,17 @@ class StepEngine:
         # layer's wgrad + split-K reduce beside the dependent dgrad -> norm-backward chain.  None of these kernels
         # fills 256 CUs on its own.
         self.overlap = int(overlap)
-        self.side = [torch.cuda.Stream(device=dev) for _ in range(2)] if overlap else []
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(3)] if overlap else []
+        self._in_g_branch = False
         # ONE coarse branch (round 3): the generator step's own work -- EIoU, backward through the head, the up and the down
         # path, its split-K reduction: ~45 launches, 0.45 ms, none of which fills the chip -- does not depend on the critic
         # (the WGAN term gives G no gradient) once the iteration's batched generator forward has run, and nothing
         # in the critic steps reads what it writes.  It runs on a second stream beside the critic steps (one fork, one join
         # per iteration; captured as a parallel graph branch).  Single-GPU schedule only: with data parallelism the same work
         # already sits under the critic's all-reduces.  GCSSL_OVERLAP_G=0 restores the serial order.
-        self.overlap_g = int(os.environ.get("GCSSL_OVERLAP_G", "1")) and allreduce is None
+        # (not together with the older fine-grained `overlap` levels: nested forks out of a captured branch crashed the ROCm 7.2
+        #  graph capture -- core dump, r3o -- and the fine-grained branches measured 0..-3 % on their own in rounds 1-2)
+        self.overlap_g = int(os.environ.get("GCSSL_OVERLAP_G", "1")) and allreduce is None and not overlap
         self.side_g = torch.cuda.Stream(device=dev) if self.overlap_g else None
         self.probe = None          # {label: {"events": [(start, stop)...], "flops": f}} when profiling is enabled
 
@@ -240,18 +243,22 @@ class StepEngine:
         if self.overlap < level or self.probe is not None:   # probing wants serial, attributable timings
             fn()
             return
+        # (inside the generator branch of run_iteration the fine-grained branches fork from / join into THAT branch and use
+        #  their own side stream: a stream shared with the critic's branches would order the two coarse branches against
+        #  each other)
+        st = self.side[2] if self._in_g_branch else self.side[which]
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)
-        self.side[which].wait_event(ev)
-        with torch.cuda.stream(self.side[which]):
+        st.wait_event(ev)
+        with torch.cuda.stream(st):
             fn()
 
     def _join_side(self):
-        """Make the current stream wait for everything enqueued on the side stream."""
+        """Make the current stream wait for everything enqueued on the side stream(s) of the current coarse branch."""
         if not self.overlap or self.probe is not None:
             return
-        for st in self.side:
+        for st in (self.side[2:3] if self._in_g_branch else self.side[:2]):
             ev = torch.cuda.Event()
             ev.record(st)
             torch.cuda.current_stream().wait_event(ev)
@@ -997,7 +1004,11 @@ class StepEngine:
             ev.record(main)
             self.side_g.wait_event(ev)
             with torch.cuda.stream(self.side_g):
-                self.g_main(pred, delta_true, pred_box, refine_fn, None if masks is None else masks[self.c])
+                self._in_g_branch = True
+                try:
+                    self.g_main(pred, delta_true, pred_box, refine_fn, None if masks is None else masks[self.c])
+                finally:
+                    self._in_g_branch = False
         ev_pre = None
         for k in range(self.c):
             if branch:
