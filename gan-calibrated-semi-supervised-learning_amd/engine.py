@@ -222,7 +222,7 @@ class StepEngine:
         # layer's wgrad + split-K reduce beside the dependent dgrad -> norm-backward chain.  None of these kernels
         # fills 256 CUs on its own.
         self.overlap = int(overlap)
-        self.side = [torch.cuda.Stream(device=dev) for _ in range(3)] if overlap else []
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(2)] if overlap else []
         self._in_g_branch = False
         # ONE coarse branch (round 3): the generator step's own work -- EIoU, backward through the head, the up and the down
         # path, its split-K reduction: ~45 launches, 0.45 ms, none of which fills the chip -- does not depend on the critic
@@ -230,23 +230,25 @@ class StepEngine:
         # in the critic steps reads what it writes.  It runs on a second stream beside the critic steps (one fork, one join
         # per iteration; captured as a parallel graph branch).  Single-GPU schedule only: with data parallelism the same work
         # already sits under the critic's all-reduces.  GCSSL_OVERLAP_G=0 restores the serial order.
-        # (not together with the older fine-grained `overlap` levels: nested forks out of a captured branch crashed the ROCm 7.2
-        #  graph capture -- core dump, r3o -- and the fine-grained branches measured 0..-3 % on their own in rounds 1-2)
-        self.overlap_g = int(os.environ.get("GCSSL_OVERLAP_G", "1")) and allreduce is None and not overlap
+        # (2: also the first critic step's spectral-norm chain + re-pack beside the batched generator forward -- measured
+        #  neutral, 120.5k vs 120.4k.  The older fine-grained `overlap` levels stay out of the generator's branch: a fork out of
+        #  a captured branch crashed the ROCm 7.2 graph capture; beside it, on the critic's side only, they cost 4.5 %.)
+        self.overlap_g = int(os.environ.get("GCSSL_OVERLAP_G", "1")) if allreduce is None else 0
         self.side_g = torch.cuda.Stream(device=dev) if self.overlap_g else None
+        self.side_sn = torch.cuda.Stream(device=dev) if self.overlap_g >= 2 else None
         self.probe = None          # {label: {"events": [(start, stop)...], "flops": f}} when profiling is enabled
 
     # ------------------------------------------------------------------------------------------ side-stream branches
     def _on_side(self, fn, which: int = 0, level: int = 2):
         """Run fn() on side stream `which`, ordered after everything enqueued so far on the current stream.
         level 1 = the coarse branches (spectral norm + re-pack, the value-only critic forward), 2 = per-layer wgrads."""
-        if self.overlap < level or self.probe is not None:   # probing wants serial, attributable timings
-            fn()
+        if self.overlap < level or self.probe is not None or self._in_g_branch:   # probing wants serial, attributable timings;
+            fn()                                                                    # no forks out of the generator's branch
             return
         # (inside the generator branch of run_iteration the fine-grained branches fork from / join into THAT branch and use
         #  their own side stream: a stream shared with the critic's branches would order the two coarse branches against
         #  each other)
-        st = self.side[2] if self._in_g_branch else self.side[which]
+        st = self.side[which]
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)
@@ -256,9 +258,9 @@ class StepEngine:
 
     def _join_side(self):
         """Make the current stream wait for everything enqueued on the side stream(s) of the current coarse branch."""
-        if not self.overlap or self.probe is not None:
+        if not self.overlap or self.probe is not None or self._in_g_branch:
             return
-        for st in (self.side[2:3] if self._in_g_branch else self.side[:2]):
+        for st in self.side:
             ev = torch.cuda.Event()
             ev.record(st)
             torch.cuda.current_stream().wait_event(ev)
@@ -993,9 +995,18 @@ class StepEngine:
     # ------------------------------------------------------------------------------------------ iteration
     def run_iteration(self, pred, gt, delta_true, pred_box, refine_fn, alphas=None, masks=None, on_critic=None):
         """Enqueue one full iteration (n_critic D steps + 1 G step); no host sync, nothing read back."""
+        branch = self.overlap_g and self.batch_g and self.probe is None and self.allreduce is None
+        sn_early = branch and self.overlap_g >= 2
+        if sn_early:
+            # (GCSSL_OVERLAP_G=2) the first critic step's spectral-norm chain + weight re-pack (8 tiny launches that depend on
+            # nothing of this iteration) beside the batched generator forward; joined in front of the first critic forward
+            ev0 = torch.cuda.Event()
+            ev0.record(torch.cuda.current_stream())
+            self.side_sn.wait_event(ev0)
+            with torch.cuda.stream(self.side_sn):
+                self._sn_and_prep()
         if self.batch_g:
             self.g_forward_all(pred, masks)
-        branch = self.overlap_g and self.batch_g and self.probe is None and self.allreduce is None
         if branch:
             # the generator step's gradient work (everything of :345-366 but the value-only critic forward) as a parallel
             # branch: it starts behind the batched forward and is joined in front of the generator update
@@ -1016,7 +1027,11 @@ class StepEngine:
                 if k == self.c - 1:                               # the critic steps' last read of the generator's step counter
                     ev_pre = torch.cuda.Event()                   # (alpha is drawn keyed by it: d_pre, pack_fake_interp)
                     ev_pre.record(torch.cuda.current_stream())
-                self.d_main()
+                if sn_early and k == 0:
+                    evs = torch.cuda.Event()
+                    evs.record(self.side_sn)
+                    torch.cuda.current_stream().wait_event(evs)
+                self.d_main(sn_done=sn_early and k == 0)
                 self.d_update()
             else:
                 self.d_step(pred, gt, refine_fn, k, None if alphas is None else alphas[k],
