@@ -890,13 +890,14 @@ class StepEngine:
         self.g_main(pred, delta_true, pred_box, refine_fn, masks)
         self.g_critic(pred)
 
-    def g_critic(self, pred) -> None:
+    def g_critic(self, pred, xbuf=None) -> None:
         """D forward on (pred, refined_G): value only (zero gradient to G) but it advances u,v (:361)."""
         B = self.B
+        xbuf = self.x0[B:2 * B] if xbuf is None else xbuf          # x0[:B] stays G's input (down1's wgrad operand)
         self.sn.iterate(0, True, zero=self.wgan_mean)              # (the closing launch clears the mean the head conv adds to)
         self._prep_d()
-        ops.pack_pair(pred, self._refined_g, self.x0[B:2 * B])     # x0[:B] stays G's input (down1's wgrad operand)
-        self._d_forward(B, lambda l: self.sn.isig[l, 0:1], B, x=self.x0[B:2 * B], means=self.wgan_mean, groups=1)   # loss_WGAN_G = -mean (:362)
+        ops.pack_pair(pred, self._refined_g, xbuf)
+        self._d_forward(B, lambda l: self.sn.isig[l, 0:1], B, x=xbuf, means=self.wgan_mean, groups=1)   # loss_WGAN_G = -mean (:362)
 
     def g_main(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
         """The generator step's forward, loss and backward (:345-366, without the value-only critic forward).  Two halves so
