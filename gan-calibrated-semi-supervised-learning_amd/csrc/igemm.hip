@@ -2205,6 +2205,10 @@ int fin_form(const ConvParams& p) {
     if (!on || !use_dma() || dma_waves() != 8 || HW > 64 || HW < 4 || p.Cin < 64 || p.Cout < 64) return 0;
     const long tm128 = (p.M + 127) / 128;
     const long t128 = tm128 * ((p.Cout + 127) / 128);
+    // ring form with 64-row tiles (4 consumer + 8 loader waves): for shapes whose 128 x 128 tiles would leave most of the chip
+    // idle (D.c4 / G.down4 at n = 768: 96 tiles) but whose 64 x 128 tiles fill one round (192)
+    const long t64x128 = (long)((p.M + 63) / 64) * ((p.Cout + 127) / 128);
+    if ((on & 8) == 0 && (on & 2) == 0 && p.Cout >= 128 && p.M >= 64 && HW <= 16 && t128 < 160 && t64x128 >= 160 && t64x128 <= cu_count()) return 5;
     if ((on & 2) == 0 && p.Cout >= 128 && p.M >= 128 && t128 <= cu_count() && t128 >= ring_min) return 1;
     // 8x8 maps with clearly more 128 x 64 tiles than resident workgroups: the persistent form (statistics in registers)
     if ((on & 4) == 0 && HW == 64 && !p.in_mask && !p.in_apre && persist_mode() && tm128 * ((p.Cout + 63) / 64) > 2 * cu_count() + cu_count() / 2 &&
@@ -2228,6 +2232,9 @@ int dispatch_fwd_in(ConvParams p, hipStream_t st) {
         } else if (form == 3) {
             dim3 grid((p.M + 63) / 64, (p.Cout + 63) / 64, 1);
             GCSSL_LAUNCH((conv_dma_kernel<O, 64, 64, 0, 2, 2, false, 0, 3, true, true>), grid, dim3(256), 0, st, p);
+        } else if (form == 5) {
+            dim3 grid((p.M + 63) / 64, (p.Cout + 127) / 128, 1);
+            GCSSL_LAUNCH((conv_dma_kernel<O, 64, 128, 0, 2, 2, false, 8, 4, false, true>), grid, dim3(768), 0, st, p);
         } else if (form == 4) {
             const int tm = (p.M + 127) / 128, tn = (p.Cout + 63) / 64;
             GCSSL_LAUNCH((conv_dma_persist_kernel<O, 128, 64, 0, 4, 2, false, true>), dim3(2 * cu_count()), dim3(512), 0, st, p, tm, tn, tm * tn);
