@@ -1164,6 +1164,29 @@ class GraphedIteration:
             raise ValueError("GraphedIteration's data-parallel form needs a dist.GradAverager-like hook (start/finish/world)")
         gs = eng.dp_grad_scale()
         eng._g_dirty, eng._d_dirty = True, True
+        # Round 3: with the batched generator forward the generator step's gradient work is its own graph, replayed on a SECOND
+        # stream beside everything the critic does (it depends on nothing of it: StepEngine.run_iteration does the same inside
+        # the single-GPU graph).  The critic's exchanges then no longer need that work to hide behind: while the compute stream
+        # waits for an all-reduce, the generator's kernels run --
+        #   main: [Gfwd_all] [pre0 main0] AR(D) [pre1] wait [updD main1] AR(D) . AR(G) wait(D) [updD g_critic] wait(G) [updG]
+        #   side:            [g_main ...................]                   join^
+        # GCSSL_DP_BRANCH=0: the round-2 schedule (generator halves serial under the critic's all-reduces).
+        self.dp_branch = eng.batch_g and os.environ.get("GCSSL_DP_BRANCH", "1") != "0"
+        if self.dp_branch:
+            self.side = torch.cuda.Stream(device=eng.dev)
+            self.gfwd = capture(lambda: eng.g_forward_all(pred, None))
+            eng._g_dirty = False
+            self.first = capture(lambda: (eng.d_pre(pred, gt, refine_fn, 0, None, None), eng.d_main()))
+            self.pre, self.upd_main = [None], [None]
+            for k in range(1, eng.c):
+                self.pre.append(capture(lambda k=k: eng.d_pre(pred, gt, refine_fn, k, None, None)))
+                self.upd_main.append(capture(lambda: (eng.d_update(gs), eng.d_main())))
+            pool_main, pool = pool, None                           # the branch replays concurrently: its own memory pool
+            self.g_branch = capture(lambda: eng.g_main(pred, delta_true, pred_box, refine_fn, None))
+            pool = pool_main
+            self.upd_crit = capture(lambda: (eng.d_update(gs), eng.g_critic(pred)))
+            self.upd_g = capture(lambda: eng.g_update(gs))
+            return
         self.first = capture(lambda: (eng.g_forward_all(pred, None) if eng.batch_g else None,
                                       eng.d_pre(pred, gt, refine_fn, 0, None, None), eng.d_main()))
         # the generator step's own work (forward already done, EIoU, backward) does not depend on the critic: with two or
@@ -1185,6 +1208,28 @@ class GraphedIteration:
         if self.fused_update:
             for g in self.graphs:
                 g.replay()
+            return
+        if self.dp_branch:
+            main = torch.cuda.current_stream()
+            self.gfwd.replay()
+            ev = torch.cuda.Event(); ev.record(main)
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                self.g_branch.replay()
+                evg = torch.cuda.Event(); evg.record(self.side)
+            self.first.replay()
+            h = eng.allreduce_start(eng.D.g)
+            for k in range(1, eng.c):
+                self.pre[k].replay()
+                eng.allreduce_wait(h, eng.D.g)
+                self.upd_main[k].replay()
+                h = eng.allreduce_start(eng.D.g)
+            main.wait_event(evg)                                  # the generator's gradient is complete
+            hg = eng.allreduce_start(eng.G.g)                     # queued behind the critic's exchange on the backend's stream
+            eng.allreduce_wait(h, eng.D.g)
+            self.upd_crit.replay()
+            eng.allreduce_wait(hg, eng.G.g)
+            self.upd_g.replay()
             return
         self.first.replay()
         h = eng.allreduce_start(eng.D.g)
