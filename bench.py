@@ -370,7 +370,10 @@ def main():
                            baseline_config="BASELINE.json configs[1] (32x32x3, batch 256, bf16, 1 GPU)"
                            if (B, S, c, args.dtype, args.generator) == (256, 32, 2, "bf16", "unet") else None,
                            global_batch=B * world, img_size=S, n_critic=c, parallelism=f"dp{world}",
-                           launch="hipGraph replay" if run.graphed is not None else "eager",
+                           launch=("hipGraph replay" + (" (software-pipelined across iterations: the replayed graph ends with the next "
+                                                        "iteration's batched generator forward; DESIGN.md 2)"
+                                                        if getattr(run.graphed, "pipelined", False) else ""))
+                           if run.graphed is not None else "eager",
                            algorithmic_tflops=round(flop_iter / (ms * 1e-3) / 1e12, 2) if flop_iter else None),
                roofline=roofline)
     del run

@@ -994,8 +994,13 @@ class StepEngine:
         self._reduce_batches()[1].run()                           # all eight weight gradients, one launch
 
     # ------------------------------------------------------------------------------------------ iteration
-    def run_iteration(self, pred, gt, delta_true, pred_box, refine_fn, alphas=None, masks=None, on_critic=None):
-        """Enqueue one full iteration (n_critic D steps + 1 G step); no host sync, nothing read back."""
+    def run_iteration(self, pred, gt, delta_true, pred_box, refine_fn, alphas=None, masks=None, on_critic=None,
+                      next_forward: bool = False):
+        """Enqueue one full iteration (n_critic D steps + 1 G step); no host sync, nothing read back.
+
+        next_forward (GraphedIteration's pipelined single-GPU form, device-drawn masks only): the iteration's batched generator
+        forward has ALREADY run (by the previous call, or a prologue); this call instead ends its generator branch with the
+        NEXT iteration's batched forward -- right behind the generator update, beside the rest of the critic's work."""
         branch = self.overlap_g and self.batch_g and self.probe is None and self.allreduce is None
         sn_early = branch and self.overlap_g >= 2
         if sn_early:
@@ -1006,7 +1011,9 @@ class StepEngine:
             self.side_sn.wait_event(ev0)
             with torch.cuda.stream(self.side_sn):
                 self._sn_and_prep()
-        if self.batch_g:
+        if next_forward:
+            assert branch and self._gall_valid and masks is None, "pipelined form: single GPU, batched forward already done"
+        elif self.batch_g:
             self.g_forward_all(pred, masks)
         if branch:
             # the generator step's gradient work (everything of :345-366 but the value-only critic forward) as a parallel
@@ -1044,12 +1051,26 @@ class StepEngine:
             # from the critic) -- but not before the last d_pre, which reads the step counter this update advances; in host
             # order it comes after the critic steps, whose d_pre still read the host flags of the batched forward it resets
             with torch.cuda.stream(self.side_g):
+                ev_gm = torch.cuda.Event()
+                ev_gm.record(self.side_g)                         # the backward (and with it the re-crop for g_critic) is enqueued
                 self.side_g.wait_event(ev_pre)
                 self.g_update()
-            ev = torch.cuda.Event()
-            ev.record(self.side_g)
-            torch.cuda.current_stream().wait_event(ev)
+                if next_forward:
+                    # software pipelining across iterations: G's weights are final for this iteration, the critic steps have
+                    # taken their deltas (ev_pre) and the backward has read the activations, so the NEXT iteration's batched
+                    # forward can overwrite them now -- beside the last critic step's gradient work and the value-only forward
+                    self.g_forward_all(pred, None)
+            if next_forward:
+                torch.cuda.current_stream().wait_event(ev_gm)
+            else:
+                ev = torch.cuda.Event()
+                ev.record(self.side_g)
+                torch.cuda.current_stream().wait_event(ev)
             self.g_critic(pred)                                   # :361-362, with the critic's final weights of the iteration
+            if next_forward:                                      # (every stream of a capture has to be joined before it ends)
+                ev = torch.cuda.Event()
+                ev.record(self.side_g)
+                torch.cuda.current_stream().wait_event(ev)
         else:
             self.g_step(pred, delta_true, pred_box, refine_fn, None if masks is None else masks[self.c])
 
@@ -1133,9 +1154,21 @@ class GraphedIteration:
         if self.fused_update and eng.overlap_g and eng.batch_g and os.environ.get("GCSSL_ONE_GRAPH", "1") != "0":
             # single GPU, ONE graph per iteration with the generator step's gradient work as a parallel branch beside the critic
             # steps (StepEngine.run_iteration: one fork behind the batched generator forward, one join in front of the updates)
+            # GCSSL_PIPELINE (default on): software pipelining across iterations -- the replayed graph is [critic steps i,
+            # value-only forward i] beside [generator backward i, generator update i, batched generator forward i+1]; a prologue
+            # graph runs the very first forward.  Same launches per iteration, same dependency order (the forward of i+1 needs
+            # exactly G's weights after update i and iteration i+1's input, which is this static batch).
+            self.pipelined = os.environ.get("GCSSL_PIPELINE", "1") != "0"
+            self._primed = False
+
             def whole():
-                eng._d_dirty = eng._g_dirty = True                # (capture-time host state must not skip the re-packs)
-                eng.run_iteration(pred, gt, delta_true, pred_box, refine_fn)
+                eng._d_dirty = True                               # (capture-time host state must not skip the re-packs)
+                if not self.pipelined:
+                    eng._g_dirty = True
+                eng.run_iteration(pred, gt, delta_true, pred_box, refine_fn, next_forward=self.pipelined)
+            if self.pipelined:
+                eng._g_dirty = True
+                self.prologue = capture(lambda: eng.g_forward_all(pred, None))
             self.graphs = [capture(whole)]
             return
         if self.fused_update:
@@ -1206,6 +1239,9 @@ class GraphedIteration:
     def replay(self):
         eng = self.eng
         if self.fused_update:
+            if getattr(self, "pipelined", False) and not self._primed:
+                self.prologue.replay()                            # the first iteration's batched generator forward
+                self._primed = True
             for g in self.graphs:
                 g.replay()
             return
