@@ -236,6 +236,14 @@ struct ConvParams {
     // (pixel stride ldy); the whole H*W map of a sample lies inside one M tile, so the statistics need no second pass.
     float* in_mean; float* in_rstd;       // [N][Cout] fp32 outputs
     const uint8_t* in_mask;               // dropout keep mask [N][Ho*Wo][Cout] or null (kept values x 2)
+    // ---- ACTB forms (gcssl_conv4x4s2_dgrad_act_bwd): the data gradient of a conv whose INPUT is the output of a norm-less
+    // LeakyReLU layer (D.c1 / G.down1), with that layer's activation backward in the epilogue: y = dzs = lrelu'(a) * dx * gscale
+    // in the compute dtype; the fp32 dx never goes to memory.
+    const void* ab_a; int ab_lda; unsigned ab_bytes;   // the layer's stored activation lrelu(z) at this dgrad's OUTPUT pixels
+    const float* ab_bias;                 // its conv bias (for the spectral-norm dot), nullable
+    float* ab_dbias; float* ab_cdot;      // [Cin] += sum dz / [group] += sum dzs (z - bias), striped over ab_nrep replicas; nullable
+    int ab_nrep, ab_rep_stride;
+    unsigned* ab_sat;                     // += fp16 stores that clipped (nullable)
     int kcap;                             // timing experiment (GCSSL_KCAP, 3x3 persistent form only; results are garbage): walk only the
                                           // first kcap K steps of every tile -- the K volume a Winograd F(2x2,3x3) GEMM stage would have
     void* in_apre; int ld_apre, apre_n0;  // optional second output: the activation WITHOUT dropout for samples n >= apre_n0
@@ -508,7 +516,7 @@ __device__ __forceinline__ void tile_decode(int L, int tiles_m, int tiles_n, int
 // statistics are the exact two-pass ones computed from LDS, and what leaves is the 16-bit activation + fp32 mean / rstd:
 // the fp32 pre-norm tensor z (4 B written by the conv, 4 B read + 2 B written by a separate norm launch) never exists.
 template <typename T, int BM, int BN, int MODE, int WM, int WN, bool SMALLK, int LW = 0, int NSLOT = 3, bool PIPE = true,
-          bool FIN = false>
+          bool FIN = false, bool ACTB = false>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParams p) {
     // The host pass only needs the launch stub; it silently marks this body invalid (device-only LDS-DMA builtin and
     // inline asm with template-dependent operands) and then emits NO stub, so the body is device-pass only.
@@ -794,6 +802,53 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
             if (p.gscale && m < p.M)          // sample -> group without an integer division (exact below 2^21 samples)
                 sc[i][r] = p.gscale[(int)(((float)(m >> p.lgHoWo) + 0.5f) * p.inv_group_n)];
         }
+    if constexpr (ACTB) {
+        // ---- activation-backward epilogue of the dgrad form (MODE 1, no K split, elementwise part only: the striped bias /
+        // spectral-norm sums are the persistent form's).  The fp32 tile goes through the idle ring; a thread then owns 8
+        // consecutive channels of one output pixel: 16 bytes of the stored activation in, 16 bytes of dzs out.
+        constexpr int RS = BN * 4 + 16;
+        constexpr int CPR = BN / 8;
+        static_assert(BM * RS <= NSLOT * STAGE && MODE == 1, "tile must fit the ring");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + 32 * i + crow(r, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    *reinterpret_cast<float*>(lds + row * RS + (wn0 + 32 * j + (lane & 31)) * 4) = acc[i][j][r];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* ab = static_cast<const unsigned char*>(p.ab_a);
+        unsigned char* yb = static_cast<unsigned char*>(p.y);
+        int nsat = 0;
+        for (int cix = threadIdx.x; cix < BM * CPR; cix += NCW * 64) {
+            const int row = cix / CPR, ch = cix % CPR, m = m0 + row, col0 = n0 + ch * 8;
+            if (m >= p.M || col0 >= p.Cin) continue;
+            const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
+            const size_t pix = (size_t)(n * p.Hi + 2 * (rem >> p.lgWo) + py) * p.Wi + 2 * (rem & (Wo - 1)) + px;
+            const float gs = p.gscale ? p.gscale[(int)(((float)n + 0.5f) * p.inv_group_n)] : 1.f;
+            const uint4 aw = *reinterpret_cast<const uint4*>(ab + (pix * p.ab_lda + col0) * 2);
+            const float4 v0 = *reinterpret_cast<const float4*>(lds + row * RS + ch * 32);
+            const float4 v1 = *reinterpret_cast<const float4*>(lds + row * RS + ch * 32 + 16);
+            const float da[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const unsigned awv[4] = {aw.x, aw.y, aw.z, aw.w};
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float av = Bits16<T>::dec(awv[e >> 1] >> (16 * (e & 1)));
+                o[e] = (av > 0.f ? da[e] : 0.2f * da[e]) * gs;
+            }
+            nsat += sat_hits<T>(o);
+            uint4 w; w.x = pack2<T>(o[0], o[1]); w.y = pack2<T>(o[2], o[3]); w.z = pack2<T>(o[4], o[5]); w.w = pack2<T>(o[6], o[7]);
+            *reinterpret_cast<uint4*>(yb + (pix * p.ldy + col0) * 2) = w;
+        }
+        sat_commit(p.ab_sat, nsat);
+        return;
+    }
     if constexpr (FIN) {
         // ---- InstanceNorm + activation epilogue (MODE 0, no K split; the host guarantees H*W <= 64 divides BM, 16-byte
         // aligned activation rows and Cout % 8 == 0).  LDS: fp32 tile [BM][BN] (+16 B row pad), then mean | rstd per
@@ -1066,7 +1121,11 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
 // combination with the partner wave that holds the sample's other 32 rows (2 floats per column through 2 KB of LDS, one
 // barrier), then the 16 stores of the 16-bit activation + mean / rstd (two more store instructions for every wave, out-of-range
 // for the non-writers: the vmcnt bookkeeping needs a fixed count).
-template <typename T, int BM, int BN, int MODE, int WM, int WN, bool SMALLK = false, bool FIN = false>
+// ACTB (dgrad form, one N tile: Cin == BN): the activation backward of the norm-less layer that produced this conv's input in the
+// epilogue -- per lane 16 two-byte loads of the stored activation at its output pixels, dzs = lrelu'(a) dx gscale stored in the
+// compute dtype, and the bias-gradient / spectral-norm sums kept in registers across the workgroup's tiles (its columns never
+// change: one N tile) and added to one replica of the striped sums when the workgroup retires.
+template <typename T, int BM, int BN, int MODE, int WM, int WN, bool SMALLK = false, bool FIN = false, bool ACTB = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvParams p, int tiles_m, int tiles_n, int total_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef typename Frag16<T>::type FragT;
@@ -1186,6 +1245,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
     issue(cur, 1, 1);                                                    // nk >= 2 for every layer that gets here
     int slot = 0;
     bool first = true;
+    float ab_sb[TN], ab_sd[4] = {0.f, 0.f, 0.f, 0.f};                    // ACTB: running column sums of dz, per-group sums of dzs (z - b)
+    int ab_nsat = 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) ab_sb[j] = 0.f;
     while (true) {
         const int next_tile = tile + (int)gridDim.x;
         const bool has_next = next_tile < total_tiles;
@@ -1248,7 +1311,52 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
                 if (p.gscale && m < p.M) sc[i][r] = p.gscale[(int)(((float)(m >> p.lgHoWo) + 0.5f) * p.inv_group_n)];
             }
         if (p.gscale || (MODE != 1 && p.bias)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // see note below
-        if constexpr (FIN) {
+        if constexpr (ACTB) {
+            static_assert(MODE == 1 && !FIN, "ACTB is an epilogue of the dgrad form");
+            const __amdgpu_buffer_rsrc_t ar = make_rsrc(p.ab_a, p.ab_bytes);
+            float bb[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = cur.n0 + wn0 + 32 * j + (lane & 31);
+                bb[j] = (p.ab_bias && col < ncols) ? p.ab_bias[col] : 0.f;
+            }
+            const int grp = (int)(((float)(cur.m0 >> p.lgHoWo) + 0.5f) * p.inv_group_n);   // (a tile never straddles sample groups)
+            float sdt = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                unsigned short araw[16][TN];
+                unsigned offs[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {                               // all activation loads of the block first
+                    const int m = cur.m0 + wm0 + 32 * i + crow(r, lane);
+                    const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
+                    const int iy = 2 * (rem >> p.lgWo) + cur.py, ix = 2 * (rem & (Wo - 1)) + cur.px;
+                    offs[r] = m < p.M ? (unsigned)((n * p.Hi + iy) * p.Wi + ix) : OOB;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = cur.n0 + wn0 + 32 * j + (lane & 31);
+                        araw[r][j] = __builtin_amdgcn_raw_buffer_load_b16(ar, (offs[r] != OOB && col < ncols) ? (offs[r] * (unsigned)p.ab_lda + (unsigned)col) * 2u : OOB, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = cur.n0 + wn0 + 32 * j + (lane & 31);
+                        const bool ok = offs[r] != OOB && col < ncols;
+                        const float av = Bits16<T>::dec(araw[r][j]);
+                        const float dx = acc[i][j][r];
+                        const float dz = ok ? (av > 0.f ? dx : 0.2f * dx) : 0.f;
+                        const float zv = av > 0.f ? av : 5.0f * av;              // invert LeakyReLU(0.2)
+                        const float o = dz * sc[i][r];
+                        ab_sb[j] += dz; sdt += o * (zv - bb[j]);
+                        ab_nsat += sat_hit<T>(o);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)Bits16<T>::enc(o), yr,
+                                                              ok ? (offs[r] * (unsigned)p.ldy + (unsigned)col) * 2u : OOB, 0, 0);
+                    }
+            }
+            if (grp == 0) ab_sd[0] += sdt; else if (grp == 1) ab_sd[1] += sdt; else if (grp == 2) ab_sd[2] += sdt; else ab_sd[3] += sdt;
+        } else if constexpr (FIN) {
             float v[16], sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { v[r] = acc[0][0][r] * sc[0][r] + bcol[0]; sum += v[r]; }
@@ -1308,6 +1416,42 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
         }
         if (!has_next) break;
         cur = nxt; tile = next_tile; first = false;
+    }
+    if constexpr (ACTB) {
+        // the workgroup's sums -> one replica of the striped bias-gradient / spectral-norm sums (norm.hip replica_offset)
+        sat_commit(p.ab_sat, ab_nsat);
+        if (p.ab_dbias || p.ab_cdot) {
+            float* red = reinterpret_cast<float*>(lds);                      // [wave][TN * 32 + 4]
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
+            constexpr int RW = TN * 32 + 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float t = ab_sb[j] + __shfl_xor(ab_sb[j], 32, 64);
+                if (lane < 32) red[wave * RW + j * 32 + lane] = t;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float t = wave_sum(ab_sd[g]);
+                if (lane == 0) red[wave * RW + TN * 32 + g] = t;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int rep = p.ab_nrep > 1 ? (int)(blockIdx.x % (unsigned)p.ab_nrep) * p.ab_rep_stride : 0;
+            if (p.ab_dbias && tid < BN) {                                    // column tid of the tile: wave column tid / (BN / WN)
+                const int wc = tid / (BN / WN), cj = tid % (BN / WN);
+                float t = 0.f;
+#pragma unroll
+                for (int wr = 0; wr < WM; ++wr) t += red[(wr * WN + wc) * RW + cj];
+                if (tid < ncols) atomicAdd(p.ab_dbias + rep + tid, t);
+            }
+            if (p.ab_cdot && tid < 4) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM * WN; ++w) t += red[w * RW + TN * 32 + tid];
+                if (t != 0.f) atomicAdd(p.ab_cdot + rep + tid, t);
+            }
+        }
     }
 #endif
 }
@@ -2410,6 +2554,36 @@ int dispatch_dgrad(ConvParams p, hipStream_t st) {
     return launch_dgrad<T, 64, 64>(p, st);      // Cin < 64 (first layer, Cin padded to 8): masked columns
 }
 
+// ---- dgrad + activation backward of the norm-less layer in front (ACTB forms).  0 = not served, 1 = persistent form (with the
+// striped bias / spectral-norm sums), 2 = plain tiled form (elementwise part only).
+int actb_form(const ConvParams& p, bool need_sums) {
+    static const int on = [] { const char* e = getenv("GCSSL_ACTB"); return e ? atoi(e) : 1; }();
+    if (!on || !use_dma() || dma_waves() != 8 || p.Cin != 64 || p.Cout < 64 || p.M < 128) return 0;
+    const long total = 4L * ((p.M + 127) / 128);
+    const long slots = 2L * cu_count();
+    if (persist_mode() && p.y_bytes && total > slots + slots / 4) return 1;
+    if (!need_sums && total >= tile_threshold()) return 2;
+    return 0;
+}
+template <typename T>
+int dispatch_dgrad_actb(ConvParams p, hipStream_t st) {
+    if constexpr (Is16<T>::v) {
+        typedef typename Op16<T>::type O;
+        const int form = actb_form(p, p.ab_dbias || p.ab_cdot);
+        p.ksplit = 1;
+        const int tm = (p.M + 127) / 128;
+        if (form == 1) {
+            GCSSL_LAUNCH((conv_dma_persist_kernel<O, 128, 64, 1, 4, 2, false, false, true>), dim3(2 * cu_count()), dim3(512), 0, st, p, tm, 1, 4 * tm);
+        } else if (form == 2) {
+            GCSSL_LAUNCH((conv_dma_kernel<O, 128, 64, 1, 4, 2, false, 0, 3, true, false, true>), dim3(tm, 1, 4), dim3(512), 0, st, p);
+        } else {
+            return GCSSL_EBADSHAPE;
+        }
+        return gcssl_launch_status();
+    }
+    return GCSSL_EBADDTYPE;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2525,6 +2699,46 @@ int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, c
     hipStream_t st = (hipStream_t)stream;
     if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     GCSSL_DISPATCH(dtype, return dispatch_dgrad<T>(p, st));
+    return GCSSL_EBADDTYPE;
+}
+
+// 1 if gcssl_conv4x4s2_dgrad_act_bwd serves these shapes (with_sums: dbias / cdot requested), else 0
+int gcssl_conv4x4s2_dgrad_act_bwd_ok(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int with_sums) {
+    int rc = check_geom(N, Hi, Wi, Cin, Cout);
+    if (rc) return rc;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (dtype == GCSSL_F32) return 0;
+    ConvParams p{}; p.y_bytes = 1;
+    fill_geom(p, N, Hi, Wi, Cin, Cout);
+    return actb_form(p, with_sums != 0) ? 1 : 0;
+}
+
+int gcssl_conv4x4s2_dgrad_act_bwd(int dtype, const void* dy, int lddy, const void* wt, const void* a, int lda, const float* gscale,
+                                  int group_n, const float* bias, void* dzs, int lddz, float* dbias, float* cdot, int nrep,
+                                  int rep_stride, unsigned* sat, int N, int Hi, int Wi, int Cin, int Cout, void* stream) {
+    if (!dy || !wt || !a || !dzs) return GCSSL_ENULL;
+    int rc = check_geom(N, Hi, Wi, Cin, Cout);
+    if (rc) return rc;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (dtype == GCSSL_F32) return GCSSL_EBADDTYPE;
+    if (lddy < Cout || lda < Cin || lddz < Cin || ((gscale || cdot) && group_n <= 0)) return GCSSL_EBADSHAPE;
+    if (nrep < 1 || (nrep > 1 && rep_stride < Cin)) return GCSSL_EBADSHAPE;
+    if ((gscale || cdot) && (group_n * (Hi / 2) * (Wi / 2)) % 128) return GCSSL_EBADSHAPE;      // a 128-row tile must not straddle groups
+    if (lddy % 8 || lda % 8 || lddz % 8 || !aligned16(dy) || !aligned16(wt) || !aligned16(a) || !aligned16(dzs)) return GCSSL_EALIGN;
+    ConvParams p{}; p.x = dy; p.w = wt; p.y = dzs; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
+    p.ldx = lddy; p.ldy = lddz;
+    p.ab_a = a; p.ab_lda = lda; p.ab_bias = bias; p.ab_dbias = dbias; p.ab_cdot = cdot; p.ab_nrep = nrep; p.ab_rep_stride = rep_stride;
+    p.ab_sat = sat;
+    p.sib_remap = sib_remap();
+    fill_geom(p, N, Hi, Wi, Cin, Cout);
+    if (!fill_bytes(p, (size_t)N * (Hi / 2) * (Wi / 2) * lddy, (size_t)Cin * 16 * Cout, 2)) return GCSSL_EBADSHAPE;
+    {
+        const size_t yb = (((size_t)N * Hi * Wi - 1) * lddz + Cin) * 2, ab = (((size_t)N * Hi * Wi - 1) * lda + Cin) * 2;
+        if (yb >= 0x7FFFFFFFull || ab >= 0x7FFFFFFFull) return GCSSL_EBADSHAPE;
+        p.y_bytes = (unsigned)yb; p.ab_bytes = (unsigned)ab;
+    }
+    if (!actb_form(p, dbias || cdot)) return GCSSL_EBADSHAPE;
+    GCSSL_DISPATCH(dtype, return dispatch_dgrad_actb<T>(p, (hipStream_t)stream));
     return GCSSL_EBADDTYPE;
 }
 

@@ -339,6 +339,13 @@ class StepEngine:
             self._fin_cache[key] = self.code != _lib.F32 and ops.conv_in_act_ok(self.code, n, hi, cin, cout)
         return self._fin_cache[key]
 
+    def _actb(self, n: int, hi: int, cin: int, cout: int, with_sums: bool) -> bool:
+        """does the one-launch dgrad + activation-backward form serve a data gradient of these shapes?"""
+        key = ("actb", n, hi, cin, cout, with_sums)
+        if key not in self._fin_cache:
+            self._fin_cache[key] = self.code != _lib.F32 and ops.conv_dgrad_act_bwd_ok(self.code, n, hi, cin, cout, with_sums)
+        return self._fin_cache[key]
+
     # ------------------------------------------------------------------------------------------ buffers
     def _alloc(self):
         B, S, T, dev = self.B, self.S, self.T, self.dev
@@ -804,14 +811,22 @@ class StepEngine:
         seeds = (-ls / (B * hw), ls / (B * hw), 0.0)
         ops.c5_dgrad(self.d_da4_3, self.d_w5p, consts=(seeds[0], seeds[1], seeds[2], 1.0), group_n=B)
         ns, st = 1, 0                                             # K-split slabs of the conv that produced gb_a[l]
+        gp_c1_done = False
         for l in (3, 2, 1):
             cin, cout = D_CH[l]
             ops.in_act_bwd(self._d_zsrc[l][I], self.d_mean[l][I], self.d_rstd[l][I], self.gb_zs[l], cout, LRELU,
                            da=self.gb_a[l], gscale=isig[l, 2:3], group_n=B, ws=self.ws, da_nslab=ns, da_slab_stride=st, sat=self.sat_d)
+            if l == 1 and self._actb(B, S >> 1, cin, cout, False):
+                # c2's data gradient with c1's LeakyReLU backward in its epilogue: gb_zs[0] directly, no fp32 gb_a[0]
+                self._conv("D.c2.gp_dgrad", conv_flops(B, S >> 1, cin, cout), ops.conv_dgrad_act_bwd, self.gb_zs[1], self.d_wt[1],
+                           self.d_a[0][I], self.gb_zs[0], cin, cout, gscale=isig[0, 2:3], group_n=B, sat=self.sat_d)
+                gp_c1_done = True
+                continue
             ns, st = self._split("dgrad", self.gb_a[l - 1], B, S >> l, cin, cout, grad=True) if l > 1 else (1, 0)
             self._conv(f"D.c{l + 1}.gp_dgrad", conv_flops(B, S >> l, cin, cout), ops.conv_dgrad, self.gb_zs[l],
                        self.d_wt[l], self.gb_a[l - 1], cin, cout, split_stride=st)
-        ops.act_bwd(self.gb_a[0], self.d_a[0][I], self.gb_zs[0], 64, gscale=isig[0, 2:3], group_n=B, sat=self.sat_d)
+        if not gp_c1_done:
+            ops.act_bwd(self.gb_a[0], self.d_a[0][I], self.gb_zs[0], 64, gscale=isig[0, 2:3], group_n=B, sat=self.sat_d)
         self._conv("D.c1.gp_dgrad", conv_flops(B, S, 6, 64), ops.conv_dgrad, self.gb_zs[0], self.d_wt[0], self.gb_x0, 8, 64)
         # :223-231, and the seed of the reverse pass (gb_x0 * coef, the create_graph=True part of d_loss.backward(), :330)
         # (lambda_gp only enters the adjoint seed coef/scaled, not gp_sum: the critic's loss scale rides on it)
@@ -836,6 +851,7 @@ class StepEngine:
         # the head's weight gradient of both parts in one launch over the 4B-sample buffer: seeds of the three forwards, and 1 for
         # the reverse GP chain's adjoint activations gt_a (the derivative of the first-order seed w5 * 1)
         ops.c5_wgrad(self.d_a4[3], gw5, 512, consts=(seeds[0], seeds[1], seeds[2], 1.0), group_n=B)
+        c1_done = False
         for l in (3, 2, 1, 0):
             cin, cout = D_CH[l]
             cp = _pad8(cin)
@@ -847,7 +863,7 @@ class StepEngine:
                 ops.in_act_bwd(self._d_zsrc[l][:N3], self.d_mean[l], self.d_rstd[l], self.d_dzs[l], cout, LRELU,
                                da=self.d_da[l], zt=self.zt[l], zt_n0=2 * B, gscale=isig[l], group_n=B, bias=bias,
                                dbias=rb, cdot=rc, ws=self.ws, nrep=self.NREP, rep_stride=self.REP_STRIDE, sat=self.sat_d)
-            else:
+            elif not c1_done:
                 ops.act_bwd(self.d_da[0], self.d_a[0], self.d_dzs[0], 64, gscale=isig[0], group_n=B, bias=bias,
                             dbias=rb, cdot=rc, nrep=self.NREP, rep_stride=self.REP_STRIDE, sat=self.sat_d)
             fl = conv_flops(N3, S >> l, cin, cout)
@@ -855,7 +871,16 @@ class StepEngine:
             def wgrad_branch(l=l, cout=cout, cp=cp, fl4=conv_flops(4 * B, S >> l, cin, cout)):
                 self._conv(f"D.c{l + 1}.wgrad", fl4, ops.conv_wgrad, self.d_x4[l], self.d_dzs4[l], self.d_slab[l], cp, cout)
             self._on_side(wgrad_branch)                           # beside the dgrad -> norm-backward chain
-            if l > 0:
+            if l == 1 and self._actb(N3, S >> 1, cin, cout, True):
+                # c2's data gradient with c1's LeakyReLU backward (+ its bias-gradient and spectral-norm sums) in the epilogue:
+                # d_dzs[0] directly; the 3B x 16x16x64 fp32 d_da[0] is neither written nor read back
+                i0 = D_IDX[0]
+                self._conv("D.c2.dgrad", fl, ops.conv_dgrad_act_bwd, self.d_dzs[1], self.d_wt[1], self.d_a[0], self.d_dzs[0], cin, cout,
+                           gscale=isig[0], group_n=B, bias=self.D.views[f"model.{i0}.bias"],
+                           dbias=self.rep[0, self.rep_bias_off[0]:self.rep_bias_off[0] + 64], cdot=self.rep[0, 960:963],
+                           nrep=self.NREP, rep_stride=self.REP_STRIDE, sat=self.sat_d)
+                c1_done = True
+            elif l > 0:
                 self._conv(f"D.c{l + 1}.dgrad", fl, ops.conv_dgrad, self.d_dzs[l], self.d_wt[l], self.d_da[l - 1], cin, cout)
         self._join_side()                                         # all gradient branches are in before the segment ends
         # dW_orig = sum_k G_k / sigma_k - sum_k c_k u_k v_k^T for the four spectrally-normalised layers, one launch -- which also

@@ -114,6 +114,22 @@ def conv_dgrad(dy, wt, dx, cin, cout, gscale=None, group_n=0, split_stride=0):
          int(split_stride))
 
 
+def conv_dgrad_act_bwd_ok(dt, N, Hi, cin, cout, with_sums) -> bool:
+    r = _lib.call_nostream("gcssl_conv4x4s2_dgrad_act_bwd_ok", dt, N, Hi, Hi, cin, cout, int(bool(with_sums)))
+    if r < 0:
+        raise RuntimeError(f"conv_dgrad_act_bwd_ok{(N, Hi, cin, cout)} -> {r}")
+    return bool(r)
+
+
+def conv_dgrad_act_bwd(dy, wt, a, dzs, cin, cout, gscale=None, group_n=0, bias=None, dbias=None, cdot=None, nrep=1, rep_stride=0,
+                       sat=None):
+    """conv_dgrad (fp32 dx) + act_bwd of the norm-less layer in front of the conv as ONE launch: dzs = lrelu'(a) dx gscale in the
+    compute dtype; dzs / a: [N][Hi][Wi][>=cin], dy: [N][Hi/2][Wi/2][>=cout]."""
+    N, Hi, Wi, _ = dzs.shape
+    call("gcssl_conv4x4s2_dgrad_act_bwd", code(dy), dy, _ld(dy), wt, a, _ld(a), gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot,
+         nrep, rep_stride, sat, N, Hi, Wi, cin, cout)
+
+
 def convt_in_relu_fwd(x, wt, mean, rstd, K, z32=None, z_n0=0, a=None, pool=None, cnt=None):
     """ConvTranspose2d(K -> 64, k4 s2 p1) + InstanceNorm + ReLU in one launch (csrc/convt_fused.hip).  x: [N][H][H][>=K],
     H in (8, 16), N*H*H a multiple of 256; wt: the dgrad pack [64][16][K].  Optional outputs: a (16-bit activation, may be a

@@ -102,6 +102,16 @@ int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, c
                           void* dx, int lddx, int N, int Hi, int Wi, int Cin, int Cout, int out_f32,
                           long split_stride, void* stream);
 int gcssl_conv4x4s2_dgrad_splits(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int out_f32);
+/* The same data gradient with the activation backward of the norm-less layer in FRONT of the conv (D.c1 / G.down1:
+ * Conv + LeakyReLU without InstanceNorm, cgan/models.py:103,246) in its epilogue -- gcssl_conv4x4s2_dgrad (fp32 dx) followed by
+ * gcssl_act_bwd as one launch, 16-bit dtypes, Cin == 64: dzs[N][Hi][Wi][lddz>=Cin] = lrelu'(a) * dx * gscale[n/group_n] in
+ * `dtype`, with a [N][Hi][Wi][lda] that layer's stored activation; dbias / cdot / nrep / rep_stride / sat as in gcssl_act_bwd
+ * (bias: that layer's conv bias).  _ok: 1 if the shapes are served (with_sums: dbias or cdot requested; only the persistent
+ * form carries them), 0 if the caller should use the two launches. */
+int gcssl_conv4x4s2_dgrad_act_bwd_ok(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int with_sums);
+int gcssl_conv4x4s2_dgrad_act_bwd(int dtype, const void* dy, int lddy, const void* wt, const void* a, int lda, const float* gscale,
+                                  int group_n, const float* bias, void* dzs, int lddz, float* dbias, float* cdot, int nrep,
+                                  int rep_stride, unsigned int* sat, int N, int Hi, int Wi, int Cin, int Cout, void* stream);
 /* weight gradient: slab[s][Cout][16][Cin] (fp32, s < gcssl_conv4x4s2_wgrad_splits(...)) partial sums over the
  * s-th K range of sum_{n,oy,ox} dy[n,oy,ox,co] x[n,2oy-1+ky,2ox-1+kx,ci].  Cin is 8 (padded first layer) or >= 64. */
 int gcssl_conv4x4s2_wgrad_splits(int N, int Hi, int Wi, int Cin, int Cout);

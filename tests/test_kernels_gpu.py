@@ -322,6 +322,59 @@ def test_instance_norm_bwd_from_activation(ops, dt, tol, N, H, C):
     assert rel_err(cd2.cpu(), (gzs * qz).sum().view(1)) < 1e-4
 
 
+@pytest.mark.parametrize("dt,tol", DTS[1:])
+@pytest.mark.parametrize("N,with_sums", [(768, True), (256, False), (771, True)])
+def test_conv_dgrad_act_bwd_fused(ops, dt, tol, N, with_sums):
+    """gcssl_conv4x4s2_dgrad_act_bwd == gcssl_conv4x4s2_dgrad (fp32 dx) followed by gcssl_act_bwd: the critic's second layer's
+    data gradient with the first layer's LeakyReLU backward (+ bias-gradient and spectral-norm sums) in the epilogue.
+    768 / 771 samples: the persistent form (771: a ragged last tile); 256: the plain tiled form (no sums)."""
+    Hi, Cin, Cout = 16, 64, 128
+    code = ops.code(torch.empty(0, dtype=dt))
+    group_n = (N + 2) // 3 if N % 3 else N // 3
+    if N == 771:
+        group_n = 257                                   # 257 * 64 rows per class: not a multiple of 128 -> no per-group scale / sums
+    assert ops.conv_dgrad_act_bwd_ok(code, N, Hi, Cin, Cout, with_sums)
+    dy = q(rnd(N, Cout, Hi // 2, Hi // 2, seed=110), dt)
+    w = rnd(Cout, Cin, 4, 4, seed=111, scale=0.05)
+    a = q(F.leaky_relu(rnd(N, Cin, Hi, Hi, seed=112), 0.2), dt)
+    bias = rnd(Cin, seed=113, scale=0.1).cuda()
+    _, wt = packed_weights(ops, w, dt)
+    dyd, ad = nhwc(dy, dt), nhwc(a, dt)
+    grouped = N != 771
+    gs = torch.tensor([1.5, 0.5, 2.0], device="cuda") if grouped else None
+    nrep, stride = 4, 128
+    # unfused pair
+    dx = torch.empty(N, Hi, Hi, Cin, device="cuda")
+    ops.conv_dgrad(dyd, wt, dx, Cin, Cout)
+    dz_ref = torch.empty(N, Hi, Hi, Cin, device="cuda", dtype=dt)
+    db_ref = torch.zeros(nrep, stride, device="cuda"); cd_ref = torch.zeros(nrep, stride, device="cuda")
+    kw = dict(gscale=gs, group_n=group_n if grouped else 0)
+    if with_sums and grouped:
+        kw.update(bias=bias, dbias=db_ref[0, :Cin], cdot=cd_ref[0, 64:67], nrep=nrep, rep_stride=stride)
+    ops.act_bwd(dx, ad, dz_ref, Cin, **kw)
+    # fused
+    dz = torch.full((N, Hi, Hi, Cin), float("nan"), device="cuda", dtype=dt)
+    db = torch.zeros(nrep, stride, device="cuda"); cd = torch.zeros(nrep, stride, device="cuda")
+    kw2 = dict(gscale=gs, group_n=group_n if grouped else 0)
+    if with_sums and grouped:
+        kw2.update(bias=bias, dbias=db[0, :Cin], cdot=cd[0, 64:67], nrep=nrep, rep_stride=stride)
+    ops.conv_dgrad_act_bwd(dyd, wt, ad, dz, Cin, Cout, **kw2)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dz.float()).all())
+    assert rel_err(dz.float().cpu(), dz_ref.float().cpu()) < tol          # same fp32 sums up to MFMA order, one output rounding
+    # against the fp64 definition too
+    ref = F.conv_transpose2d(dy.double(), q(w, dt).double(), None, 2, 1)
+    ref = torch.where(a.double() > 0, ref, 0.2 * ref)
+    if grouped:
+        ref = ref * gs.cpu().double()[torch.arange(N) // group_n].view(-1, 1, 1, 1)
+    assert rel_err(nchw(dz), ref) < tol
+    if with_sums and grouped:
+        sb, sb_ref = db.sum(0)[:Cin].cpu(), db_ref.sum(0)[:Cin].cpu()
+        assert rel_err(sb, sb_ref) < 1e-4
+        sc, sc_ref = cd.sum(0)[64:67].cpu(), cd_ref.sum(0)[64:67].cpu()
+        assert rel_err(sc, sc_ref) < 1e-4
+
+
 @pytest.mark.parametrize("dt,tol", DTS)
 def test_act_bwd_and_dot(ops, dt, tol):
     N, H, C = 4, 16, 64
