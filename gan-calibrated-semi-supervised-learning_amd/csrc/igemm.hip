@@ -244,6 +244,8 @@ struct ConvParams {
     float* ab_dbias; float* ab_cdot;      // [Cin] += sum dz / [group] += sum dzs (z - bias), striped over ab_nrep replicas; nullable
     int ab_nrep, ab_rep_stride;
     unsigned* ab_sat;                     // += fp16 stores that clipped (nullable)
+    const void* ab_dotx; int ab_lddot; float* ab_dot_out;   // conv_fwd_c8_kernel's ACTB form: dot_out += sum dotx * y (y = the conv
+                                          // output BEFORE the activation backward: gcssl_dot_accum folded in), nullable
     int kcap;                             // timing experiment (GCSSL_KCAP, 3x3 persistent form only; results are garbage): walk only the
                                           // first kcap K steps of every tile -- the K volume a Winograd F(2x2,3x3) GEMM stage would have
     void* in_apre; int ld_apre, apre_n0;  // optional second output: the activation WITHOUT dropout for samples n >= apre_n0
@@ -2213,6 +2215,8 @@ __global__ __launch_bounds__(256) void conv_fwd_c8_kernel(ConvParams p, int ntil
             bf[j][ks] = __builtin_bit_cast(FragT, reinterpret_cast<const uint4*>(outt)[(32 * j + (lane & 31)) * WROW + 2 * ks + (lane >> 5)]);
     const int pl = 32 * wave + (lane & 31), oyl = pl >> p.lgWo, ox = pl & (Wo - 1), h = lane >> 5;
     const bool f32out = p.out_f32;
+    const bool actb = p.ab_a != nullptr;                                 // (the tile then holds fp32 values: host sizes it so)
+    float dot_acc = 0.f; int nsat = 0;
     const int cpp = f32out ? 16 : 8, es = f32out ? 4 : 2;                // 16-byte chunks per output pixel (64 channels)
     unsigned char* yb = static_cast<unsigned char*>(p.y);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -2255,15 +2259,49 @@ __global__ __launch_bounds__(256) void conv_fwd_c8_kernel(ConvParams p, int ntil
                 const int prow = 32 * wave + crow(r, lane);
                 float v = acc[j][r] * gs + b;
                 if (p.act == 1) v = lrelu_f(v);
-                if (f32out) reinterpret_cast<float*>(outt)[prow * 64 + co] = v;
+                if (f32out || actb) reinterpret_cast<float*>(outt)[prow * 64 + co] = v;
                 else reinterpret_cast<unsigned short*>(outt)[prow * 64 + co] = (unsigned short)Bits16<T>::enc(v);
             }
         }
         __syncthreads();
         const size_t m0 = (size_t)(n * Ho + oy0) * Wo;                   // first output pixel of the tile
+        if (actb) {
+            // activation backward of the layer whose (reverse-chain) forward this is: y = lrelu'(a) * v in the compute dtype,
+            // a = the stored activation at the same pixels; and the spectral-norm dot <dotx, v> of the same pass
+            const unsigned char* ab = static_cast<const unsigned char*>(p.ab_a);
+            const unsigned char* xb = static_cast<const unsigned char*>(p.ab_dotx);
+            for (int c = tid; c < MT * 8; c += 256) {
+                const int px = c >> 3, ch = c & 7;
+                const float4 v0 = reinterpret_cast<const float4*>(outt)[px * 16 + ch * 2], v1 = reinterpret_cast<const float4*>(outt)[px * 16 + ch * 2 + 1];
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                const uint4 aw = *reinterpret_cast<const uint4*>(ab + ((m0 + px) * p.ab_lda) * 2 + ch * 16);
+                const unsigned awv[4] = {aw.x, aw.y, aw.z, aw.w};
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = Bits16<T>::dec(awv[e >> 1] >> (16 * (e & 1))) > 0.f ? v[e] : 0.2f * v[e];
+                if (xb) {
+                    const uint4 xw = *reinterpret_cast<const uint4*>(xb + ((m0 + px) * p.ab_lddot) * 2 + ch * 16);
+                    const unsigned xwv[4] = {xw.x, xw.y, xw.z, xw.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dot_acc += Bits16<T>::dec(xwv[e >> 1] >> (16 * (e & 1))) * v[e];
+                }
+                nsat += sat_hits<T>(o);
+                uint4 w; w.x = pack2<T>(o[0], o[1]); w.y = pack2<T>(o[2], o[3]); w.z = pack2<T>(o[4], o[5]); w.w = pack2<T>(o[6], o[7]);
+                *reinterpret_cast<uint4*>(yb + ((m0 + px) * p.ldy) * 2 + ch * 16) = w;
+            }
+            continue;
+        }
         for (int c = tid; c < MT * cpp; c += 256) {
             const int px = f32out ? c >> 4 : c >> 3, ch = c & (cpp - 1);
             *reinterpret_cast<uint4*>(yb + ((m0 + px) * p.ldy) * es + ch * 16) = reinterpret_cast<const uint4*>(outt)[c];
+        }
+    }
+    if (actb) {
+        sat_commit(p.ab_sat, nsat);
+        if (p.ab_dot_out) {
+            __shared__ float dred[4];
+            const float tot = block_sum<4>(dot_acc, dred);
+            if (tid == 0) atomicAdd(p.ab_dot_out, tot);
         }
     }
 #endif
@@ -2279,7 +2317,7 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
             p.ldx % 8 == 0 && p.ldy % (p.out_f32 ? 4 : 8) == 0 && aligned16(p.y)) {
             if (p.plan_out) { *p.plan_out = 1; return GCSSL_OK; }
             const int R = 128 / Wo, rows = 2 * R + 2;
-            size_t tile_b = (size_t)128 * 64 * (p.out_f32 ? 4 : 2);
+            size_t tile_b = (size_t)128 * 64 * ((p.out_f32 || p.ab_a) ? 4 : 2);
             if (tile_b < (size_t)64 * 17 * 16) tile_b = (size_t)64 * 17 * 16;       // the region first holds the padded weight image
             const size_t lds = (size_t)rows * (p.Wi + 2) * 16 + tile_b;
             const int ntiles = p.N * ((p.Hi / 2) / R), per = (ntiles + 1023) / 1024, grid = (ntiles + per - 1) / per;
@@ -2739,6 +2777,44 @@ int gcssl_conv4x4s2_dgrad_act_bwd(int dtype, const void* dy, int lddy, const voi
     }
     if (!actb_form(p, dbias || cdot)) return GCSSL_EBADSHAPE;
     GCSSL_DISPATCH(dtype, return dispatch_dgrad_actb<T>(p, (hipStream_t)stream));
+    return GCSSL_EBADDTYPE;
+}
+
+// The 8-channel first layer's conv as the FORWARD of the reverse (double-backward) gradient-penalty chain, with the layer's
+// LeakyReLU backward and the <dotx, conv output> spectral-norm term in the epilogue: y = lrelu'(a) * (gscale * conv(x)) in the
+// compute dtype.  The fp32 conv output never goes to memory.  Served by conv_fwd_c8_kernel's shapes only (Cin 8 -> Cout 64).
+static bool fwd_actb_shape(int N, int Hi, int Wi, int Cin, int Cout) {
+    static const bool on = [] { const char* e = getenv("GCSSL_FWD_ACTB"); return !(e && e[0] == '0'); }();
+    const int Wo = Wi / 2;
+    return on && Cin == 8 && Cout == 64 && (Wo == 16 || Wo == 32 || Wo == 64) && (Hi / 2) % (128 / Wo) == 0 && c8_fwd_on();
+}
+int gcssl_conv4x4s2_fwd_act_bwd_ok(int dtype, int N, int Hi, int Wi, int Cin, int Cout) {
+    int rc = check_geom(N, Hi, Wi, Cin, Cout);
+    if (rc) return rc;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    return dtype != GCSSL_F32 && fwd_actb_shape(N, Hi, Wi, Cin, Cout) ? 1 : 0;
+}
+
+int gcssl_conv4x4s2_fwd_act_bwd(int dtype, const void* x, int ldx, const void* wf, const float* gscale, int group_n, const void* a,
+                                int lda, void* y, int ldy, const void* dotx, int lddot, float* dot_out, unsigned* sat, int N, int Hi,
+                                int Wi, int Cin, int Cout, void* stream) {
+    if (!x || !wf || !a || !y) return GCSSL_ENULL;
+    int rc = check_geom(N, Hi, Wi, Cin, Cout);
+    if (rc) return rc;
+    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (dtype == GCSSL_F32) return GCSSL_EBADDTYPE;
+    if (!fwd_actb_shape(N, Hi, Wi, Cin, Cout)) return GCSSL_EBADSHAPE;
+    if ((dotx != nullptr) != (dot_out != nullptr)) return GCSSL_EBADSHAPE;
+    if (ldx < Cin || lda < Cout || ldy < Cout || (dotx && lddot < Cout) || (gscale && group_n <= 0)) return GCSSL_EBADSHAPE;
+    if (ldx % 8 || lda % 8 || ldy % 8 || (dotx && lddot % 8) || !aligned16(x) || !aligned16(wf) || !aligned16(a) || !aligned16(y) ||
+        (dotx && !aligned16(dotx))) return GCSSL_EALIGN;
+    ConvParams p{}; p.x = x; p.w = wf; p.y = y; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
+    p.ldx = ldx; p.ldy = ldy;
+    p.ab_a = a; p.ab_lda = lda; p.ab_dotx = dotx; p.ab_lddot = lddot; p.ab_dot_out = dot_out; p.ab_sat = sat;
+    fill_geom(p, N, Hi, Wi, Cin, Cout);
+    if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)Cout * 16 * Cin, 2)) return GCSSL_EBADSHAPE;
+    p.y_bytes = 1;
+    GCSSL_DISPATCH(dtype, return dispatch_fwd<T>(p, (hipStream_t)stream));
     return GCSSL_EBADDTYPE;
 }
 

@@ -346,6 +346,13 @@ class StepEngine:
             self._fin_cache[key] = self.code != _lib.F32 and ops.conv_dgrad_act_bwd_ok(self.code, n, hi, cin, cout, with_sums)
         return self._fin_cache[key]
 
+    def _fwd_actb(self, n: int, hi: int, cin: int, cout: int) -> bool:
+        """... and the one-launch first-layer conv + activation backward + dot of the reverse gradient-penalty chain?"""
+        key = ("fwd_actb", n, hi, cin, cout)
+        if key not in self._fin_cache:
+            self._fin_cache[key] = self.code != _lib.F32 and ops.conv_fwd_act_bwd_ok(self.code, n, hi, cin, cout)
+        return self._fin_cache[key]
+
     # ------------------------------------------------------------------------------------------ buffers
     def _alloc(self):
         B, S, T, dev = self.B, self.S, self.T, self.dev
@@ -835,6 +842,12 @@ class StepEngine:
         for l, (cin, cout) in enumerate(D_CH):
             cp = _pad8(cin)
             fl = conv_flops(B, S >> l, cin, cout)
+            if l == 0 and self._fwd_actb(B, S, cp, cout):
+                # conv + c1's LeakyReLU backward + the <gb_zs, gt_z> spectral-norm term as one launch: no fp32 gt_z[0]
+                self._conv("D.c1.gp_rev_fwd", fl, ops.conv_fwd_act_bwd, src, self.d_wf[0], self.d_a[0][I], self.gt_a[0], cp, cout,
+                           gscale=isig[0, 2:3], group_n=B, dotx=self.gb_zs[0], dot_out=self.cdot[0, 2:3], sat=self.sat_d)
+                src = self.gt_a[0]
+                continue
             ns, st = self._split("fwd", self.gt_z[l], B, S >> l, cin, cout, max_hw=64, grad=True) if l > 0 else (1, 0)
             self._conv(f"D.c{l + 1}.gp_rev_fwd", fl, ops.conv_fwd, src, self.d_wf[l], self.gt_z[l], cp, cout,
                        gscale=isig[l, 2:3], group_n=B, split_stride=st)

@@ -130,6 +130,21 @@ def conv_dgrad_act_bwd(dy, wt, a, dzs, cin, cout, gscale=None, group_n=0, bias=N
          nrep, rep_stride, sat, N, Hi, Wi, cin, cout)
 
 
+def conv_fwd_act_bwd_ok(dt, N, Hi, cin, cout) -> bool:
+    r = _lib.call_nostream("gcssl_conv4x4s2_fwd_act_bwd_ok", dt, N, Hi, Hi, cin, cout)
+    if r < 0:
+        raise RuntimeError(f"conv_fwd_act_bwd_ok{(N, Hi, cin, cout)} -> {r}")
+    return bool(r)
+
+
+def conv_fwd_act_bwd(x, wf, a, y, cin, cout, gscale=None, group_n=0, dotx=None, dot_out=None, sat=None):
+    """conv_fwd (fp32 v, first layer 8 -> 64) + act_bwd + the <dotx, v> sum as ONE launch: y = lrelu'(a) v in the compute
+    dtype; x: [N][Hi][Wi][>=cin], a / y / dotx: [N][Hi/2][Wi/2][>=cout]."""
+    N, Hi, Wi, _ = x.shape
+    call("gcssl_conv4x4s2_fwd_act_bwd", code(x), x, _ld(x), wf, gscale, group_n, a, _ld(a), y, _ld(y), dotx,
+         _ld(dotx) if dotx is not None else 0, dot_out, sat, N, Hi, Wi, cin, cout)
+
+
 def convt_in_relu_fwd(x, wt, mean, rstd, K, z32=None, z_n0=0, a=None, pool=None, cnt=None):
     """ConvTranspose2d(K -> 64, k4 s2 p1) + InstanceNorm + ReLU in one launch (csrc/convt_fused.hip).  x: [N][H][H][>=K],
     H in (8, 16), N*H*H a multiple of 256; wt: the dgrad pack [64][16][K].  Optional outputs: a (16-bit activation, may be a

@@ -112,6 +112,16 @@ int gcssl_conv4x4s2_dgrad_act_bwd_ok(int dtype, int N, int Hi, int Wi, int Cin, 
 int gcssl_conv4x4s2_dgrad_act_bwd(int dtype, const void* dy, int lddy, const void* wt, const void* a, int lda, const float* gscale,
                                   int group_n, const float* bias, void* dzs, int lddz, float* dbias, float* cdot, int nrep,
                                   int rep_stride, unsigned int* sat, int N, int Hi, int Wi, int Cin, int Cout, void* stream);
+/* gcssl_conv4x4s2_fwd of the 8-channel first layer (Cin 8 -> Cout 64) as the forward of the double-backward gradient-penalty
+ * chain (the create_graph=True part of d_loss.backward(), cgan/cgan_train_enhanced.py:330, through D.c1 = Conv + LeakyReLU,
+ * cgan/models.py:246), with gcssl_act_bwd and gcssl_dot_accum in its epilogue, 16-bit dtypes: with v = gscale[n/group_n] *
+ * conv(x, W) (fp32, never stored), y[N][Hi/2][Wi/2][ldy>=Cout] = lrelu'(a) * v in `dtype` (a: that layer's stored activation,
+ * same layout, lda) and, if dotx is given, *dot_out += sum dotx * v.  sat as in gcssl_act_bwd.  _ok: 1 if served, 0 if the
+ * caller should use the three launches. */
+int gcssl_conv4x4s2_fwd_act_bwd_ok(int dtype, int N, int Hi, int Wi, int Cin, int Cout);
+int gcssl_conv4x4s2_fwd_act_bwd(int dtype, const void* x, int ldx, const void* wf, const float* gscale, int group_n, const void* a,
+                                int lda, void* y, int ldy, const void* dotx, int lddot, float* dot_out, unsigned int* sat, int N,
+                                int Hi, int Wi, int Cin, int Cout, void* stream);
 /* weight gradient: slab[s][Cout][16][Cin] (fp32, s < gcssl_conv4x4s2_wgrad_splits(...)) partial sums over the
  * s-th K range of sum_{n,oy,ox} dy[n,oy,ox,co] x[n,2oy-1+ky,2ox-1+kx,ci].  Cin is 8 (padded first layer) or >= 64. */
 int gcssl_conv4x4s2_wgrad_splits(int N, int Hi, int Wi, int Cin, int Cout);

@@ -56,6 +56,10 @@ def test_argument_validation_without_gpu(lib_mod):
     assert h.gcssl_conv4x4s2_in_act_ok(2, 768, 8, 8, 128, 256) == 1          # D.c3 at the bench batch, fp16: the fused launch
     assert h.gcssl_conv4x4s2_in_act_ok(2, 384, 32, 32, 64, 128) == 0         # 16x16 maps: a sample does not fit a tile
     assert h.gcssl_conv4x4s2_in_act_fwd(2, None, 64, None, None, None, 0, None, 64, None, None, None, None, 0, 0, 4, 8, 8, 64, 64, 1, None) == -4
+    assert h.gcssl_conv4x4s2_fwd_act_bwd_ok(2, 256, 32, 32, 8, 64) == 1          # D.c1 of the reverse GP chain
+    assert h.gcssl_conv4x4s2_fwd_act_bwd_ok(0, 256, 32, 32, 8, 64) == 0
+    assert h.gcssl_conv4x4s2_fwd_act_bwd_ok(2, 256, 16, 16, 64, 128) == 0
+    assert h.gcssl_conv4x4s2_fwd_act_bwd(2, None, 8, None, None, 0, None, 64, None, 64, None, 0, None, None, 4, 32, 32, 8, 64, None) == -4
     assert h.gcssl_last_kernel() is not None
 
 

@@ -375,6 +375,47 @@ def test_conv_dgrad_act_bwd_fused(ops, dt, tol, N, with_sums):
         assert rel_err(sc, sc_ref) < 1e-4
 
 
+@pytest.mark.parametrize("dt,tol", DTS[1:])
+@pytest.mark.parametrize("N,S", [(256, 32), (5, 64), (3, 128)])
+def test_conv_fwd_act_bwd_fused(ops, dt, tol, N, S):
+    """gcssl_conv4x4s2_fwd_act_bwd == gcssl_conv4x4s2_fwd (fp32 out) -> gcssl_act_bwd with its dot: the first layer of the reverse
+    gradient-penalty chain as one launch."""
+    Cin, Cout = 8, 64
+    code = ops.code(torch.empty(0, dtype=dt))
+    assert ops.conv_fwd_act_bwd_ok(code, N, S, Cin, Cout)
+    x = q(rnd(N, Cin, S, S, seed=120), dt)
+    w = rnd(Cout, Cin, 4, 4, seed=121, scale=0.1)
+    a = q(F.leaky_relu(rnd(N, Cout, S // 2, S // 2, seed=122), 0.2), dt)
+    dx = q(rnd(N, Cout, S // 2, S // 2, seed=123), dt)
+    wf, _ = packed_weights(ops, w, dt)
+    xd, ad, dxd = nhwc(x, dt), nhwc(a, dt), nhwc(dx, dt)
+    gs = torch.tensor([0.75], device="cuda")
+    # unfused
+    v = torch.empty(N, S // 2, S // 2, Cout, device="cuda")
+    ops.conv_fwd(xd, wf, v, Cin, Cout, gscale=gs, group_n=N)
+    y_ref = torch.empty(N, S // 2, S // 2, Cout, device="cuda", dtype=dt)
+    dot_ref = torch.zeros(1, device="cuda")
+    ops.act_bwd(v, ad, y_ref, Cout, dotx=dxd, dot_out=dot_ref)
+    # fused
+    y = torch.full((N, S // 2, S // 2, Cout), float("nan"), device="cuda", dtype=dt)
+    dot = torch.zeros(1, device="cuda")
+    sat = torch.zeros(1, device="cuda", dtype=torch.int32)
+    ops.conv_fwd_act_bwd(xd, wf, ad, y, Cin, Cout, gscale=gs, group_n=N, dotx=dxd, dot_out=dot, sat=sat)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y.float()).all())
+    assert torch.equal(y.cpu(), y_ref.cpu())                         # the same fp32 values, one rounding
+    assert rel_err(dot.cpu(), dot_ref.cpu()) < 1e-4
+    assert int(sat.item()) == 0
+    ref = 0.75 * F.conv2d(x.double(), q(w, dt).double(), None, 2, 1)
+    assert rel_err(dot.cpu().double(), (dx.double() * ref).sum().view(1)) < 1e-3
+    ref = torch.where(a.double() > 0, ref, 0.2 * ref)
+    assert rel_err(nchw(y), ref) < tol
+    # without the dot
+    y2 = torch.empty_like(y)
+    ops.conv_fwd_act_bwd(xd, wf, ad, y2, Cin, Cout, gscale=gs, group_n=N)
+    assert torch.equal(y2.cpu(), y.cpu())
+
+
 @pytest.mark.parametrize("dt,tol", DTS)
 def test_act_bwd_and_dot(ops, dt, tol):
     N, H, C = 4, 16, 64
