@@ -276,6 +276,9 @@ def main():
             raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
         dev = torch.device("cuda", local)
         torch.cuda.set_device(dev)
+        if os.environ.get("GCSSL_MAIN_PRIO"):              # A/B knob: the rank's compute stream at another priority (-1 = high)
+            torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["GCSSL_MAIN_PRIO"])))
+            print(f"[bench] main stream priority {torch.cuda.current_stream().priority} of range {torch.cuda.Stream.priority_range()}", file=sys.stderr)
         if torch.distributed.is_initialized():
             torch.distributed.all_reduce(torch.zeros(1, device=dev))
             torch.cuda.synchronize()

@@ -2197,6 +2197,23 @@ __global__ __launch_bounds__(256) void conv_fwd_c8_kernel(ConvParams p, int ntil
     uint4* img = reinterpret_cast<uint4*>(c8_lds);                       // [rows][Wi + 2] pixels of 16 bytes
     unsigned char* outt = c8_lds + (size_t)rows * rowpx * 16;            // [128][64] result tile; first: the weight image
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+    // input image: chunk c -> (row, px); rows outside the map read OOB = 0; the two pad pixels of a row are zeroed.  A tile's
+    // chunks (<= 3 per thread) are fetched into registers one tile AHEAD: the loads of tile t+1 fly under the MFMAs, the LDS
+    // transpose and the stores of tile t (fetch -> LDS -> MFMA -> LDS -> store in sequence left every phase exposed)
+    constexpr int NC = 3;
+    const int nchunk = rows * p.Wi;                                      // 576 / 640 / 768 for Wo = 16 / 32 / 64
+    u32x4 pre[NC];
+    auto fetch = [&](int tile) {
+        const int n = tile / tiles_per_n, iy0 = 2 * (tile - n * tiles_per_n) * R - 1;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c >> (p.lgWo + 1), px = c & (p.Wi - 1), iy = iy0 + row;
+            const bool ok = c < nchunk && (unsigned)iy < (unsigned)p.Hi;
+            pre[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((((n * p.Hi + iy) * p.Wi + px) * p.ldx) * 2) : OOB, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);                     // (in flight under the weight prologue below)
     // The packed weight Wf[64 co][16 taps][8 ci] (16 KB) is fetched ONCE per workgroup with coalesced 16-byte loads and
     // passed through LDS (rows padded to 17 chunks: the fragment reads of 32 consecutive co are conflict-free).  Loading
     // the fragments straight from memory touches 32 different 128-byte lines per instruction, and L1 serves lines, not
@@ -2221,17 +2238,15 @@ __global__ __launch_bounds__(256) void conv_fwd_c8_kernel(ConvParams p, int ntil
     unsigned char* yb = static_cast<unsigned char*>(p.y);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int n = tile / tiles_per_n, oy0 = (tile - n * tiles_per_n) * R;
-        // input image: chunk c -> (row, px); rows outside the map read OOB = 0; the two pad pixels of a row are zeroed.
         // (The barrier that follows also closes the previous tile's reads of `outt` / the weight image.)
-        const int iy0 = 2 * oy0 - 1, nchunk = rows * p.Wi;
-        for (int c = tid; c < nchunk; c += 256) {
-            const int row = c >> (p.lgWo + 1), px = c & (p.Wi - 1), iy = iy0 + row;
-            const bool ok = (unsigned)iy < (unsigned)p.Hi;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((((n * p.Hi + iy) * p.Wi + px) * p.ldx) * 2) : OOB, 0, 0);
-            img[row * rowpx + px + 1] = __builtin_bit_cast(uint4, v);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = tid + 256 * i;
+            if (c < nchunk) img[(c >> (p.lgWo + 1)) * rowpx + (c & (p.Wi - 1)) + 1] = __builtin_bit_cast(uint4, pre[i]);
         }
         if (tid < 2 * rows) img[(tid >> 1) * rowpx + ((tid & 1) ? p.Wi + 1 : 0)] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
         // A fragments: lane -> output pixel pl of the tile, tap = 2 ks + h: one ds_read_b128 of the image each
         f32x16 acc[2];
 #pragma unroll
@@ -2320,7 +2335,10 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
             size_t tile_b = (size_t)128 * 64 * ((p.out_f32 || p.ab_a) ? 4 : 2);
             if (tile_b < (size_t)64 * 17 * 16) tile_b = (size_t)64 * 17 * 16;       // the region first holds the padded weight image
             const size_t lds = (size_t)rows * (p.Wi + 2) * 16 + tile_b;
-            const int ntiles = p.N * ((p.Hi / 2) / R), per = (ntiles + 1023) / 1024, grid = (ntiles + per - 1) / per;
+            // two workgroups per CU, each walking its share of the tiles (768 x 32 x 32: 19.4 us with 768 workgroups of two tiles,
+            // 16.2 us with 512 of three; GCSSL_C8_GRID: A/B)
+            static const int gmax = [] { const char* e = getenv("GCSSL_C8_GRID"); return e ? atoi(e) : 2 * cu_count(); }();
+            const int ntiles = p.N * ((p.Hi / 2) / R), per = (ntiles + gmax - 1) / gmax, grid = (ntiles + per - 1) / per;
             GCSSL_LAUNCH(conv_fwd_c8_kernel<T>, dim3((unsigned)grid), dim3(256), lds, st, p, ntiles);
             return gcssl_launch_status();
         }
@@ -2451,6 +2469,22 @@ __global__ __launch_bounds__(256) void conv_dgrad_c8_kernel(ConvParams p, int nt
     uint4* img = reinterpret_cast<uint4*>(c8_lds);                       // [rows][Wo + 2] pixels x 8 chunks
     unsigned char* outt = c8_lds + (size_t)rows * rowpx * 128;           // [2R][Wi][8] result tile; first: the weight image
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+    // dy image: chunk c -> (row, pixel, 16-byte chunk); image row i = dy row oy0 - 1 + i.  Fetched into registers one tile
+    // ahead (<= 3 chunks per thread), like conv_fwd_c8_kernel's input image.
+    constexpr int NC = 3;
+    const int nchunk = rows * Wo * 8;                                    // 512 / 768 for Wo = 16 / 32
+    u32x4 pre[NC];
+    auto fetch = [&](int tile) {
+        const int n = tile / tiles_per_n, oy0 = (tile - n * tiles_per_n) * R;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = tid + 256 * i;
+            const int ch = c & 7, pxl = (c >> 3) & (Wo - 1), row = c >> (3 + p.lgWo), oy = oy0 - 1 + row;
+            const bool ok = c < nchunk && (unsigned)oy < (unsigned)Ho;
+            pre[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((((n * Ho + oy) * Wo + pxl) * p.ldx + ch * 8) * 2) : OOB, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);                     // (in flight under the weight prologue below)
     {
         uint4* wimg = reinterpret_cast<uint4*>(outt);
         for (int c = tid; c < 8 * 128; c += 256)
@@ -2476,20 +2510,21 @@ __global__ __launch_bounds__(256) void conv_dgrad_c8_kernel(ConvParams p, int nt
     unsigned char* yb = static_cast<unsigned char*>(p.y);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int n = tile / tiles_per_n, oy0 = (tile - n * tiles_per_n) * R;
-        // dy image: chunk c -> (row, pixel, 16-byte chunk); image row i = dy row oy0 - 1 + i
-        const int nchunk = rows * Wo * 8;
-        for (int c = tid; c < nchunk; c += 256) {
-            const int ch = c & 7, pxl = (c >> 3) & (Wo - 1), row = c >> (3 + p.lgWo), oy = oy0 - 1 + row;
-            const bool ok = (unsigned)oy < (unsigned)Ho;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((((n * Ho + oy) * Wo + pxl) * p.ldx + ch * 8) * 2) : OOB, 0, 0);
-            const int pix = row * rowpx + pxl + 1;
-            img[pix * 8 + (ch ^ (pix & 7))] = __builtin_bit_cast(uint4, v);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = tid + 256 * i;
+            if (c < nchunk) {
+                const int ch = c & 7, pxl = (c >> 3) & (Wo - 1), row = c >> (3 + p.lgWo);
+                const int pix = row * rowpx + pxl + 1;
+                img[pix * 8 + (ch ^ (pix & 7))] = __builtin_bit_cast(uint4, pre[i]);
+            }
         }
         if (tid < 2 * rows * 8) {                                        // the two pad pixels of every row
             const int pix = (tid >> 4) * rowpx + (((tid >> 3) & 1) ? Wo + 1 : 0);
             img[pix * 8 + (tid & 7)] = make_uint4(0u, 0u, 0u, 0u);
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -2539,7 +2574,9 @@ int dispatch_dgrad(ConvParams p, hipStream_t st) {
             size_t tile_b = (size_t)2 * R * p.Wi * 8 * (p.out_f32 ? 4 : 2);
             if (tile_b < (size_t)8 * 129 * 16) tile_b = (size_t)8 * 129 * 16;       // the region first holds the padded weight image
             const size_t lds = (size_t)rows * (Wo + 2) * 128 + tile_b;
-            const int ntiles = p.N * ((p.Hi / 2) / R), per = (ntiles + 1023) / 1024, grid = (ntiles + per - 1) / per;
+            // (256 x 32 x 32, 2048 tiles: 12.9 us with 1024 workgroups, 11.3 us with 512; GCSSL_C8_DGRID: A/B)
+            static const int gmax = [] { const char* e = getenv("GCSSL_C8_DGRID"); return e ? atoi(e) : 2 * cu_count(); }();
+            const int ntiles = p.N * ((p.Hi / 2) / R), per = (ntiles + gmax - 1) / gmax, grid = (ntiles + per - 1) / per;
             GCSSL_LAUNCH(conv_dgrad_c8_kernel<T>, dim3((unsigned)grid), dim3(256), lds, st, p, ntiles);
             return gcssl_launch_status();
         }

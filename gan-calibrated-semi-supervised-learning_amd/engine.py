@@ -1204,6 +1204,41 @@ class GraphedIteration:
                 if not self.pipelined:
                     eng._g_dirty = True
                 eng.run_iteration(pred, gt, delta_true, pred_box, refine_fn, next_forward=self.pipelined)
+            # GCSSL_TWO_STREAM (default on, pipelined form only): the same launches in the same dependency order as FOUR LINEAR
+            # graphs on two streams instead of one graph with a parallel branch --
+            #   this stream:  [Ca: critic steps 0..c-2, d_pre of the last]  [Cb: last critic step, value-only forward]
+            #   side stream:  [Ga: generator backward]                      [Gb: generator update, batched forward i+1]
+            #   Ca(i) after Gb(i-1);  Gb(i) after Ca(i) (the last d_pre's reads);  Cb(i) after Ga(i) (the re-crop);
+            #   Ga(i+1) after Cb(i) (it rewrites that re-crop)
+            # The runtime's executor for a graph WITH branches left the critic's chain idle for ~240 us at the head of every replay
+            # and ~190 us at its tail (profiles/round3_timeline_one_graph.txt: 77 % of the period with ONE kernel resident); linear
+            # graphs replay as pre-built packet streams, and the generator's chain now runs a segment ahead of the critic's.
+            self.two_stream = self.pipelined and os.environ.get("GCSSL_TWO_STREAM", "1") != "0"
+            if self.two_stream:
+                c = eng.c
+                self.side = torch.cuda.Stream(device=eng.dev)
+                eng._g_dirty = True
+                pool_main, pool = pool, None                       # the generator's graphs replay beside the critic's: own pool
+                self.prologue = capture(lambda: eng.g_forward_all(pred, None))
+                eng._in_g_branch = True                            # (no forks inside a segment: every graph stays linear)
+                try:
+                    self.g_a = capture(lambda: eng.g_main(pred, delta_true, pred_box, refine_fn, None))
+                    pool_g, pool = pool, pool_main
+
+                    def seg_a():
+                        eng._d_dirty = True
+                        for k in range(c):
+                            eng.d_pre(pred, gt, refine_fn, k, None, None)
+                            if k < c - 1:
+                                eng.d_main(); eng.d_update()
+                    self.c_a = capture(seg_a)
+                    self.c_b = capture(lambda: (eng.d_main(), eng.d_update(), eng.g_critic(pred)))
+                    pool = pool_g
+                    self.g_b = capture(lambda: (eng.g_update(), eng.g_forward_all(pred, None)))
+                finally:
+                    eng._in_g_branch = False
+                self.ev_cb = self.ev_gb = None
+                return
             if self.pipelined:
                 eng._g_dirty = True
                 self.prologue = capture(lambda: eng.g_forward_all(pred, None))
@@ -1244,7 +1279,7 @@ class GraphedIteration:
         # GCSSL_DP_BRANCH=0: the round-2 schedule (generator halves serial under the critic's all-reduces).
         self.dp_branch = eng.batch_g and os.environ.get("GCSSL_DP_BRANCH", "1") != "0"
         if self.dp_branch:
-            self.side = torch.cuda.Stream(device=eng.dev)
+            self.side = torch.cuda.Stream(device=eng.dev, priority=int(os.environ.get("GCSSL_SIDE_PRIO", "0")))
             self.gfwd = capture(lambda: eng.g_forward_all(pred, None))
             eng._g_dirty = False
             self.first = capture(lambda: (eng.d_pre(pred, gt, refine_fn, 0, None, None), eng.d_main()))
@@ -1276,6 +1311,26 @@ class GraphedIteration:
 
     def replay(self):
         eng = self.eng
+        if self.fused_update and getattr(self, "two_stream", False):
+            main, side = torch.cuda.current_stream(), self.side
+            if not self._primed:
+                self.prologue.replay()                            # the first iteration's batched generator forward
+                self._primed = True
+            ev0 = torch.cuda.Event(); ev0.record(main)            # (Gb(i-1) and Cb(i-1) are ordered in front of this: see the tail)
+            side.wait_event(ev0)
+            with torch.cuda.stream(side):
+                self.g_a.replay()
+                ev_ga = torch.cuda.Event(); ev_ga.record(side)
+            self.c_a.replay()
+            ev_ca = torch.cuda.Event(); ev_ca.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_ca)
+                self.g_b.replay()
+                ev_gb = torch.cuda.Event(); ev_gb.record(side)
+            main.wait_event(ev_ga)
+            self.c_b.replay()
+            main.wait_event(ev_gb)                                # the caller's stream sees the whole iteration
+            return
         if self.fused_update:
             if getattr(self, "pipelined", False) and not self._primed:
                 self.prologue.replay()                            # the first iteration's batched generator forward

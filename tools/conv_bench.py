@@ -1,5 +1,5 @@
 """Standalone launcher of ONE conv configuration (for rocprofv3 --pmc / timing experiments).
-usage: python tools/conv_bench.py {fwd|fwd_in|dgrad|wgrad} N Hi Cin Cout [dtype] [reps]
+usage: python tools/conv_bench.py {fwd|fwd16|fwd_in|dgrad|wgrad} N Hi Cin Cout [dtype] [reps]
 (fwd_in: the one-launch conv + InstanceNorm + LeakyReLU form, 16-bit activation + fp32 statistics out)"""
 import importlib, sys, time, torch
 from pathlib import Path
@@ -21,6 +21,7 @@ a16 = torch.empty(N, Hi // 2, Hi // 2, Cout, device="cuda", dtype=dt)
 mean = torch.empty(N, Cout, device="cuda"); rstd = torch.empty(N, Cout, device="cuda")
 def run():
     if kind == "fwd": ops.conv_fwd(x, wf, y, Cin, Cout)
+    elif kind == "fwd16": ops.conv_fwd(x, wf, a16, Cin, Cout, act=1)          # 16-bit output + LeakyReLU (the norm-less first layers)
     elif kind == "fwd_in": ops.conv_in_act_fwd(x, wf, a16, mean, rstd, Cin, Cout)
     elif kind == "dgrad": ops.conv_dgrad(dy, wt, dx, Cin, Cout)
     else: ops.conv_wgrad(x, dy, slab, Cin, Cout)
@@ -32,4 +33,4 @@ for _ in range(reps): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 fl = 2.0 * N * (Hi // 2) ** 2 * Cout * 16 * Cin
-print(f"{kind} N={N} Hi={Hi} Cin={Cin} Cout={Cout} {dt}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF/s")
+print(f"{kind} N={N} Hi={Hi} Cin={Cin} Cout={Cout} {dt}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF/s  {ops.last_kernel()}")

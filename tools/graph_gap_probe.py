@@ -1,0 +1,43 @@
+"""GPU-side gaps between graph launches (run under rocprofv3 --kernel-trace, then tools/prof_timeline.py).
+usage: python tools/graph_gap_probe.py {critic_only|critic_first|full|no_events} [iterations]"""
+import importlib, os, sys, time
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import bench
+PKG = bench.PKG
+engine = importlib.import_module(PKG + ".engine"); synth = importlib.import_module(PKG + ".synth"); dist_mod = importlib.import_module(PKG + ".dist")
+mode = sys.argv[1]; iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+run = bench.Runner(engine, synth, dist_mod, dev, 0, 1, 256, 32, 2, "bf16", "unet", 3)
+gi = run.graphed
+assert gi.two_stream
+for _ in range(20): gi.replay()
+torch.cuda.synchronize()
+main, side = torch.cuda.current_stream(), gi.side
+t0 = time.perf_counter()
+for _ in range(iters):
+    if mode == "critic_only":
+        gi.c_a.replay(); gi.c_b.replay()
+    elif mode == "full":
+        gi.replay()
+    elif mode == "no_events":                      # both chains free-running (results are garbage: timing only)
+        with torch.cuda.stream(side):
+            gi.g_a.replay(); gi.g_b.replay()
+        gi.c_a.replay(); gi.c_b.replay()
+    elif mode == "critic_first":
+        ev0 = torch.cuda.Event(); ev0.record(main)
+        gi.c_a.replay()
+        ev_ca = torch.cuda.Event(); ev_ca.record(main)
+        side.wait_event(ev0)
+        with torch.cuda.stream(side):
+            gi.g_a.replay()
+            ev_ga = torch.cuda.Event(); ev_ga.record(side)
+            side.wait_event(ev_ca)
+            gi.g_b.replay()
+            ev_gb = torch.cuda.Event(); ev_gb.record(side)
+        main.wait_event(ev_ga)
+        gi.c_b.replay()
+        main.wait_event(ev_gb)
+torch.cuda.synchronize()
+print(f"{mode}: {(time.perf_counter() - t0) / iters * 1e6:.1f} us per iteration")
