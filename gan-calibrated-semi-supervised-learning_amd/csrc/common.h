@@ -27,6 +27,11 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
         else if ((dt) == GCSSL_F16) { typedef f16_t T; __VA_ARGS__; }        \
         else { typedef bf16_t T; __VA_ARGS__; }                              \
     } while (0)
+#define GCSSL_DISPATCH16(dt, ...)    /* 16-bit compute dtypes only (the caller has excluded GCSSL_F32) */ \
+    do {                                                                     \
+        if ((dt) == GCSSL_F16) { typedef f16_t T; __VA_ARGS__; }             \
+        else { typedef bf16_t T; __VA_ARGS__; }                              \
+    } while (0)
 static inline bool gcssl_bad_dtype(int dt) { return dt != GCSSL_F32 && dt != GCSSL_BF16 && dt != GCSSL_F16; }
 
 static inline int gcssl_launch_status() {

@@ -217,6 +217,116 @@ __global__ __launch_bounds__(256) void c5_wgrad_kernel(const T* __restrict__ x, 
     }
 }
 
+// ---- the two head-conv gradients with a per-group CONSTANT dout (the only form the step engine launches: the WGAN seeds
+// -1/(B hw), +1/(B hw), 0 and the gradient-penalty seed 1), 16-bit activations, C = 512: a pixel's 512 channels are ONE
+// 1-KB row = one 16-byte access per lane of a wave.
+// dx[n, p, :] = g(n) * tab[p][:],  tab[p][c] = sum of wp[tap][c] over the taps through which pixel p reaches an output:
+// the table is built once per workgroup (<= 16 L2-hot rows per pixel), then the kernel is a streaming write.
+template <typename T>
+__global__ __launch_bounds__(256) void c5_dgrad_const_kernel(float g0, float g1, float g2, float g3, int group_n, const float* __restrict__ wp,
+                                                             T* __restrict__ dx, int lddx, int N, int Hi, int Wi, int per) {
+    constexpr int C = 512;
+    const int Ho = Hi - 1, Wo = Wi - 1, P = Hi * Wi;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane * 8;
+    const int nb = blockIdx.x * per, ne = min(N, nb + per);
+    for (int p = wave; p < P; p += 4) {
+        const int iy = p / Wi, ix = p - iy * Wi;
+        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < 4; ++ky) {
+            if ((unsigned)(iy + 1 - ky) >= (unsigned)Ho) continue;
+            for (int kx = 0; kx < 4; ++kx) {
+                if ((unsigned)(ix + 1 - kx) >= (unsigned)Wo) continue;
+                const float4 a = *reinterpret_cast<const float4*>(wp + (ky * 4 + kx) * C + c), b = *reinterpret_cast<const float4*>(wp + (ky * 4 + kx) * C + c + 4);
+                t[0] += a.x; t[1] += a.y; t[2] += a.z; t[3] += a.w; t[4] += b.x; t[5] += b.y; t[6] += b.z; t[7] += b.w;
+            }
+        }
+        for (int n = nb; n < ne; ++n) {
+            const int g = n / group_n;
+            const float gc = g == 0 ? g0 : (g == 1 ? g1 : (g == 2 ? g2 : g3));
+            T* o = dx + ((size_t)n * P + p) * lddx + c;
+            if constexpr (std::is_same<T, float>::value) {
+                reinterpret_cast<float4*>(o)[0] = make_float4(gc * t[0], gc * t[1], gc * t[2], gc * t[3]);
+                reinterpret_cast<float4*>(o)[1] = make_float4(gc * t[4], gc * t[5], gc * t[6], gc * t[7]);
+            } else {
+                uint4 w;
+                w.x = pack2<T>(gc * t[0], gc * t[1]); w.y = pack2<T>(gc * t[2], gc * t[3]);
+                w.z = pack2<T>(gc * t[4], gc * t[5]); w.w = pack2<T>(gc * t[6], gc * t[7]);
+                *reinterpret_cast<uint4*>(o) = w;
+            }
+        }
+    }
+}
+// dw[c][tap] += sum_p [p reaches an output through tap] sum_n g(n) x[n, p, c]: per-pixel sums over a chunk of samples (the four
+// waves take every fourth sample; four pixels x their samples = up to 16 independent 16-byte loads in flight), one LDS combine,
+// then one atomic per (channel, tap, pixel) and workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void c5_wgrad_const_kernel(const T* __restrict__ x, int ldx, float g0, float g1, float g2, float g3, int group_n,
+                                                             float* __restrict__ dw, int N, int Hi, int Wi, int per) {
+    constexpr int C = 512, PG = 4, NS = 4;
+    __shared__ float sm[4][PG][C];
+    const int Ho = Hi - 1, Wo = Wi - 1, P = Hi * Wi;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane * 8;
+    const int nb = blockIdx.x * per, ne = min(N, nb + per);
+    for (int p0 = 0; p0 < P; p0 += PG) {
+        float acc[PG][8];
+#pragma unroll
+        for (int i = 0; i < PG; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+        for (int n0 = nb + wave; n0 < ne; n0 += 4 * NS) {                   // NS samples x PG pixels: all loads first
+            uint4 w[NS][PG];
+            float gc[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int n = n0 + 4 * k;
+                const int g = n / group_n;
+                gc[k] = n < ne ? (g == 0 ? g0 : (g == 1 ? g1 : (g == 2 ? g2 : g3))) : 0.f;
+#pragma unroll
+                for (int i = 0; i < PG; ++i)
+                    w[k][i] = (n < ne && p0 + i < P) ? *reinterpret_cast<const uint4*>(x + ((size_t)n * P + p0 + i) * ldx + c) : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int i = 0; i < PG; ++i) {
+                    const unsigned wv[4] = {w[k][i].x, w[k][i].y, w[k][i].z, w[k][i].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[i][e] += gc[k] * Bits16<T>::dec(wv[e >> 1] >> (16 * (e & 1)));
+                }
+        }
+        if (p0) __syncthreads();                                           // (the previous pixel group's sums are consumed)
+#pragma unroll
+        for (int i = 0; i < PG; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm[wave][i][c + e] = acc[i][e];
+        __syncthreads();
+        for (int q = threadIdx.x; q < PG * C; q += 256) {                  // the four waves' partial sums -> sm[0]
+            float* r = &sm[0][0][0] + q;
+            r[0] = (r[0] + r[PG * C]) + (r[2 * PG * C] + r[3 * PG * C]);
+        }
+        __syncthreads();
+        // dw[ch][tap]: a channel's 16 taps are contiguous -- consecutive lanes add to consecutive floats (a wave touches 4 cache
+        // lines per atomic instruction).  A thread's tap is fixed (256 % 16 == 0): which pixels of the group reach an output
+        // through it is decided once.
+        const int ky = (threadIdx.x >> 2) & 3, kx = threadIdx.x & 3;
+        unsigned valid = 0;
+#pragma unroll
+        for (int i = 0; i < PG; ++i) {
+            const int p = p0 + i, iy = p / Wi, ix = p - iy * Wi;
+            if (p < P && (unsigned)(iy + 1 - ky) < (unsigned)Ho && (unsigned)(ix + 1 - kx) < (unsigned)Wo) valid |= 1u << i;
+        }
+        if (valid)
+            for (int e = threadIdx.x; e < 16 * C; e += 256) {
+                const int ch = e >> 4;
+                float tot = 0.f;
+#pragma unroll
+                for (int i = 0; i < PG; ++i)
+                    if ((valid >> i) & 1u) tot += sm[0][i][ch];
+                atomicAdd(dw + e, tot);
+            }
+    }
+}
+
 // fake group (pred, refined) and interpolated group (alpha-mix of the real and fake pairs, cgan/losses.py:203-204) of a
 // critic step in one pass over pred / gt / refined; alpha given per sample or drawn from the counter-based hash
 template <typename T>
@@ -817,6 +927,11 @@ int gcssl_prep_c5_weight(const float* w, float* wp, int C, void* stream) {
     return gcssl_launch_status();
 }
 
+// the constant-dout fast paths of the head conv's two gradients: 16-bit dtype, 512 channels, 16-byte rows (GCSSL_C5_CONST=0: A/B)
+static bool c5_const_ok(int dtype, const float* dout, int C, int ld, const void* ptr, bool f32_too) {
+    static const bool on = [] { const char* e = getenv("GCSSL_C5_CONST"); return !(e && e[0] == '0'); }();
+    return on && !dout && (f32_too || dtype != GCSSL_F32) && C == 512 && ld % 8 == 0 && (((uintptr_t)ptr) & 15) == 0;
+}
 int gcssl_conv4x4s1_c1_fwd(int dtype, const void* x, int ldx, const float* wp, float* out, float* group_mean, int groups,
                            int N, int Hi, int Wi, int C, void* stream) {
     if (!x || !wp || !out) return GCSSL_ENULL;
@@ -840,6 +955,12 @@ int gcssl_conv4x4s1_c1_dgrad(int dtype, const float* dout, float g0, float g1, f
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || lddx < C || (!dout && group_n <= 0)) return GCSSL_EBADSHAPE;
     const size_t n = (size_t)N * Hi * Wi * C;
+    if (c5_const_ok(dtype, dout, C, lddx, dx, true) && (((uintptr_t)wp) & 15) == 0) {
+        const int per = 8;                                                 // samples per workgroup: N / 8 workgroups of 256 threads
+        GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(c5_dgrad_const_kernel<T>, dim3((N + per - 1) / per), dim3(256), 0, (hipStream_t)stream,
+                                                   g0, g1, g2, g3, group_n, wp, (T*)dx, lddx, N, Hi, Wi, per));
+        return gcssl_launch_status();
+    }
     GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(c5_dgrad_kernel<T>, GRID1(n), dout, g0, g1, g2, g3, group_n, wp, (T*)dx, lddx, N, Hi, Wi, C));
     return gcssl_launch_status();
 }
@@ -849,6 +970,12 @@ int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dou
     if (!x || !dw) return GCSSL_ENULL;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (N <= 0 || Hi < 2 || Wi < 2 || C <= 0 || ldx < C || (!dout && group_n <= 0)) return GCSSL_EBADSHAPE;
+    if (c5_const_ok(dtype, dout, C, ldx, x, false)) {
+        static const int per = [] { const char* e = getenv("GCSSL_C5_PER"); return e ? atoi(e) : 16; }();   // samples per workgroup (16 / 32: 12.4 / 13.4 us at 1024 samples)
+        GCSSL_DISPATCH16(dtype, hipLaunchKernelGGL(c5_wgrad_const_kernel<T>, dim3((N + per - 1) / per), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)x, ldx, g0, g1, g2, g3, group_n, dw, N, Hi, Wi, per));
+        return gcssl_launch_status();
+    }
     static const int zcap = [] { const char* e = getenv("GCSSL_C5_ZS"); return e ? atoi(e) : 64; }();   // 8/16/32/64: 77.1/80.7/82.1/82.4k img/s
     int zs = N * zcap / 768; if (zs < 1) zs = 1; if (zs > zcap) zs = zcap;
     const int per = (N + zs - 1) / zs;

@@ -441,7 +441,7 @@ def test_act_bwd_and_dot(ops, dt, tol):
 
 
 @pytest.mark.parametrize("dt,tol", DTS)
-@pytest.mark.parametrize("N,H,C", [(6, 2, 512), (3, 4, 512), (3, 8, 512), (3, 4, 20)])    # C = 20: the scalar forward form
+@pytest.mark.parametrize("N,H,C", [(6, 2, 512), (3, 4, 512), (3, 8, 512), (3, 4, 20), (768, 2, 512)])    # C = 20: the scalar forward form; 768: several workgroups of the constant-seed forms
 def test_critic_head(ops, dt, tol, N, H, C):
     x = q(rnd(N, C, H, H, seed=30), dt)
     w = rnd(1, C, 4, 4, seed=31, scale=0.05)
