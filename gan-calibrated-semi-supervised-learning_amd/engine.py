@@ -237,6 +237,7 @@ class StepEngine:
         self.side_g = torch.cuda.Stream(device=dev) if self.overlap_g else None
         self.side_sn = torch.cuda.Stream(device=dev) if self.overlap_g >= 2 else None
         self.probe = None          # {label: {"events": [(start, stop)...], "flops": f}} when profiling is enabled
+        self.probe_repeats = 0
 
     # ------------------------------------------------------------------------------------------ side-stream branches
     def _on_side(self, fn, which: int = 0, level: int = 2):
@@ -266,9 +267,13 @@ class StepEngine:
             torch.cuda.current_stream().wait_event(ev)
 
     # ------------------------------------------------------------------------------------------ in-situ kernel timing
-    def enable_probe(self, on: bool = True):
-        """Bracket every MFMA conv launch with HIP events on the launch stream (eager mode only)."""
+    def enable_probe(self, on: bool = True, repeats: int = 0):
+        """Bracket every MFMA conv launch with HIP events on the launch stream (eager mode only).
+        repeats > 0: each launch is then issued `repeats` MORE times back to back inside a second event pair -- what the launch
+        costs inside a chain of launches (the graph replay's situation) rather than behind an idle gap and an event packet.
+        (Launches that accumulate into sums then over-count them: the engine's state after such a pass is scrap.)"""
         self.probe = {} if on else None
+        self.probe_repeats = int(repeats) if on else 0
 
     def _conv(self, label: str, flops: float, fn, *args, _bytes=None, **kw):
         """_bytes: (algorithmic, stored) bytes of the launch when its argument list does not show them (fused launches)"""
@@ -278,25 +283,38 @@ class StepEngine:
         e0.record()
         fn(*args, **kw)
         e1.record()
+        e2 = None
+        if self.probe_repeats:
+            e2 = torch.cuda.Event(enable_timing=True)
+            for _ in range(self.probe_repeats):
+                fn(*args, **kw)
+            e2.record()
         rec = self.probe.get(label)
         if rec is None:
             algo, stored = _bytes or _algorithmic_bytes(label, args, 4 if self.code == _lib.F32 else 2)
             rec = self.probe[label] = {"events": [], "flops": flops, "bytes": algo, "stored": stored,
                                        "kernel": ops.last_kernel()}      # the template expression the dispatcher launched
-        rec["events"].append((e0, e1))
+        rec["events"].append((e0, e1, e2))
 
     def probe_summary(self):
-        """-> {label: (n_launches, mean_ms, flops_per_launch, algorithmic_bytes_per_launch, stored_bytes_per_launch, kernel)}
-        (synchronises).  kernel: the kernel template expression of the label's launch (gcssl_last_kernel)."""
+        """-> {label: (n_launches, mean_ms, flops_per_launch, algorithmic_bytes_per_launch, stored_bytes_per_launch, kernel,
+        mean_ms_chained)} (synchronises).  kernel: the kernel template expression of the label's launch (gcssl_last_kernel);
+        mean_ms_chained: per launch inside the back-to-back repeats (enable_probe(repeats=...)), else None."""
         torch.cuda.synchronize()
-        out = {}
-        for k, rec in (self.probe or {}).items():
-            ts = sorted(a.elapsed_time(b) for a, b in rec["events"])
+
+        def robust(ts):
             # an eager launch whose host-side enqueue stalls (GC pause, first-use lazy init) shows up as tens of ms between
             # its two events: average the samples within 3x the median (all of them, when nothing stalled)
+            ts = sorted(ts)
             med = ts[len(ts) // 2] if ts else 0.0
             keep = [t for t in ts if t <= 3.0 * med] or ts
-            out[k] = (len(ts), sum(keep) / max(len(keep), 1), rec["flops"], rec["bytes"], rec["stored"], rec["kernel"])
+            return sum(keep) / max(len(keep), 1)
+        out = {}
+        for k, rec in (self.probe or {}).items():
+            ev = rec["events"]
+            rep = [b.elapsed_time(c) / self.probe_repeats for _, b, c in ev if c is not None]
+            out[k] = (len(ev), robust([a.elapsed_time(b) for a, b, _ in ev]), rec["flops"], rec["bytes"], rec["stored"], rec["kernel"],
+                      robust(rep) if rep else None)
         return out
 
     # ------------------------------------------------------------------------------------------ split-K slabs

@@ -323,15 +323,16 @@ def test_instance_norm_bwd_from_activation(ops, dt, tol, N, H, C):
 
 
 @pytest.mark.parametrize("dt,tol", DTS[1:])
-@pytest.mark.parametrize("N,with_sums", [(768, True), (256, False), (771, True)])
+@pytest.mark.parametrize("N,with_sums", [(768, True), (256, False), (771, True), (769, False), (513, False), (1536, True)])
 def test_conv_dgrad_act_bwd_fused(ops, dt, tol, N, with_sums):
     """gcssl_conv4x4s2_dgrad_act_bwd == gcssl_conv4x4s2_dgrad (fp32 dx) followed by gcssl_act_bwd: the critic's second layer's
     data gradient with the first layer's LeakyReLU backward (+ bias-gradient and spectral-norm sums) in the epilogue.
-    768 / 771 samples: the persistent form (771: a ragged last tile); 256: the plain tiled form (no sums)."""
+    768 / 771 / 769 / 513 / 1536 samples: the persistent form (771, 769, 513: a ragged last tile); 256: the plain tiled form
+    (no sums)."""
     Hi, Cin, Cout = 16, 64, 128
     code = ops.code(torch.empty(0, dtype=dt))
     group_n = (N + 2) // 3 if N % 3 else N // 3
-    if N == 771:
+    if N in (771, 769, 513):
         group_n = 257                                   # 257 * 64 rows per class: not a multiple of 128 -> no per-group scale / sums
     assert ops.conv_dgrad_act_bwd_ok(code, N, Hi, Cin, Cout, with_sums)
     dy = q(rnd(N, Cout, Hi // 2, Hi // 2, seed=110), dt)
@@ -340,7 +341,7 @@ def test_conv_dgrad_act_bwd_fused(ops, dt, tol, N, with_sums):
     bias = rnd(Cin, seed=113, scale=0.1).cuda()
     _, wt = packed_weights(ops, w, dt)
     dyd, ad = nhwc(dy, dt), nhwc(a, dt)
-    grouped = N != 771
+    grouped = N not in (771, 769, 513)
     gs = torch.tensor([1.5, 0.5, 2.0], device="cuda") if grouped else None
     nrep, stride = 4, 128
     # unfused pair
