@@ -1,5 +1,5 @@
 """GPU time of gcssl_conv4x4s2_dgrad_act_bwd at the critic's c2 shape (N x 16 x 16 x 64 <- N x 8 x 8 x 128), 40 launches per
-graph replay.  usage: python tools/actb_bench.py [N]"""
+graph replay.  usage: python tools/actb_bench.py [N] [eager launches instead of the graph, for rocprofv3 --pmc passes]"""
 import importlib, sys, torch
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -16,6 +16,11 @@ rep = torch.zeros(4, 128, device="cuda")
 def run(): ops.conv_dgrad_act_bwd(dy, wt, a, dz, 64, 128, gscale=gs, group_n=N // 3, bias=bias, dbias=rep[0, :64], cdot=rep[0, 64:67], nrep=4, rep_stride=128)
 for _ in range(3): run()
 torch.cuda.synchronize()
+if len(sys.argv) > 2:
+    for _ in range(int(sys.argv[2])): run()
+    torch.cuda.synchronize()
+    print(f"N={N}: {sys.argv[2]} eager launches  {ops.last_kernel()}")
+    sys.exit(0)
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
     for _ in range(40): run()
