@@ -1296,6 +1296,38 @@ class GraphedIteration:
         #   side:            [g_main ...................]                   join^
         # GCSSL_DP_BRANCH=0: the round-2 schedule (generator halves serial under the critic's all-reduces).
         self.dp_branch = eng.batch_g and os.environ.get("GCSSL_DP_BRANCH", "1") != "0"
+        # GCSSL_DP_PIPELINE (default on): the single-GPU two-stream schedule with the exchanges in it -- the generator's chain
+        # (backward, all-reduce of ITS gradient on a communicator of its own, update, the NEXT iteration's batched forward) runs
+        # whole on the second stream beside the critic's, so no generator launch is left on the critic's stream and the 25-MB
+        # exchange never queues in front of a critic exchange:
+        #   main: [d_pre0 d_main0] AR(D) [d_pre1] wait [updD d_main1] AR(D) .............. wait(D) [updD g_critic]
+        #   side: [g_main] AR'(G) ........................ wait(last d_pre, G) [updG  Gfwd i+1]          (AR' = second process group)
+        # The collectives of a group are issued in the same program order on every rank.
+        self.dp_pipeline = (self.dp_branch and os.environ.get("GCSSL_DP_PIPELINE", "1") != "0" and
+                            getattr(eng.allreduce, "group", "x") != "x" and torch.distributed.is_initialized())
+        if self.dp_pipeline:
+            c = eng.c
+            self.side = torch.cuda.Stream(device=eng.dev)
+            self.g_avg = type(eng.allreduce)(group=torch.distributed.new_group())    # (collective: every rank builds its engine here)
+            self._primed, self.pipelined = False, True
+            pool_main, pool = pool, None                                   # the generator's graphs replay beside the critic's: own pool
+            self.prologue = capture(lambda: eng.g_forward_all(pred, None))
+            eng._g_dirty = False
+            eng._in_g_branch = True                                        # (no forks inside a segment: every graph stays linear)
+            try:
+                self.g_a = capture(lambda: eng.g_main(pred, delta_true, pred_box, refine_fn, None))
+                pool_g, pool = pool, pool_main
+                self.first = capture(lambda: (eng.d_pre(pred, gt, refine_fn, 0, None, None), eng.d_main()))
+                self.pre, self.upd_main = [None], [None]
+                for k in range(1, c):
+                    self.pre.append(capture(lambda k=k: eng.d_pre(pred, gt, refine_fn, k, None, None)))
+                    self.upd_main.append(capture(lambda: (eng.d_update(gs), eng.d_main())))
+                self.upd_crit = capture(lambda: (eng.d_update(gs), eng.g_critic(pred)))
+                pool = pool_g
+                self.g_b = capture(lambda: (eng.g_update(gs), eng.g_forward_all(pred, None)))
+            finally:
+                eng._in_g_branch = False
+            return
         if self.dp_branch:
             self.side = torch.cuda.Stream(device=eng.dev, priority=int(os.environ.get("GCSSL_SIDE_PRIO", "0")))
             self.gfwd = capture(lambda: eng.g_forward_all(pred, None))
@@ -1355,6 +1387,39 @@ class GraphedIteration:
                 self._primed = True
             for g in self.graphs:
                 g.replay()
+            return
+        if getattr(self, "dp_pipeline", False):
+            main, side = torch.cuda.current_stream(), self.side
+            if not self._primed:
+                self.prologue.replay()                            # the first iteration's batched generator forward
+                self._primed = True
+            ev0 = torch.cuda.Event(); ev0.record(main)            # (the previous replay ended with main behind its g_b)
+            side.wait_event(ev0)
+            with torch.cuda.stream(side):
+                self.g_a.replay()
+                ev_ga = torch.cuda.Event(); ev_ga.record(side)
+                hg = self.g_avg.start(eng.G.g)                    # the generator's exchange: its own communicator, behind g_a
+            self.first.replay()
+            ev_pre = torch.cuda.Event()
+            if eng.c == 1:
+                ev_pre.record(main)
+            h = eng.allreduce_start(eng.D.g)
+            for k in range(1, eng.c):
+                self.pre[k].replay()
+                if k == eng.c - 1:
+                    ev_pre.record(main)                           # the iteration's last d_pre (its reads of the deltas and of G's step count)
+                eng.allreduce_wait(h, eng.D.g)
+                self.upd_main[k].replay()
+                h = eng.allreduce_start(eng.D.g)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_pre)
+                self.g_avg.finish(hg, eng.G.g, scale=False)       # (1 / world is baked into the captured update)
+                self.g_b.replay()
+                ev_gb = torch.cuda.Event(); ev_gb.record(side)
+            main.wait_event(ev_ga)                                # the re-crop the value-only forward packs
+            eng.allreduce_wait(h, eng.D.g)
+            self.upd_crit.replay()
+            main.wait_event(ev_gb)                                # the caller's stream sees the whole iteration
             return
         if self.dp_branch:
             main = torch.cuda.current_stream()
