@@ -381,9 +381,11 @@ def _bench_like(synth, dtype, **kw):
     return engine, eng, call
 
 
+@pytest.mark.parametrize("form", ["two_stream", "one_graph", "one_graph_unpipelined"])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_graph_replay_matches_eager_at_bench_config(synth, dtype):
-    """GraphedIteration (single-GPU, one graph per iteration: what bench.py replays) == run_iteration launched eagerly, on two
+def test_graph_replay_matches_eager_at_bench_config(synth, dtype, form, monkeypatch):
+    """GraphedIteration (single-GPU: four linear graphs on two streams -- what bench.py replays -- or the fallback forms: one
+    graph with the generator's chain as a branch, with / without the pipelined forward) == run_iteration launched eagerly, on two
     FRESH default engines (keep_clipped_grads=True) with the same seed.  Alpha and the dropout masks are drawn on the device
     keyed by (seed, phase, optimiser step count), so both sides draw identical values; what remains is the order of float atomics.
 
@@ -392,10 +394,13 @@ def test_graph_replay_matches_eager_at_bench_config(synth, dtype):
     clipped gradients the updates leave in the buckets must agree after every replay.  This is also the check of ADVICE r1:
     the captured graph must contain the gradient zero fills although a fresh engine's buckets are zero at capture time --
     replays used to accumulate onto the previous iteration's clipped gradients (a 2x error at the second replay)."""
+    monkeypatch.setenv("GCSSL_TWO_STREAM", "1" if form == "two_stream" else "0")
+    monkeypatch.setenv("GCSSL_PIPELINE", "0" if form == "one_graph_unpipelined" else "1")
     engine, eng_e, call = _bench_like(synth, dtype, lr=0.0)
     _, eng_e2, call_e2 = _bench_like(synth, dtype, lr=0.0)      # a second eager run: the noise floor of the comparison
     _, eng_g, call_g = _bench_like(synth, dtype, lr=0.0)
     gi = engine.GraphedIteration(eng_g, *call_g)                # captured on the fresh engine, nothing executed yet
+    assert getattr(gi, "two_stream", False) == (form == "two_stream") and gi.pipelined == (form != "one_graph_unpipelined")
     assert float(eng_g.G.state[0]) == 0.0 and float(eng_g.D.state[0]) == 0.0
     for it in range(3):
         eng_e.run_iteration(*call)
