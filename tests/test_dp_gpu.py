@@ -148,6 +148,7 @@ def _run_rccl_one_rank(rank, world, port):
     one, dp = mk(None), mk(avg)
     g_one, g_dp = engine.GraphedIteration(one, *call), engine.GraphedIteration(dp, *call)
     assert g_one.fused_update and not g_dp.fused_update                   # one graph per iteration vs the DP segments
+    assert g_dp.dp_pipeline == (os.environ.get("GCSSL_DP_PIPELINE", "1") != "0")
     for _ in range(2):
         g_one.replay()
         g_dp.replay()
@@ -162,6 +163,9 @@ def _run_rccl_one_rank(rank, world, port):
     torch.distributed.destroy_process_group()
 
 
-def test_rccl_backend_single_rank_graph_segments():
-    """the nccl (RCCL) path under -m gpu -- a fresh child process, one rank."""
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_rccl_backend_single_rank_graph_segments(pipeline, monkeypatch):
+    """the nccl (RCCL) path under -m gpu -- a fresh child process, one rank.  pipeline 1: the generator's
+    chain with its own communicator on the second stream (the default); 0: the first round-3 schedule."""
+    monkeypatch.setenv("GCSSL_DP_PIPELINE", pipeline)          # (the spawned child inherits the environment)
     mp.spawn(_run_rccl_one_rank, args=(1, _free_port()), nprocs=1, join=True)
