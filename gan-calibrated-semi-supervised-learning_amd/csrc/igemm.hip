@@ -2563,8 +2563,19 @@ __global__ __launch_bounds__(256) void conv_dgrad_c8_kernel(ConvParams p, int nt
 // (A/B knob: GCSSL_C8_DGRAD=0 sends the shape back to the generic tiles)
 bool c8_dgrad_on() { static const bool v = [] { const char* e = getenv("GCSSL_C8_DGRAD"); return !(e && e[0] == '0'); }(); return v; }
 
+int dgrad_img_on(const ConvParams& p);                                   // (dgrad_img_kernel, below)
+template <typename O, int OUT> void launch_dgrad_img(const ConvParams& p, hipStream_t st);
+
 template <typename T>
 int dispatch_dgrad(ConvParams p, hipStream_t st) {
+    if constexpr (Is16<T>::v) {
+        // the 64 <- 128 layer on 16 x 16 maps, fp32 dx, >= 3 samples per CU: dy maps resident in LDS (dgrad_img_kernel)
+        if (p.out_f32 && !p.split_stride && p.ldy % 4 == 0 && aligned16(p.y) && p.y_bytes && !forced_tile() && dgrad_img_on(p)) {
+            if (p.plan_out) { *p.plan_out = 1; return GCSSL_OK; }
+            launch_dgrad_img<typename Op16<T>::type, 1>(p, st);
+            return gcssl_launch_status();
+        }
+    }
     if constexpr (Is16<T>::v) {
         const int Wo = p.Wi / 2;
         if (p.Cin == 8 && p.Cout == 64 && (Wo == 16 || Wo == 32) && (p.Hi / 2) % (32 / Wo) == 0 && c8_dgrad_on() &&
@@ -2629,11 +2640,238 @@ int dispatch_dgrad(ConvParams p, hipStream_t st) {
     return launch_dgrad<T, 64, 64>(p, st);      // Cin < 64 (first layer, Cin padded to 8): masked columns
 }
 
+// ------------------------------------------------------------------------------------------
+// Data gradient of the 64 -> 128 layer on 16 x 16 inputs (D.c2 of the 32 x 32 configurations; dy maps of 8 x 8 x 128) with the
+// dy maps RESIDENT in LDS, for batches of at least three samples per CU.  A workgroup owns three whole samples (768 samples =
+// 256 workgroups = one round of the chip), 12 waves:
+//   * their dy maps go to LDS ONCE, as a zero-haloed 10 x 10 image per sample (256-byte pixels, the sixteen 16-byte chunks
+//     XOR-swizzled by the pixel index); an MFMA A fragment of any (parity class, tap) is one ds_read_b128 at a lane-constant
+//     pixel + a step-uniform offset -- the im2col happens in the LDS address, as in conv_dgrad_c8_kernel.  (The ring forms
+//     refill a 128-row A tile for every (class, tap): each dy pixel crosses the CU's LDS-DMA path 16 times.)
+//   * only the weights stream: 16 K steps (4 classes x 4 taps, all 128 dy channels: K = 128) of one 64 ci x 128 co tile (16 KB)
+//     through a 3-slot LDS-DMA ring issued by waves 0-3 ALONE;
+//   * a class (192 rows x 64 ci, fp32) leaves sample by sample through a 17-KB LDS tile in 8-channel chunks, and all of that
+//     memory traffic belongs to waves 4-11: vmcnt retires in order, so a wave that waits for its next weight tile also waits
+//     for every store it issued before -- waves that issue no DMA never wait for a store, and the 50 MB of the epilogue
+//     (stored activation in, dzs out) flow under the next class's MFMAs.  OUT 0 = gcssl_act_bwd's elementwise part and sums
+//     (dzs = lrelu'(a) dx gscale in the compute dtype; the activation chunks are fetched at the head of the class), OUT 1 =
+//     fp32 dx * gscale.
+// ------------------------------------------------------------------------------------------
+template <typename T, int OUT>
+__global__ __launch_bounds__(768) void dgrad_img_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef typename Frag16<T>::type FragT;
+    constexpr int SPW = 3, NT = 768, NW = 12, NE = 512;                   // NE: threads of the epilogue waves (4-11)
+    constexpr int IMG = SPW * 100 * 256, SLOT = 16384, RS = 64 * 4 + 16;  // image bytes; ring slot; stage row stride (64 columns)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IMG + 3 * SLOT + 64 * RS];
+    unsigned char* ring = lds + IMG;
+    unsigned char* stage = ring + 3 * SLOT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * SPW;
+    const bool dma = wave < 4, epi = !dma;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+    // ---- the dy images: LDS slot g (16 bytes) = pixel g >> 4, physical chunk g & 15 <- logical chunk (g & 15) ^ (pixel & 15);
+    // halo pixels and samples past N read OOB = 0.  75 wave-wide DMA instructions over the 12 waves.
+    for (int wi = wave; wi < 25 * SPW; wi += NW) {
+        const int g = wi * 64 + lane, pi = g >> 4, lc = (g & 15) ^ (pi & 15);
+        const int s = pi / 100, rem = pi - s * 100, iy = rem / 10 - 1, ix = rem - (rem / 10) * 10 - 1;
+        const bool ok = (unsigned)iy < 8u && (unsigned)ix < 8u && n0 + s < p.N;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_p)(lds + wi * 1024), 16,
+            ok ? (unsigned)(((((n0 + s) * 8 + iy) * 8 + ix) * p.ldx + lc * 8) * 2) : OOB, 0, 0, 0);
+    }
+    // ---- weight ring (waves 0-3): step q = (class, tap pair); 1024 chunks per tile: chunk c -> channel half c >> 9, ci row
+    // (c >> 3) & 63, 16-byte piece c & 7 (swizzled); thread tid < 256 fetches chunks tid, tid + 256, tid + 512, tid + 768
+    int plain_slot = SLOT;                                               // (plain int: see conv_dma_kernel's note on the host pass)
+    auto issue = [&](int q, int slot) {
+        const int cls = q >> 2, t4 = q & 3, py = cls >> 1, px = cls & 1;
+        const int tap = (1 - py + 2 * (t4 >> 1)) * 4 + (1 - px + 2 * (t4 & 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = (c >> 3) & 63, lcw = (c & 7) ^ ((row >> 1) & 7);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_p)(ring + slot * plain_slot + (wave + 4 * i) * 1024), 16,
+                (unsigned)(((row * 16 + tap) * 128 + (c >> 9) * 64 + lcw * 8) * 2), 0, 0, 0);
+        }
+    };
+    if (dma) { issue(0, 0); issue(1, 1); }
+    // ---- per-lane constants of the MFMA role (all 12 waves: wave = 32 rows x 32 ci of the 192 x 64 class tile)
+    const int wr_ = wave >> 1, wc = wave & 1;
+    const int arow = wr_ * 32 + (lane & 31), as = arow >> 6, ajy = (arow >> 3) & 7, ajx = arow & 7, h = lane >> 5;
+    const int pix0 = as * 100 + (ajy + 1) * 10 + (ajx + 1);
+    const int brow = wc * 32 + (lane & 31);
+    const unsigned char* bbase = ring + brow * 128;
+    const int bsw = (brow >> 1) & 7;
+    // ---- the epilogue role (waves 4-11): thread te -> row te >> 3 of a sample's 64 x 64 block, channels 8 ech .. 8 ech + 7
+    const int te = tid - 256, erow = (te >> 3) & 63, ech = te & 7;
+    const __amdgpu_buffer_rsrc_t ar = make_rsrc(p.ab_a, OUT == 0 ? p.ab_bytes : 0u), yr = make_rsrc(p.y, p.y_bytes);
+    float bias8[8], gsv[SPW];
+    int grpv[SPW];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = (OUT == 0 && epi && p.ab_bias) ? p.ab_bias[ech * 8 + e] : 0.f;
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+        const int n = n0 + s;
+        grpv[s] = (p.gscale || (OUT == 0 && p.ab_cdot)) ? (int)(((float)n + 0.5f) * p.inv_group_n) : 0;
+        gsv[s] = (p.gscale && n < p.N) ? p.gscale[grpv[s]] : 1.f;
+    }
+    float sb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sdg[4] = {0.f, 0.f, 0.f, 0.f};
+    int nsat = 0;
+    uint4 areg[SPW];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int slot = 0;
+    for (int q = 0; q < 16; ++q) {
+        const int cls = q >> 2, t4 = q & 3, py = cls >> 1, px = cls & 1;
+        // DMA waves: tile q has landed once only tile q + 1's four DMA instructions can still be outstanding (they issue no
+        // other vector memory operation after the prologue).  Epilogue waves: their part of the image, once.
+        if (dma) {
+            if (q == 15) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else if (q == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int pi = pix0 + (py - (t4 >> 1)) * 10 + (px - (t4 & 1));
+        const unsigned char* abase = lds + pi * 256;
+        const int asw = pi & 15;
+        const unsigned char* bt = bbase + slot * SLOT;
+        FragT a[8], b[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {                                 // kk >> 2 = channel half
+            a[kk] = __builtin_bit_cast(FragT, *reinterpret_cast<const uint4*>(abase + (((2 * kk + h) ^ asw) << 4)));
+            b[kk] = __builtin_bit_cast(FragT, *reinterpret_cast<const uint4*>(bt + (kk >> 2) * 8192 + (((2 * (kk & 3) + h) ^ bsw) << 4)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (OUT == 0 && epi && t4 == 0) {                                // this class's activation chunks: in flight under its 4 steps
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                const int n = n0 + s;
+                const unsigned pix = (unsigned)((n * 16 + 2 * (erow >> 3) + py) * 16 + 2 * (erow & 7) + px);
+                areg[s] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ar,
+                    n < p.N ? (pix * (unsigned)p.ab_lda + ech * 8u) * 2u : OOB, 0, 0));
+            }
+        }
+        if (dma && q + 2 < 16) issue(q + 2, slot == 0 ? 2 : slot - 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) acc = mfma(a[kk], b[kk], acc);
+        slot = slot == 2 ? 0 : slot + 1;
+        if (t4 != 3) continue;
+        // ---- the class is complete: sample by sample, fp32 block -> LDS -> 8-channel chunks (epilogue waves)
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            if (s) __builtin_amdgcn_s_barrier();                         // the previous sample's chunk reads are done
+            if ((wr_ >> 1) == s) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<float*>(stage + ((wr_ & 1) * 32 + crow(r, lane)) * RS + (wc * 32 + (lane & 31)) * 4) = acc[r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (epi) {
+                const int n = n0 + s;
+                const bool live = n < p.N;
+                const unsigned pix = (unsigned)((n * 16 + 2 * (erow >> 3) + py) * 16 + 2 * (erow & 7) + px);
+                const float gs = gsv[s];
+                const float4 v0 = *reinterpret_cast<const float4*>(stage + erow * RS + ech * 32);
+                const float4 v1 = *reinterpret_cast<const float4*>(stage + erow * RS + ech * 32 + 16);
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if constexpr (OUT == 0) {
+                    const unsigned awv[4] = {areg[s].x, areg[s].y, areg[s].z, areg[s].w};
+                    float o[8], sd = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float av = Bits16<T>::dec(awv[e >> 1] >> (16 * (e & 1)));
+                        const float dz = av > 0.f ? v[e] : 0.2f * v[e];
+                        const float zv = av > 0.f ? av : 5.0f * av;      // invert LeakyReLU(0.2)
+                        o[e] = dz * gs;
+                        sb[e] += dz; sd += o[e] * (zv - bias8[e]);
+                    }
+                    const int grp = grpv[s];
+                    if (grp == 0) sdg[0] += sd; else if (grp == 1) sdg[1] += sd; else if (grp == 2) sdg[2] += sd; else sdg[3] += sd;
+                    nsat += sat_hits<T>(o);
+                    u32x4 w; w[0] = pack2<T>(o[0], o[1]); w[1] = pack2<T>(o[2], o[3]); w[2] = pack2<T>(o[4], o[5]); w[3] = pack2<T>(o[6], o[7]);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, yr, live ? (pix * (unsigned)p.ldy + ech * 8u) * 2u : OOB, 0, 0);
+                } else {
+                    const unsigned off = live ? (pix * (unsigned)p.ldy + ech * 8u) * 4u : OOB;
+                    u32x4 w0, w1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { w0[e] = __builtin_bit_cast(unsigned, v[e] * gs); w1[e] = __builtin_bit_cast(unsigned, v[4 + e] * gs); }
+                    __builtin_amdgcn_raw_buffer_store_b128(w0, yr, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(w1, yr, off == OOB ? OOB : off + 16u, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // (the next class's stage writes are 4 barriers away)
+    }
+    if constexpr (OUT == 0) {
+        if (epi) sat_commit(p.ab_sat, nsat);
+        if (p.ab_dbias || p.ab_cdot) {
+            // the workgroup's sums -> one replica of the striped bias-gradient / spectral-norm sums (norm.hip replica_offset);
+            // scratch: the idle ring ([NE][8] column sums, [8][4] group sums, [8][64] second-level sums: 18.6 KB of 48)
+            float* red = reinterpret_cast<float*>(ring);
+            float* redg = red + NE * 8;
+            float* red2 = redg + 8 * 4;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                   // every wave is done with the ring and the stage
+            if (epi) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[te * 8 + e] = sb[e];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float t = wave_sum(sdg[g]);
+                    if (lane == 0) redg[(wave - 4) * 4 + g] = t;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (epi) {                     // channel ch = te & 63 = 8 ech + e: its terms sit with the 64 threads te' = ech + 8 k; 8 threads share them
+                const int ch = te & 63, part = te >> 6, ce = ch >> 3, e = ch & 7;
+                float t = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t += red[(ce + 8 * (part * 8 + j)) * 8 + e];
+                red2[part * 64 + ch] = t;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int rep = p.ab_nrep > 1 ? (int)(blockIdx.x % (unsigned)p.ab_nrep) * p.ab_rep_stride : 0;
+            if (p.ab_dbias && tid < 64) {
+                float u = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) u += red2[w * 64 + tid];
+                atomicAdd(p.ab_dbias + rep + tid, u);
+            }
+            if (p.ab_cdot && tid >= 64 && tid < 68) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) t += redg[w * 4 + (tid - 64)];
+                if (t != 0.f) atomicAdd(p.ab_cdot + rep + (tid - 64), t);
+            }
+        }
+    }
+#endif
+}
+// shapes the image-resident form serves (GCSSL_DGRAD_IMG=0: A/B): three samples per workgroup, from one round of the chip up
+// (fewer samples: a grid of a third of the CUs loses to the ring forms' 256 tiles)
+int dgrad_img_on(const ConvParams& p) {
+    static const bool on = [] { const char* e = getenv("GCSSL_DGRAD_IMG"); return !(e && e[0] == '0'); }();
+    return on && use_dma() && p.Cin == 64 && p.Cout == 128 && p.Hi == 16 && p.Wi == 16 && p.ldx % 8 == 0 && p.N >= 3 * cu_count();
+}
+template <typename O, int OUT>
+void launch_dgrad_img(const ConvParams& p0, hipStream_t st) {
+    ConvParams p = p0;
+    GCSSL_LAUNCH((dgrad_img_kernel<O, OUT>), dim3((p.N + 2) / 3), dim3(768), 0, st, p);
+}
+
 // ---- dgrad + activation backward of the norm-less layer in front (ACTB forms).  0 = not served, 1 = persistent form (with the
 // striped bias / spectral-norm sums), 2 = plain tiled form (elementwise part only).
 int actb_form(const ConvParams& p, bool need_sums) {
     static const int on = [] { const char* e = getenv("GCSSL_ACTB"); return e ? atoi(e) : 1; }();
     if (!on || !use_dma() || dma_waves() != 8 || p.Cin != 64 || p.Cout < 64 || p.M < 128) return 0;
+    if (dgrad_img_on(p) && p.ab_lda % 8 == 0 && p.ldy % 8 == 0) return 3;     // (_ok probes carry ab_lda = ldy = 0)
     const long total = 4L * ((p.M + 127) / 128);
     const long slots = 2L * cu_count();
     if (persist_mode() && p.y_bytes && total > slots + slots / 4) return 1;
@@ -2651,6 +2889,8 @@ int dispatch_dgrad_actb(ConvParams p, hipStream_t st) {
             GCSSL_LAUNCH((conv_dma_persist_kernel<O, 128, 64, 1, 4, 2, false, false, true>), dim3(2 * cu_count()), dim3(512), 0, st, p, tm, 1, 4 * tm);
         } else if (form == 2) {
             GCSSL_LAUNCH((conv_dma_kernel<O, 128, 64, 1, 4, 2, false, 0, 3, true, false, true>), dim3(tm, 1, 4), dim3(512), 0, st, p);
+        } else if (form == 3) {
+            launch_dgrad_img<O, 0>(p, st);
         } else {
             return GCSSL_EBADSHAPE;
         }
