@@ -10,7 +10,7 @@ out_dir, dt = sys.argv[1], sys.argv[2]
 out_name = sys.argv[3] if len(sys.argv) > 3 else "round2_pmc_dominant.json"
 script = sys.argv[4] if len(sys.argv) > 4 else "tools/pmc_round2.sh"
 CASES = {"D.c2.fwd[n=768]": "conv_dma", "D.c3.fwd[n=768]": "conv_dma", "D.c4.fwd[n=768]": "conv_dma", "D.c2.wgrad": "conv_wgrad",
-         "D.c3.wgrad": "conv_wgrad", "D.c4.wgrad": "conv_wgrad", "D.c2.dgrad": "conv_dma", "D.c3.dgrad": "conv_dma", "D.c4.dgrad": "conv_dma", "D.c1.fwd[n=768]": "conv_",
+         "D.c3.wgrad": "conv_wgrad", "D.c4.wgrad": "conv_wgrad", "D.c2.dgrad": "dgrad_img", "D.c3.dgrad": "conv_dma", "D.c4.dgrad": "conv_dma", "D.c1.fwd[n=768]": "conv_",
          "D.c1.gp_dgrad": "conv_", "G.up4.fwd[n=768]": "convt_in_relu"}
 labels = {}
 for tag, flt in CASES.items():
