@@ -2661,14 +2661,15 @@ template <typename T, int OUT>
 __global__ __launch_bounds__(768) void dgrad_img_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef typename Frag16<T>::type FragT;
-    constexpr int SPW = 3, NT = 768, NW = 12, NE = 512;                   // NE: threads of the epilogue waves (4-11)
+    constexpr int SPW = 3, NW = 12, NCH = 2 * SPW;                        // NCH: chunks per epilogue thread and class
     constexpr int IMG = SPW * 100 * 256, SLOT = 16384, RS = 64 * 4 + 16;  // image bytes; ring slot; stage row stride (64 columns)
     __shared__ __attribute__((aligned(16))) unsigned char lds[IMG + 3 * SLOT + 64 * RS];
     unsigned char* ring = lds + IMG;
     unsigned char* stage = ring + 3 * SLOT;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = blockIdx.x * SPW;
-    const bool dma = wave < 4, epi = !dma;
+    // roles: waves 0-5 run the MFMAs (one sample's 64 rows x 32 ci each), 6-7 issue the weight DMA, 8-11 own the epilogue
+    const bool mm = wave < 6, dma = wave == 6 || wave == 7, epi = wave >= 8;
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
     // ---- the dy images: LDS slot g (16 bytes) = pixel g >> 4, physical chunk g & 15 <- logical chunk (g & 15) ^ (pixel & 15);
     // halo pixels and samples past N read OOB = 0.  75 wave-wide DMA instructions over the 12 waves.
@@ -2679,29 +2680,36 @@ __global__ __launch_bounds__(768) void dgrad_img_kernel(ConvParams p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_p)(lds + wi * 1024), 16,
             ok ? (unsigned)(((((n0 + s) * 8 + iy) * 8 + ix) * p.ldx + lc * 8) * 2) : OOB, 0, 0, 0);
     }
-    // ---- weight ring (waves 0-3): step q = (class, tap pair); 1024 chunks per tile: chunk c -> channel half c >> 9, ci row
-    // (c >> 3) & 63, 16-byte piece c & 7 (swizzled); thread tid < 256 fetches chunks tid, tid + 256, tid + 512, tid + 768
+    // ---- weight ring (waves 6-7): step q = (class, tap pair); 1024 chunks per tile: chunk c -> channel half c >> 9, ci row
+    // (c >> 3) & 63, 16-byte piece c & 7 (swizzled); DMA thread td fetches chunks td + 128 i, i < 8
     int plain_slot = SLOT;                                               // (plain int: see conv_dma_kernel's note on the host pass)
+    const int td = tid - 384;
     auto issue = [&](int q, int slot) {
         const int cls = q >> 2, t4 = q & 3, py = cls >> 1, px = cls & 1;
         const int tap = (1 - py + 2 * (t4 >> 1)) * 4 + (1 - px + 2 * (t4 & 1));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, row = (c >> 3) & 63, lcw = (c & 7) ^ ((row >> 1) & 7);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_p)(ring + slot * plain_slot + (wave + 4 * i) * 1024), 16,
+        for (int i = 0; i < 8; ++i) {
+            const int c = td + 128 * i, row = (c >> 3) & 63, lcw = (c & 7) ^ ((row >> 1) & 7);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_p)(ring + slot * plain_slot + ((wave - 6) + 2 * i) * 1024), 16,
                 (unsigned)(((row * 16 + tap) * 128 + (c >> 9) * 64 + lcw * 8) * 2), 0, 0, 0);
         }
     };
     if (dma) { issue(0, 0); issue(1, 1); }
-    // ---- per-lane constants of the MFMA role (all 12 waves: wave = 32 rows x 32 ci of the 192 x 64 class tile)
-    const int wr_ = wave >> 1, wc = wave & 1;
-    const int arow = wr_ * 32 + (lane & 31), as = arow >> 6, ajy = (arow >> 3) & 7, ajx = arow & 7, h = lane >> 5;
-    const int pix0 = as * 100 + (ajy + 1) * 10 + (ajx + 1);
+    // ---- MFMA role: wave = (sample rb, ci half wc); lane -> rows 32 i + (lane & 31) of the sample's class block, i < 2
+    const int rb = wave >> 1, wc = wave & 1, h = lane >> 5;
+    int pix0[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) pix0[i] = rb * 100 + (4 * i + ((lane & 31) >> 3) + 1) * 10 + (lane & 7) + 1;
     const int brow = wc * 32 + (lane & 31);
     const unsigned char* bbase = ring + brow * 128;
     const int bsw = (brow >> 1) & 7;
-    // ---- the epilogue role (waves 4-11): thread te -> row te >> 3 of a sample's 64 x 64 block, channels 8 ech .. 8 ech + 7
-    const int te = tid - 256, erow = (te >> 3) & 63, ech = te & 7;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // ---- epilogue role: thread te -> chunks (sample s, row (te >> 3) + 32 j) x channels 8 ech .. 8 ech + 7, s < 3, j < 2
+    const int te = tid - 512, erow0 = (te >> 3) & 31, ech = te & 7;
     const __amdgpu_buffer_rsrc_t ar = make_rsrc(p.ab_a, OUT == 0 ? p.ab_bytes : 0u), yr = make_rsrc(p.y, p.y_bytes);
     float bias8[8], gsv[SPW];
     int grpv[SPW];
@@ -2710,111 +2718,161 @@ __global__ __launch_bounds__(768) void dgrad_img_kernel(ConvParams p) {
 #pragma unroll
     for (int s = 0; s < SPW; ++s) {
         const int n = n0 + s;
-        grpv[s] = (p.gscale || (OUT == 0 && p.ab_cdot)) ? (int)(((float)n + 0.5f) * p.inv_group_n) : 0;
-        gsv[s] = (p.gscale && n < p.N) ? p.gscale[grpv[s]] : 1.f;
+        grpv[s] = (epi && (p.gscale || (OUT == 0 && p.ab_cdot))) ? (int)(((float)n + 0.5f) * p.inv_group_n) : 0;
+        gsv[s] = (epi && p.gscale && n < p.N) ? p.gscale[grpv[s]] : 1.f;
     }
     float sb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sdg[4] = {0.f, 0.f, 0.f, 0.f};
     int nsat = 0;
-    uint4 areg[SPW];
-    f32x16 acc;
+    uint4 areg[NCH];                                                     // the finished class's activation chunks (fetched at its end)
+    float vreg[NCH][8];                                                  // ... and its values of this thread's six chunks
+    int pcls = -1;                                                       // class whose chunks still have to leave
+    // one chunk (slot k = 2 s + j of class c: 8 channels of one output pixel) from registers to memory
+    auto apply = [&](int c, int k) __attribute__((always_inline)) {      // (inlined with a constant k everywhere: the register arrays must
+        const int s = k >> 1, j = k & 1;                                 //  not be indexed by a run-time value, they would go to scratch)
+        const int n = n0 + s, py = c >> 1, px = c & 1, erow = erow0 + 32 * j;
+        const bool live = n < p.N;
+        const unsigned pix = (unsigned)((n * 16 + 2 * (erow >> 3) + py) * 16 + 2 * (erow & 7) + px);
+        const float gs = gsv[s];
+        if constexpr (OUT == 0) {
+            const unsigned awv[4] = {areg[k].x, areg[k].y, areg[k].z, areg[k].w};
+            float o[8], sd = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    int slot = 0;
-    for (int q = 0; q < 16; ++q) {
-        const int cls = q >> 2, t4 = q & 3, py = cls >> 1, px = cls & 1;
-        // DMA waves: tile q has landed once only tile q + 1's four DMA instructions can still be outstanding (they issue no
-        // other vector memory operation after the prologue).  Epilogue waves: their part of the image, once.
-        if (dma) {
-            if (q == 15) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else if (q == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const int pi = pix0 + (py - (t4 >> 1)) * 10 + (px - (t4 & 1));
-        const unsigned char* abase = lds + pi * 256;
-        const int asw = pi & 15;
-        const unsigned char* bt = bbase + slot * SLOT;
-        FragT a[8], b[8];
+            for (int e = 0; e < 8; ++e) {
+                const float av = Bits16<T>::dec(awv[e >> 1] >> (16 * (e & 1)));
+                const float dz = av > 0.f ? vreg[k][e] : 0.2f * vreg[k][e];
+                const float zv = av > 0.f ? av : 5.0f * av;              // invert LeakyReLU(0.2)
+                o[e] = dz * gs;
+                sb[e] += dz; sd += o[e] * (zv - bias8[e]);
+            }
+            const int grp = grpv[s];
+            if (grp == 0) sdg[0] += sd; else if (grp == 1) sdg[1] += sd; else if (grp == 2) sdg[2] += sd; else sdg[3] += sd;
+            nsat += sat_hits<T>(o);
+            u32x4 w; w[0] = pack2<T>(o[0], o[1]); w[1] = pack2<T>(o[2], o[3]); w[2] = pack2<T>(o[4], o[5]); w[3] = pack2<T>(o[6], o[7]);
+            __builtin_amdgcn_raw_buffer_store_b128(w, yr, live ? (pix * (unsigned)p.ldy + ech * 8u) * 2u : OOB, 0, 0);
+        } else {
+            const unsigned off = live ? (pix * (unsigned)p.ldy + ech * 8u) * 4u : OOB;
+            u32x4 w0, w1;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {                                 // kk >> 2 = channel half
-            a[kk] = __builtin_bit_cast(FragT, *reinterpret_cast<const uint4*>(abase + (((2 * kk + h) ^ asw) << 4)));
-            b[kk] = __builtin_bit_cast(FragT, *reinterpret_cast<const uint4*>(bt + (kk >> 2) * 8192 + (((2 * (kk & 3) + h) ^ bsw) << 4)));
+            for (int e = 0; e < 4; ++e) { w0[e] = __builtin_bit_cast(unsigned, vreg[k][e] * gs); w1[e] = __builtin_bit_cast(unsigned, vreg[k][4 + e] * gs); }
+            __builtin_amdgcn_raw_buffer_store_b128(w0, yr, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w1, yr, off == OOB ? OOB : off + 16u, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (OUT == 0 && epi && t4 == 0) {                                // this class's activation chunks: in flight under its 4 steps
+    };
+    // ---- one loop per role (the register sets of the roles are then allocated independently: acc + fragments for the MFMA
+    // waves, the six staged chunks + their activation chunks for the epilogue waves); every role executes the same barrier
+    // sequence: one per K step, and five around the three sample blocks when a class completes.
+    if (mm) {
+        int slot = 0;
+        for (int q = 0; q < 16; ++q) {
+            const int cls = q >> 2, t4 = q & 3, py = cls >> 1, px = cls & 1;
+            if (q == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the image
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const int doff = (py - (t4 >> 1)) * 10 + (px - (t4 & 1));
+            const unsigned char* bt = bbase + slot * SLOT;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {                             // channel halves of the K = 128 step: 12 fragments in flight
+                FragT a[2][4], b[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    b[kk] = __builtin_bit_cast(FragT, *reinterpret_cast<const uint4*>(bt + hf * 8192 + (((2 * kk + h) ^ bsw) << 4)));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int pi = pix0[i] + doff;
+                        a[i][kk] = __builtin_bit_cast(FragT, *reinterpret_cast<const uint4*>(lds + pi * 256 + (((8 * hf + 2 * kk + h) ^ (pi & 15)) << 4)));
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i] = mfma(a[i][kk], b[kk], acc[i]);
+            }
+            slot = slot == 2 ? 0 : slot + 1;
+            if (t4 != 3) continue;
+            // the class is complete: this wave's sample block goes to the stage in its turn
 #pragma unroll
             for (int s = 0; s < SPW; ++s) {
-                const int n = n0 + s;
-                const unsigned pix = (unsigned)((n * 16 + 2 * (erow >> 3) + py) * 16 + 2 * (erow & 7) + px);
-                areg[s] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ar,
-                    n < p.N ? (pix * (unsigned)p.ab_lda + ech * 8u) * 2u : OOB, 0, 0));
+                if (s) __builtin_amdgcn_s_barrier();                     // the previous sample's block has been read
+                if (rb == s) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            *reinterpret_cast<float*>(stage + (32 * i + crow(r, lane)) * RS + (wc * 32 + (lane & 31)) * 4) = acc[i][r];
+                            acc[i][r] = 0.f;
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
         }
-        if (dma && q + 2 < 16) issue(q + 2, slot == 0 ? 2 : slot - 1);
-        __builtin_amdgcn_sched_barrier(0);
+    } else if (dma) {
+        int slot = 0;
+        for (int q = 0; q < 16; ++q) {
+            // tile q has landed once only tile q + 1's eight DMA instructions can still be outstanding (these waves issue no other
+            // vector memory operation after the prologue)
+            if (q == 15) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                // tile q is published; tile q - 1's slot is free
+            if (q + 2 < 16) issue(q + 2, slot == 0 ? 2 : slot - 1);
+            slot = slot == 2 ? 0 : slot + 1;
+            if ((q & 3) != 3) continue;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) acc = mfma(a[kk], b[kk], acc);
-        slot = slot == 2 ? 0 : slot + 1;
-        if (t4 != 3) continue;
-        // ---- the class is complete: sample by sample, fp32 block -> LDS -> 8-channel chunks (epilogue waves)
-#pragma unroll
-        for (int s = 0; s < SPW; ++s) {
-            if (s) __builtin_amdgcn_s_barrier();                         // the previous sample's chunk reads are done
-            if ((wr_ >> 1) == s) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    *reinterpret_cast<float*>(stage + ((wr_ & 1) * 32 + crow(r, lane)) * RS + (wc * 32 + (lane & 31)) * 4) = acc[r];
+            for (int s = 0; s < SPW; ++s) {
+                if (s) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else {
+        for (int q = 0; q < 16; ++q) {
+            const int cls = q >> 2, t4 = q & 3, py = cls >> 1, px = cls & 1;
+            if (q == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the image
             __builtin_amdgcn_s_barrier();
-            if (epi) {
-                const int n = n0 + s;
-                const bool live = n < p.N;
-                const unsigned pix = (unsigned)((n * 16 + 2 * (erow >> 3) + py) * 16 + 2 * (erow & 7) + px);
-                const float gs = gsv[s];
-                const float4 v0 = *reinterpret_cast<const float4*>(stage + erow * RS + ech * 32);
-                const float4 v1 = *reinterpret_cast<const float4*>(stage + erow * RS + ech * 32 + 16);
-                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                if constexpr (OUT == 0) {
-                    const unsigned awv[4] = {areg[s].x, areg[s].y, areg[s].z, areg[s].w};
-                    float o[8], sd = 0.f;
+            if (pcls >= 0) {
+                // the PREVIOUS class's chunks leave under this class's MFMAs: two per step in steps 1, 2, 3 (their activation
+                // chunks were fetched when the class completed)
+                if (t4 == 1) { apply(pcls, 0); apply(pcls, 1); }
+                else if (t4 == 2) { apply(pcls, 2); apply(pcls, 3); }
+                else if (t4 == 3) { apply(pcls, 4); apply(pcls, 5); }
+            }
+            if (t4 != 3) continue;
+            // the class is complete: its sample blocks, fp32, from the stage into this thread's six chunk slots
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float av = Bits16<T>::dec(awv[e >> 1] >> (16 * (e & 1)));
-                        const float dz = av > 0.f ? v[e] : 0.2f * v[e];
-                        const float zv = av > 0.f ? av : 5.0f * av;      // invert LeakyReLU(0.2)
-                        o[e] = dz * gs;
-                        sb[e] += dz; sd += o[e] * (zv - bias8[e]);
-                    }
-                    const int grp = grpv[s];
-                    if (grp == 0) sdg[0] += sd; else if (grp == 1) sdg[1] += sd; else if (grp == 2) sdg[2] += sd; else sdg[3] += sd;
-                    nsat += sat_hits<T>(o);
-                    u32x4 w; w[0] = pack2<T>(o[0], o[1]); w[1] = pack2<T>(o[2], o[3]); w[2] = pack2<T>(o[4], o[5]); w[3] = pack2<T>(o[6], o[7]);
-                    __builtin_amdgcn_raw_buffer_store_b128(w, yr, live ? (pix * (unsigned)p.ldy + ech * 8u) * 2u : OOB, 0, 0);
-                } else {
-                    const unsigned off = live ? (pix * (unsigned)p.ldy + ech * 8u) * 4u : OOB;
-                    u32x4 w0, w1;
+            for (int s = 0; s < SPW; ++s) {
+                if (s) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { w0[e] = __builtin_bit_cast(unsigned, v[e] * gs); w1[e] = __builtin_bit_cast(unsigned, v[4 + e] * gs); }
-                    __builtin_amdgcn_raw_buffer_store_b128(w0, yr, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(w1, yr, off == OOB ? OOB : off + 16u, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(stage + (erow0 + 32 * j) * RS + ech * 32);
+                    const float4 v1 = *reinterpret_cast<const float4*>(stage + (erow0 + 32 * j) * RS + ech * 32 + 16);
+                    float* v = vreg[2 * s + j];
+                    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // returned before the block is overwritten
+            }
+            pcls = cls;
+            if constexpr (OUT == 0) {                                    // the finished class's activation chunks, in the order they are applied
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int n = n0 + (k >> 1), erow = erow0 + 32 * (k & 1);
+                    const unsigned pix = (unsigned)((n * 16 + 2 * (erow >> 3) + py) * 16 + 2 * (erow & 7) + px);
+                    areg[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ar,
+                        n < p.N ? (pix * (unsigned)p.ab_lda + ech * 8u) * 2u : OOB, 0, 0));
                 }
             }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // (the next class's stage writes are 4 barriers away)
+    }
+    if (epi && pcls >= 0) {                                              // the last class's chunks
+        apply(pcls, 0); apply(pcls, 1); apply(pcls, 2); apply(pcls, 3); apply(pcls, 4); apply(pcls, 5);
     }
     if constexpr (OUT == 0) {
         if (epi) sat_commit(p.ab_sat, nsat);
         if (p.ab_dbias || p.ab_cdot) {
             // the workgroup's sums -> one replica of the striped bias-gradient / spectral-norm sums (norm.hip replica_offset);
-            // scratch: the idle ring ([NE][8] column sums, [8][4] group sums, [8][64] second-level sums: 18.6 KB of 48)
+            // scratch: the idle ring ([256][8] column sums, [4][4] group sums, [4][64] second-level sums)
             float* red = reinterpret_cast<float*>(ring);
-            float* redg = red + NE * 8;
-            float* red2 = redg + 8 * 4;
+            float* redg = red + 256 * 8;
+            float* red2 = redg + 4 * 4;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                   // every wave is done with the ring and the stage
             if (epi) {
@@ -2823,12 +2881,12 @@ __global__ __launch_bounds__(768) void dgrad_img_kernel(ConvParams p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float t = wave_sum(sdg[g]);
-                    if (lane == 0) redg[(wave - 4) * 4 + g] = t;
+                    if (lane == 0) redg[(wave - 8) * 4 + g] = t;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (epi) {                     // channel ch = te & 63 = 8 ech + e: its terms sit with the 64 threads te' = ech + 8 k; 8 threads share them
+            if (epi) {                     // channel ch = te & 63 = 8 ce + e: its terms sit with the 32 threads te' = ce + 8 k; 4 threads share them
                 const int ch = te & 63, part = te >> 6, ce = ch >> 3, e = ch & 7;
                 float t = 0.f;
 #pragma unroll
@@ -2841,13 +2899,13 @@ __global__ __launch_bounds__(768) void dgrad_img_kernel(ConvParams p) {
             if (p.ab_dbias && tid < 64) {
                 float u = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) u += red2[w * 64 + tid];
+                for (int w = 0; w < 4; ++w) u += red2[w * 64 + tid];
                 atomicAdd(p.ab_dbias + rep + tid, u);
             }
             if (p.ab_cdot && tid >= 64 && tid < 68) {
                 float t = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) t += redg[w * 4 + (tid - 64)];
+                for (int w = 0; w < 4; ++w) t += redg[w * 4 + (tid - 64)];
                 if (t != 0.f) atomicAdd(p.ab_cdot + rep + (tid - 64), t);
             }
         }
