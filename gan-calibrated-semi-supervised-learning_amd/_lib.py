@@ -22,6 +22,10 @@ LIB_PATH = PKG_DIR / "libgcssl_hip.so"
 SOURCES = ["igemm.hip", "norm.hip", "misc.hip", "recrop.hip", "simple_gen.hip", "convt_fused.hip"]
 
 F32, BF16, F16 = 0, 1, 2
+# split-precision conv modes (csrc/common.h): fp32 tensors, operands split hi + lo into 16-bit halves inside the conv kernels,
+# three 16-bit MFMAs per K step.  Conv entry points only; everything else is called with F32.
+F32_F16X3, F32_BF16X3 = 3, 4
+SPLIT_MODES = {"fp16x3": F32_F16X3, "bf16x3": F32_BF16X3}
 ERRORS = {-1: "GCSSL_EBADSHAPE", -2: "GCSSL_EBADDTYPE", -3: "GCSSL_EALIGN", -4: "GCSSL_ENULL"}
 
 _CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
@@ -141,7 +145,19 @@ def dtype_code(dt) -> int:
         return BF16
     if dt in (F16, "fp16", "f16", torch.float16):
         return F16
+    if dt in SPLIT_MODES or dt in SPLIT_MODES.values():
+        return F32                            # storage / non-conv dtype of the split-precision modes (mma_code gives the conv code)
     raise ValueError(f"unsupported compute dtype {dt!r}")
+
+
+def mma_code(dt) -> int:
+    """dtype code the CONV entry points get for compute mode `dt`: the split-precision code for "fp16x3" / "bf16x3",
+    dtype_code(dt) otherwise."""
+    if dt in SPLIT_MODES:
+        return SPLIT_MODES[dt]
+    if dt in SPLIT_MODES.values():
+        return dt
+    return dtype_code(dt)
 
 
 def torch_dtype(code: int):
@@ -149,4 +165,4 @@ def torch_dtype(code: int):
 
 
 def dtype_name(code: int) -> str:
-    return {F32: "fp32", BF16: "bf16", F16: "fp16"}[code]
+    return {F32: "fp32", BF16: "bf16", F16: "fp16", F32_F16X3: "fp16x3", F32_BF16X3: "bf16x3"}[code]

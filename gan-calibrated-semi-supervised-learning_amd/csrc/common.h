@@ -13,6 +13,12 @@
 #define GCSSL_F32 0
 #define GCSSL_BF16 1
 #define GCSSL_F16 2      // IEEE half operands (v_mfma_f32_32x32x16_f16: the bf16 rate, 3 more mantissa bits), fp32 accumulate
+// Split-precision conv modes: tensors are fp32 in memory exactly as with GCSSL_F32 (every non-conv entry point is called with
+// GCSSL_F32); only the conv contractions differ -- operands split into hi + lo 16-bit halves on their way into LDS, three
+// 16-bit MFMAs per K step (hi*hi + lo*hi + hi*lo), fp32 accumulate.  Accepted by the gcssl_conv4x4s2_{fwd,dgrad,wgrad}[_splits]
+// and gcssl_conv3x3_{fwd,wgrad} entry points only.
+#define GCSSL_F32_F16X3 3    // fp16 halves: 22 mantissa bits per operand (operands must sit in fp16's range: static loss scale)
+#define GCSSL_F32_BF16X3 4   // bf16 halves: 16 mantissa bits per operand, fp32's exponent range
 
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;
@@ -33,6 +39,17 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
         else { typedef bf16_t T; __VA_ARGS__; }                              \
     } while (0)
 static inline bool gcssl_bad_dtype(int dt) { return dt != GCSSL_F32 && dt != GCSSL_BF16 && dt != GCSSL_F16; }
+// conv entry points: + the split-precision modes.  T = storage element type, MM = MFMA mode (0 native, 1 fp16x3, 2 bf16x3)
+#define GCSSL_DISPATCH_CONV(dt, ...)                                                            \
+    do {                                                                                        \
+        if ((dt) == GCSSL_F32) { typedef float T; constexpr int MM = 0; (void)MM; __VA_ARGS__; }            \
+        else if ((dt) == GCSSL_F32_F16X3) { typedef float T; constexpr int MM = 1; (void)MM; __VA_ARGS__; } \
+        else if ((dt) == GCSSL_F32_BF16X3) { typedef float T; constexpr int MM = 2; (void)MM; __VA_ARGS__; }\
+        else if ((dt) == GCSSL_F16) { typedef f16_t T; constexpr int MM = 0; (void)MM; __VA_ARGS__; }       \
+        else { typedef bf16_t T; constexpr int MM = 0; (void)MM; __VA_ARGS__; }                             \
+    } while (0)
+static inline bool gcssl_bad_conv_dtype(int dt) { return gcssl_bad_dtype(dt) && dt != GCSSL_F32_F16X3 && dt != GCSSL_F32_BF16X3; }
+static inline bool gcssl_f32_storage(int dt) { return dt == GCSSL_F32 || dt == GCSSL_F32_F16X3 || dt == GCSSL_F32_BF16X3; }
 
 static inline int gcssl_launch_status() {
     hipError_t e = hipGetLastError();

@@ -43,6 +43,7 @@ template <typename T, int ROWS> struct KMajor;
 template <int ROWS> struct KMajor<float, ROWS> {
     static constexpr int BK = BKOf<float>::v;
     static constexpr int STRIDE = BK + 1;                     // conflict-free b32 fragment reads
+    static constexpr bool SPLIT = false;
     static constexpr int KSTEPS = BK / 2;
     typedef float Frag;
     float d[ROWS * STRIDE];
@@ -56,6 +57,7 @@ template <int ROWS> struct KMajor<float, ROWS> {
 };
 template <typename T, int ROWS> struct KMajor16 {
     static constexpr int BK = 64;
+    static constexpr bool SPLIT = false;
     static constexpr int KSTEPS = BK / 16;
     typedef typename Frag16<T>::type Frag;
     uint4 d[ROWS * 8];                                        // 128-byte rows of 8 16-byte chunks, XOR-swizzled:
@@ -73,6 +75,7 @@ template <int ROWS> struct KMajor<f16_t, ROWS> : KMajor16<f16_t, ROWS> {};
 template <typename T, int ROWS> struct MMajor;
 template <int ROWS> struct MMajor<float, ROWS> {
     static constexpr int BK = BKOf<float>::v;
+    static constexpr bool SPLIT = false;
     static constexpr int KSTEPS = BK / 2;
     typedef float Frag;
     float d[BK * ROWS];
@@ -85,6 +88,7 @@ template <int ROWS> struct MMajor<float, ROWS> {
 };
 template <typename T, int ROWS> struct MMajor16 {
     static constexpr int BK = 64;
+    static constexpr bool SPLIT = false;
     static constexpr int KSTEPS = BK / 16;
     static constexpr int STRIDE = ROWS * 2 + 64;              // bytes; +64 B keeps the 4 rows of a tr block on distinct banks
     typedef typename Frag16<T>::type Frag;
@@ -109,6 +113,85 @@ template <typename T, int ROWS> struct MMajor16 {
 };
 template <int ROWS> struct MMajor<bf16_t, ROWS> : MMajor16<bf16_t, ROWS> {};
 template <int ROWS> struct MMajor<f16_t, ROWS> : MMajor16<f16_t, ROWS> {};
+
+// ------------------------------------------------------------------------------------------
+// SPLIT-PRECISION tiles (MM = 1: fp16 hi + lo, MM = 2: bf16 hi + lo; the "fp16x3" / "bf16x3" modes).  Tensors stay fp32 in
+// HBM exactly as in the fp32 parity mode; a loaded 4-float vector is split ONCE, on its way into LDS, into
+//   hi = rne16(x * s),  lo = rne16(x * s - hi)         (s: a power of two per operand, exact; undone in the epilogue)
+// and the 32 real K elements of a tile row become one 128-byte row [hi k0..31 | lo k0..31] -- the 16-bit KMajor16 / MMajor16
+// layouts with four physical 16-deep K steps (0, 1 = hi; 2, 3 = lo).  The contraction then runs on the 2.5-PFLOP/s 16-bit
+// MFMA pipe as THREE products per real K step, A_hi B_hi + A_lo B_hi + A_hi B_lo (A_lo B_lo is below fp32's own rounding),
+// accumulated in fp32: 22 (fp16) / 16 (bf16) mantissa bits per operand instead of 11 / 8, against v_mfma_f32_32x32x2_f32's
+// 157 TFLOP/s for the exact form.  SURVEY.md 7 "hard part 2" names this ("bf16x3 split"); reference arithmetic: pure fp32,
+// cgan/models.py:222-258, cgan/losses.py:185-233.
+// ------------------------------------------------------------------------------------------
+template <int MM> struct SplitH;
+template <> struct SplitH<1> { typedef f16_t type; };
+template <> struct SplitH<2> { typedef bf16_t type; };
+template <typename H> __device__ __forceinline__ void split4(const float4& v, float s, uint2& hi, uint2& lo) {
+    const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
+    hi.x = pack2<H>(x0, x1); hi.y = pack2<H>(x2, x3);
+    lo.x = pack2<H>(x0 - Bits16<H>::dec(hi.x), x1 - Bits16<H>::dec(hi.x >> 16));
+    lo.y = pack2<H>(x2 - Bits16<H>::dec(hi.y), x3 - Bits16<H>::dec(hi.y >> 16));
+}
+template <typename H, int ROWS> struct KMajorSplit {
+    static constexpr int BK = 32;                             // REAL K elements per tile (fp32 in memory)
+    static constexpr int KSTEPS = 4;                          // physical 16-deep steps: hi, hi, lo, lo
+    static constexpr bool SPLIT = true;
+    typedef typename Frag16<H>::type Frag;
+    uint4 d[ROWS * 8];
+    __device__ static int swz(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
+    // chunk: which 4-float vector of the row's 32 (0..7)
+    __device__ void store_vec(int row, int chunk, const Vec16<float>& v, float s) {
+        uint2 hi, lo;
+        split4<H>(v.v, s, hi, lo);
+        uint2* b = reinterpret_cast<uint2*>(d);
+        b[swz(row, chunk >> 1) * 2 + (chunk & 1)] = hi;
+        b[swz(row, 4 + (chunk >> 1)) * 2 + (chunk & 1)] = lo;
+    }
+    __device__ Frag frag(int row0, int ks, int lane) const {
+        return __builtin_bit_cast(Frag, d[swz(row0 + (lane & 31), ks * 2 + (lane >> 5))]);
+    }
+};
+template <typename H, int ROWS> struct MMajorSplit {
+    static constexpr int BK = 32;
+    static constexpr int KSTEPS = 4;
+    static constexpr bool SPLIT = true;
+    static constexpr int STRIDE = ROWS * 2 + 64;              // bytes (as MMajor16)
+    typedef typename Frag16<H>::type Frag;
+    __attribute__((aligned(16))) unsigned char d[64 * STRIDE];   // k-rows 0..31: hi, 32..63: lo
+    // chunk: which 4-row vector of k-row k (rows 4 chunk .. 4 chunk + 3)
+    __device__ void store_vec(int k, int chunk, const Vec16<float>& v, float s) {
+        uint2 hi, lo;
+        split4<H>(v.v, s, hi, lo);
+        *reinterpret_cast<uint2*>(d + k * STRIDE + chunk * 8) = hi;
+        *reinterpret_cast<uint2*>(d + (k + 32) * STRIDE + chunk * 8) = lo;
+    }
+    __device__ Frag frag(int row0, int ks, int lane) const {
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+        const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, h = g >> 1;
+        const int kb = ks * 16 + 8 * h + q;
+        const unsigned char* a0 = d + kb * STRIDE + (row0 + 16 * (g & 1) + 4 * p) * 2;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0 + 4 * STRIDE));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(Frag, r);
+    }
+};
+// tile types of the register-staged kernels by MFMA mode
+template <typename T, int ROWS, int MM> struct KTile { typedef KMajor<T, ROWS> type; };
+template <int ROWS> struct KTile<float, ROWS, 1> { typedef KMajorSplit<f16_t, ROWS> type; };
+template <int ROWS> struct KTile<float, ROWS, 2> { typedef KMajorSplit<bf16_t, ROWS> type; };
+template <typename T, int ROWS, int MM> struct MTile { typedef MMajor<T, ROWS> type; };
+template <int ROWS> struct MTile<float, ROWS, 1> { typedef MMajorSplit<f16_t, ROWS> type; };
+template <int ROWS> struct MTile<float, ROWS, 2> { typedef MMajorSplit<bf16_t, ROWS> type; };
+// store a fetched vector into a tile: the split tiles take the operand's power-of-two pre-scale
+template <class Tile, class V> __device__ __forceinline__ auto tile_store(Tile& t, int r, int c, const V& v, float s)
+    -> decltype(t.store_vec(r, c, v, s)) { t.store_vec(r, c, v, s); }
+template <class Tile, class V> __device__ __forceinline__ auto tile_store(Tile& t, int r, int c, const V& v, ...)
+    -> decltype(t.store_vec(r, c, v)) { t.store_vec(r, c, v); }
 
 // Branch-free gather loads.  hipcc turns `ok ? load(p) : 0` into an exec-mask branch per load (each with its own
 // vmcnt drain), which serialises the whole tile fetch; a raw buffer load with an out-of-range offset returns 0 in
@@ -136,9 +219,35 @@ __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
 }
 
 // one BK slab: acc[i][j] += A(rows wm0+32i..) x B(rows wn0+32j..)^T
+// split tiles (KMajorSplit / MMajorSplit): per real 16-deep K step s, acc += A_lo[s] B_hi[s] + A_hi[s] B_lo[s] + A_hi[s] B_hi[s]
+// (physical steps 0, 1 = hi, 2, 3 = lo; every term is an fp32 accumulate, A_lo B_lo is dropped: below fp32's own rounding)
+template <int TM, int TN, class TA, class TB>
+__device__ __forceinline__ void mma_slab_split(const TA& As, const TB& Bs, int wm0, int wn0, int lane, f32x16 (&acc)[TM][TN]) {
+    typename TA::Frag a[4][TM];
+    typename TB::Frag b[4][TN];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[ks][i] = As.frag(wm0 + 32 * i, ks, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[ks][j] = Bs.frag(wn0 + 32 * j, ks, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = mfma(a[ks + 2][i], b[ks][j], acc[i][j]);
+                acc[i][j] = mfma(a[ks][i], b[ks + 2][j], acc[i][j]);
+                acc[i][j] = mfma(a[ks][i], b[ks][j], acc[i][j]);
+            }
+}
 template <int TM, int TN, class TA, class TB>
 __device__ __forceinline__ void mma_slab(const TA& As, const TB& Bs, int wm0, int wn0, int lane,
                                          f32x16 (&acc)[TM][TN]) {
+    if constexpr (TA::SPLIT) { mma_slab_split<TM, TN>(As, Bs, wm0, wn0, lane, acc); return; }
     if constexpr (sizeof(typename TA::Frag) == 16 && TA::KSTEPS * (TM + TN) <= 16) {
         // 16-bit operands: every fragment read of the slab goes out first, then the MFMAs run behind counted lgkmcnt waits
         // (left to itself hipcc emits reads, lgkmcnt(0), MFMAs per k-step: each group paid a full LDS round trip)
@@ -248,6 +357,8 @@ struct ConvParams {
                                           // output BEFORE the activation backward: gcssl_dot_accum folded in), nullable
     int kcap;                             // timing experiment (GCSSL_KCAP, 3x3 persistent form only; results are garbage): walk only the
                                           // first kcap K steps of every tile -- the K volume a Winograd F(2x2,3x3) GEMM stage would have
+    float mm_ascale, mm_bscale, mm_oscale; // split-precision forms (MM != 0): power-of-two pre-scales of the two operands on their way
+                                          // into LDS and their inverse product, applied to the accumulators in the epilogue
     void* in_apre; int ld_apre, apre_n0;  // optional second output: the activation WITHOUT dropout for samples n >= apre_n0
                                           // ([N - apre_n0][Ho*Wo][ld_apre]): what the backward rebuilds xhat from
 };
@@ -256,15 +367,15 @@ struct ConvParams {
 // forward: y[m][co] = act( gscale[g(m)] * sum_{tap,ci} x[n, 2oy-1+ky, 2ox-1+kx, ci] Wf[co][tap][ci] + bias[co] )
 // GEMM M = N*Ho*Wo, N = Cout, K = 16*Cin
 // ------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int KS = 4>
+template <typename T, int BM, int BN, int KS = 4, int MM = 0>
 __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
     typedef Geo<KS> G;
     constexpr int BK = BKOf<T>::v;
     constexpr int KV = Elem<T>::KV, CH = BK / KV, RPT = NT / CH;   // rows covered per pass
     constexpr int NVA = BM / RPT, NVB = BN / RPT;
     constexpr int TM = BM / 64, TN = BN / 64;
-    __shared__ KMajor<T, BM> As[2];
-    __shared__ KMajor<T, BN> Bs[2];
+    __shared__ typename KTile<T, BM, MM>::type As[2];
+    __shared__ typename KTile<T, BN, MM>::type Bs[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
@@ -309,9 +420,9 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
     };
     auto lstore = [&](const Vec16<T> (&qa)[NVA], const Vec16<T> (&qb)[NVB], int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) As[buf].store_vec(row_t + i * RPT, chunk, qa[i]);
+        for (int i = 0; i < NVA; ++i) tile_store(As[buf], row_t + i * RPT, chunk, qa[i], p.mm_ascale);
 #pragma unroll
-        for (int j = 0; j < NVB; ++j) Bs[buf].store_vec(row_t + j * RPT, chunk, qb[j]);
+        for (int j = 0; j < NVB; ++j) tile_store(Bs[buf], row_t + j * RPT, chunk, qb[j], p.mm_bscale);
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -348,8 +459,8 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm0 + 32 * i + crow(r, lane);
             if (m >= p.M) continue;
-            float s = 1.f;
-            if (p.gscale) s = p.gscale[(m >> p.lgHoWo) / p.group_n];
+            float s = MM ? p.mm_oscale : 1.f;
+            if (p.gscale) s *= p.gscale[(m >> p.lgHoWo) / p.group_n];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int co = n0 + wn0 + 32 * j + (lane & 31);
@@ -374,14 +485,14 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
 // One launch z-slice per output parity class (py,px); per class M = N*Ho*Wo, N = Cin, K = 4*Cout.
 //   ky = 1-py+2ty, oy = iy' + py - ty   (iy = 2 iy' + py), same in x.
 // ------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int MM = 0>
 __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
     constexpr int BK = BKOf<T>::v;
     constexpr int KV = Elem<T>::KV, CH = BK / KV, RPT = NT / CH;
     constexpr int NVA = BM / RPT, NVB = BN / RPT;
     constexpr int TM = BM / 64, TN = BN / 64;
-    __shared__ KMajor<T, BM> As[2];
-    __shared__ KMajor<T, BN> Bs[2];
+    __shared__ typename KTile<T, BM, MM>::type As[2];
+    __shared__ typename KTile<T, BN, MM>::type Bs[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int cls = p.ksplit > 1 ? (int)blockIdx.z / p.ksplit : (int)blockIdx.z;
@@ -430,9 +541,9 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
     };
     auto lstore = [&](const Vec16<T> (&qa)[NVA], const Vec16<T> (&qb)[NVB], int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) As[buf].store_vec(row_t + i * RPT, chunk, qa[i]);
+        for (int i = 0; i < NVA; ++i) tile_store(As[buf], row_t + i * RPT, chunk, qa[i], p.mm_ascale);
 #pragma unroll
-        for (int j = 0; j < NVB; ++j) Bs[buf].store_vec(row_t + j * RPT, chunk, qb[j]);
+        for (int j = 0; j < NVB; ++j) tile_store(Bs[buf], row_t + j * RPT, chunk, qb[j], p.mm_bscale);
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -467,8 +578,8 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
             const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
             const int iy = 2 * (rem >> p.lgWo) + py, ix = 2 * (rem & (Wo - 1)) + px;
             const size_t pix = (size_t)(n * p.Hi + iy) * p.Wi + ix;
-            float s = 1.f;
-            if (p.gscale) s = p.gscale[n / p.group_n];
+            float s = MM ? p.mm_oscale : 1.f;
+            if (p.gscale) s *= p.gscale[n / p.group_n];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int ci = n0 + wn0 + 32 * j + (lane & 31);
@@ -1002,7 +1113,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
 // Both operands arrive row(k)-major with channels contiguous -> MMajor tiles, transposed LDS reads.
 // ------------------------------------------------------------------------------------------
 // SMALLC (first layers, Cin padded to 8): the N tile is all 16 taps x 8 channels (BN must be 128).
-template <typename T, int BM, int BN, bool SMALLC, int KS = 4>
+template <typename T, int BM, int BN, bool SMALLC, int KS = 4, int MM = 0>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
     typedef Geo<KS> G;
     constexpr int BK = BKOf<T>::v;
@@ -1012,8 +1123,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
     constexpr int NVA = BK * CHA / NT, NVB = BK * CHB / NT;
     static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 threads");
     constexpr int TM = BM / 64, TN = BN / 64;
-    __shared__ MMajor<T, BM> As[2];
-    __shared__ MMajor<T, BN> Bs[2];
+    __shared__ typename MTile<T, BM, MM>::type As[2];
+    __shared__ typename MTile<T, BN, MM>::type Bs[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // All (co-tile, tap, ci-tile) workgroups of one K split read the same dy rows and overlapping x rows.  In dispatch order
     // (x, then y, then z) they are consecutive and therefore spread over the 8 XCDs, each of which fetches its own copy:
@@ -1068,9 +1179,9 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
     };
     auto lstore = [&](const Vec16<T> (&qa)[NVA], const Vec16<T> (&qb)[NVB], int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) { const int v = tid + i * NT; As[buf].store_vec(v / CHA, v % CHA, qa[i]); }
+        for (int i = 0; i < NVA; ++i) { const int v = tid + i * NT; tile_store(As[buf], v / CHA, v % CHA, qa[i], p.mm_ascale); }
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) { const int v = tid + i * NT; Bs[buf].store_vec(v / CHB, v % CHB, qb[i]); }
+        for (int i = 0; i < NVB; ++i) { const int v = tid + i * NT; tile_store(Bs[buf], v / CHB, v % CHB, qb[i], p.mm_bscale); }
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1099,7 +1210,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int ci = ci0 + wn0 + 32 * j + (lane & 31);   // SMALLC: ci is the packed (tap*8 + channel) column
-                slab[((size_t)co * 16 + tap) * p.Cin + ci] = acc[i][j][r];
+                slab[((size_t)co * 16 + tap) * p.Cin + ci] = MM ? acc[i][j][r] * p.mm_oscale : acc[i][j][r];
             }
         }
 }
@@ -2013,21 +2124,30 @@ __global__ __launch_bounds__(256) void prep_weight_batch_kernel(PrepBatch b) {
     }
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int MM = 0>
 int launch_fwd(const ConvParams& p, hipStream_t st) {
     if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
     if (Is16<T>::v && use_dma()) launch_dma<typename Op16<T>::type, BM, BN, 0>(p, grid, p.Cin < 64, st);
-    else GCSSL_LAUNCH((conv_fwd_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
+    else GCSSL_LAUNCH((conv_fwd_kernel<T, BM, BN, 4, MM>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
 }
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int MM = 0>
 int launch_dgrad(const ConvParams& p, hipStream_t st) {
     if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cin + BN - 1) / BN, 4 * (p.ksplit > 1 ? p.ksplit : 1));
     if (Is16<T>::v && use_dma()) launch_dma<typename Op16<T>::type, BM, BN, 1>(p, grid, false, st);
-    else GCSSL_LAUNCH((conv_dgrad_kernel<T, BM, BN>), grid, dim3(NT), 0, st, p);
+    else GCSSL_LAUNCH((conv_dgrad_kernel<T, BM, BN, MM>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
+}
+// split-precision forms: the weights (B operand of the forward / data-gradient GEMMs) are pre-scaled by 2^6 on their way into
+// LDS -- N(0, 0.02) entries land at O(1), where the fp16 lo part keeps all its bits (below 6e-5 it would be subnormal) -- and the
+// accumulators are scaled back in the epilogue.  Exact (powers of two).  GCSSL_X3_WSCALE: log2 of the factor (experiments).
+void set_mm_scales(ConvParams& p, bool weights_b) {
+    static const int lg = [] { const char* e = getenv("GCSSL_X3_WSCALE"); return e ? atoi(e) : 6; }();
+    p.mm_ascale = 1.f;
+    p.mm_bscale = weights_b ? (float)(1 << lg) : 1.f;
+    p.mm_oscale = 1.f / p.mm_bscale;
 }
 
 int check_geom(int N, int Hi, int Wi, int Cin, int Cout) {
@@ -2324,8 +2444,9 @@ __global__ __launch_bounds__(256) void conv_fwd_c8_kernel(ConvParams p, int ntil
 // (A/B knob: GCSSL_C8_FWD=0 sends these shapes back to the generic tiles)
 bool c8_fwd_on() { static const bool v = [] { const char* e = getenv("GCSSL_C8_FWD"); return !(e && e[0] == '0'); }(); return v; }
 
-template <typename T>
+template <typename T, int MM = 0>
 int dispatch_fwd(ConvParams p, hipStream_t st) {
+    if (MM) set_mm_scales(p, true);
     if constexpr (Is16<T>::v) {
         const int Wo = p.Wi / 2;
         if (p.Cin == 8 && p.Cout == 64 && (Wo == 16 || Wo == 32 || Wo == 64) && (p.Hi / 2) % (128 / Wo) == 0 && c8_fwd_on() &&
@@ -2348,8 +2469,8 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
         if (f && !strcmp(f, "ring") && p.Cout >= 128) return launch_ring<typename Op16<T>::type, 0>(p, st);
         if (f && !strcmp(f, "256x128") && p.Cout >= 128) return launch_big<typename Op16<T>::type, 256, 128, 0>(p, st);
         if (f && !strcmp(f, "256x64")) return launch_big<typename Op16<T>::type, 256, 64, 0>(p, st);
-        if (f && !strcmp(f, "128x128") && p.Cout >= 128) return launch_fwd<T, 128, 128>(p, st);
-        if (f && !strcmp(f, "128x64")) return launch_fwd<T, 128, 64>(p, st);
+        if (f && !strcmp(f, "128x128") && p.Cout >= 128) return launch_fwd<T, 128, 128, MM>(p, st);
+        if (f && !strcmp(f, "128x64")) return launch_fwd<T, 128, 64, MM>(p, st);
     }
     const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if constexpr (Is16<T>::v) {
@@ -2367,8 +2488,8 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
             }
         }
     }
-    if (p.Cout >= 128 && t128 >= tile128_threshold()) return launch_fwd<T, 128, 128>(p, st);
-    if (p.Cout >= 64 && (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64) >= tile_threshold()) return launch_fwd<T, 128, 64>(p, st);
+    if (p.Cout >= 128 && t128 >= tile128_threshold()) return launch_fwd<T, 128, 128, MM>(p, st);
+    if (p.Cout >= 64 && (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64) >= tile_threshold()) return launch_fwd<T, 128, 64, MM>(p, st);
     const long t64 = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64);
     const int nk = 16 * p.Cin / BKOf<T>::v;
     const bool f32out = p.out_f32 || std::is_same<T, float>::value;
@@ -2382,7 +2503,7 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
             p.ktiles_per_split = (nk + p.ksplit - 1) / p.ksplit;
             int rc = zero_output(p, p.M, p.Cout, st);
             if (rc) return rc;
-            return launch_fwd<T, 128, 64>(p, st);
+            return launch_fwd<T, 128, 64, MM>(p, st);
         }
     }
     p.ksplit = pick_ksplit(t64, nk, split_ok);
@@ -2391,7 +2512,7 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
         int rc = zero_output(p, p.M, p.Cout, st);
         if (rc) return rc;
     }
-    return launch_fwd<T, 64, 64>(p, st);
+    return launch_fwd<T, 64, 64, MM>(p, st);
 }
 // ---- forward conv + InstanceNorm + LeakyReLU in one launch (the FIN instantiations of conv_dma_kernel).
 // Which form serves these shapes: 0 none (the caller keeps the conv -> fp32 z -> gcssl_in_act_fwd pair), 1 the loader /
@@ -2566,8 +2687,9 @@ bool c8_dgrad_on() { static const bool v = [] { const char* e = getenv("GCSSL_C8
 int dgrad_img_on(const ConvParams& p);                                   // (dgrad_img_kernel, below)
 template <typename O, int OUT> void launch_dgrad_img(const ConvParams& p, hipStream_t st);
 
-template <typename T>
+template <typename T, int MM = 0>
 int dispatch_dgrad(ConvParams p, hipStream_t st) {
+    if (MM) set_mm_scales(p, true);
     if constexpr (Is16<T>::v) {
         // the 64 <- 128 layer on 16 x 16 maps, fp32 dx, >= 3 samples per CU: dy maps resident in LDS (dgrad_img_kernel)
         if (p.out_f32 && !p.split_stride && p.ldy % 4 == 0 && aligned16(p.y) && p.y_bytes && !forced_tile() && dgrad_img_on(p)) {
@@ -2597,8 +2719,8 @@ int dispatch_dgrad(ConvParams p, hipStream_t st) {
         if (f && !strcmp(f, "ring") && p.Cin >= 128) return launch_ring<typename Op16<T>::type, 1>(p, st);
         if (f && !strcmp(f, "256x128") && p.Cin >= 128) return launch_big<typename Op16<T>::type, 256, 128, 1>(p, st);
         if (f && !strcmp(f, "256x64")) return launch_big<typename Op16<T>::type, 256, 64, 1>(p, st);
-        if (f && !strcmp(f, "128x128") && p.Cin >= 128) return launch_dgrad<T, 128, 128>(p, st);
-        if (f && !strcmp(f, "128x64")) return launch_dgrad<T, 128, 64>(p, st);
+        if (f && !strcmp(f, "128x128") && p.Cin >= 128) return launch_dgrad<T, 128, 128, MM>(p, st);
+        if (f && !strcmp(f, "128x64")) return launch_dgrad<T, 128, 64, MM>(p, st);
     }
     const long t128 = 4L * ((p.M + 127) / 128) * ((p.Cin + 127) / 128);
     if constexpr (Is16<T>::v) {
@@ -2616,8 +2738,8 @@ int dispatch_dgrad(ConvParams p, hipStream_t st) {
             }
         }
     }
-    if (p.Cin >= 128 && t128 >= tile128_threshold()) return launch_dgrad<T, 128, 128>(p, st);
-    if (p.Cin >= 64 && 4L * ((p.M + 127) / 128) * ((p.Cin + 63) / 64) >= tile_threshold()) return launch_dgrad<T, 128, 64>(p, st);
+    if (p.Cin >= 128 && t128 >= tile128_threshold()) return launch_dgrad<T, 128, 128, MM>(p, st);
+    if (p.Cin >= 64 && 4L * ((p.M + 127) / 128) * ((p.Cin + 63) / 64) >= tile_threshold()) return launch_dgrad<T, 128, 64, MM>(p, st);
     const long t64 = 4L * ((p.M + 63) / 64) * ((p.Cin + 63) / 64);
     const int nk = 4 * p.Cout / BKOf<T>::v;
     const bool f32out = p.out_f32 || std::is_same<T, float>::value;
@@ -2628,7 +2750,7 @@ int dispatch_dgrad(ConvParams p, hipStream_t st) {
             p.ktiles_per_split = (nk + p.ksplit - 1) / p.ksplit;
             int rc = zero_output(p, (long)p.N * p.Hi * p.Wi, p.Cin, st);
             if (rc) return rc;
-            return launch_dgrad<T, 128, 64>(p, st);
+            return launch_dgrad<T, 128, 64, MM>(p, st);
         }
     }
     p.ksplit = pick_ksplit(t64, nk, f32out);
@@ -2637,7 +2759,7 @@ int dispatch_dgrad(ConvParams p, hipStream_t st) {
         int rc = zero_output(p, (long)p.N * p.Hi * p.Wi, p.Cin, st);
         if (rc) return rc;
     }
-    return launch_dgrad<T, 64, 64>(p, st);      // Cin < 64 (first layer, Cin padded to 8): masked columns
+    return launch_dgrad<T, 64, 64, MM>(p, st);      // Cin < 64 (first layer, Cin padded to 8): masked columns
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2968,8 +3090,8 @@ int gcssl_conv4x4s2_fwd_splits(int dtype, int N, int Hi, int Wi, int Cin, int Co
     int ks = 1;
     ConvParams p{}; p.act = act; p.out_f32 = out_f32; p.plan_out = &ks; p.ldx = Cin; p.ldy = Cout; p.y_bytes = 1;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    GCSSL_DISPATCH(dtype, rc = dispatch_fwd<T>(p, nullptr));
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH_CONV(dtype, rc = (dispatch_fwd<T, MM>(p, nullptr)));
     return rc ? rc : ks;
 }
 int gcssl_conv4x4s2_dgrad_splits(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int out_f32) {
@@ -2978,8 +3100,8 @@ int gcssl_conv4x4s2_dgrad_splits(int dtype, int N, int Hi, int Wi, int Cin, int 
     int ks = 1;
     ConvParams p{}; p.out_f32 = out_f32; p.plan_out = &ks; p.ldx = Cout; p.ldy = Cin; p.y_bytes = 1;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    GCSSL_DISPATCH(dtype, rc = dispatch_dgrad<T>(p, nullptr));
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH_CONV(dtype, rc = (dispatch_dgrad<T, MM>(p, nullptr)));
     return rc ? rc : ks;
 }
 
@@ -2991,7 +3113,7 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
     int rc = check_geom(N, Hi, Wi, Cin, Cout);
     if (rc) return rc;
     if (Cout < 64 || ldx < Cin || ldy < Cout || (gscale && group_n <= 0)) return GCSSL_EBADSHAPE;
-    const int kv = dtype == GCSSL_F32 ? 4 : 8;
+    const int kv = gcssl_f32_storage(dtype) ? 4 : 8;
     if (ldx % kv || !aligned16(x) || !aligned16(wf)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = x; p.w = wf; p.y = y; p.bias = bias; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
     p.ldx = ldx; p.ldy = ldy; p.act = act; p.out_f32 = out_f32; p.split_stride = split_stride;
@@ -3003,8 +3125,8 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
         p.y_bytes = yb < 0x7FFFFFFFull ? (unsigned)yb : 0u;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    GCSSL_DISPATCH(dtype, return dispatch_fwd<T>(p, st));
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH_CONV(dtype, return (dispatch_fwd<T, MM>(p, st)));
     return GCSSL_EBADDTYPE;
 }
 
@@ -3056,7 +3178,7 @@ int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, c
     int rc = check_geom(N, Hi, Wi, Cin, Cout);
     if (rc) return rc;
     if (Cout < 8 || lddy < Cout || lddx < Cin || (gscale && group_n <= 0)) return GCSSL_EBADSHAPE;
-    const int kv = dtype == GCSSL_F32 ? 4 : 8;
+    const int kv = gcssl_f32_storage(dtype) ? 4 : 8;
     if (lddy % kv || !aligned16(dy) || !aligned16(wt)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = dy; p.w = wt; p.y = dx; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
     static const int class_major = [] { const char* e = getenv("GCSSL_DGRAD_ORDER"); return (e && e[0] == '1') ? 1 : 0; }();
@@ -3070,8 +3192,8 @@ int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, c
         p.y_bytes = yb < 0x7FFFFFFFull ? (unsigned)yb : 0u;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    GCSSL_DISPATCH(dtype, return dispatch_dgrad<T>(p, st));
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH_CONV(dtype, return (dispatch_dgrad<T, MM>(p, st)));
     return GCSSL_EBADDTYPE;
 }
 
@@ -3195,7 +3317,7 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
     int rc = check_geom(N, Hi, Wi, Cin, Cout);
     if (rc) return rc;
     if ((Cin < 64 && Cin != 8) || Cout < 64 || ldx < Cin || lddy < Cout) return GCSSL_EBADSHAPE;
-    const int kv = dtype == GCSSL_F32 ? 4 : 8;
+    const int kv = gcssl_f32_storage(dtype) ? 4 : 8;
     if (ldx % kv || lddy % kv || !aligned16(x) || !aligned16(dy)) return GCSSL_EALIGN;
     const int nsplit = gcssl_conv4x4s2_wgrad_splits(N, Hi, Wi, Cin, Cout);
     if (nsplit <= 0) return GCSSL_EBADSHAPE;
@@ -3204,12 +3326,13 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)N * (Hi / 2) * (Wi / 2) * lddy, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
     const int nkt = (p.M + 63) / 64;
-    p.ktiles_per_split = ((nkt + nsplit - 1) / nsplit) * (64 / (dtype == GCSSL_F32 ? BKOf<float>::v : BKOf<bf16_t>::v));
+    p.ktiles_per_split = ((nkt + nsplit - 1) / nsplit) * (64 / (gcssl_f32_storage(dtype) ? BKOf<float>::v : BKOf<bf16_t>::v));
     hipStream_t st = (hipStream_t)stream;
     const int bm = Cout >= 128 ? 128 : 64, bn = Cin >= 128 ? 128 : 64;
     const bool smallc = Cin == 8;
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    if (dtype != GCSSL_F32 && wgrad_dma_shape(N, Hi, Wi, Cin, Cout)) {
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
+    set_mm_scales(p, false);
+    if (!gcssl_f32_storage(dtype) && wgrad_dma_shape(N, Hi, Wi, Cin, Cout)) {
         dim3 gd(Cout / 128, 4 * (Cin / 64), nsplit);                    // LDS-DMA ring, one filter row (4 taps) per workgroup
         static const int lw = [] { const char* e = getenv("GCSSL_WGRAD_LW"); return e ? atoi(e) : 8; }();    // A/B knob: 0 = all waves fetch
         if (lw) {
@@ -3222,8 +3345,8 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
         return gcssl_launch_status();
     }
     dim3 grid(Cout / bm, smallc ? 1 : 16 * (Cin / bn), nsplit);
-#define WG(T, A, B, S) GCSSL_LAUNCH((conv_wgrad_kernel<T, A, B, S>), grid, dim3(NT), 0, st, p)
-    GCSSL_DISPATCH(dtype,
+#define WG(T, A, B, S) GCSSL_LAUNCH((conv_wgrad_kernel<T, A, B, S, 4, MM>), grid, dim3(NT), 0, st, p)
+    GCSSL_DISPATCH_CONV(dtype,
         if (smallc) { if (bm == 128) WG(T, 128, 128, true); else WG(T, 64, 128, true); }
         else if (bm == 128 && bn == 128) WG(T, 128, 128, false); else if (bm == 128) WG(T, 128, 64, false);
         else if (bn == 128) WG(T, 64, 128, false); else WG(T, 64, 64, false));
@@ -3326,8 +3449,8 @@ int gcssl_conv3x3_fwd(int dtype, const void* x, int ldx, const void* w, const fl
     int rc = check_geom(N, H, W, Cin, Cout);
     if (rc) return rc;
     if (Cout < 64 || ldx < Cin || ldy < Cout) return GCSSL_EBADSHAPE;
-    const int kv = dtype == GCSSL_F32 ? 4 : 8;
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    const int kv = gcssl_f32_storage(dtype) ? 4 : 8;
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (ldx % kv || !aligned16(x) || !aligned16(w)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = x; p.w = w; p.y = y; p.bias = bias; p.ldx = ldx; p.ldy = ldy; p.out_f32 = out_f32;
     p.N = N; p.Hi = H; p.Wi = W; p.Cin = Cin; p.Cout = Cout; p.wk = wk3(Cin);
@@ -3344,7 +3467,7 @@ int gcssl_conv3x3_fwd(int dtype, const void* x, int ldx, const void* w, const fl
     const bool big = (long)((p.M + 127) / 128) * (Cout / 64) >= 256;
     dim3 grid((p.M + (big ? 127 : 63)) / (big ? 128 : 64), Cout / 64, 1);
     static const bool dma3 = [] { const char* e = getenv("GCSSL_CONV3_DMA"); return !(e && e[0] == '0'); }();   // A/B knob
-    if (dtype != GCSSL_F32 && use_dma() && dma3) {             // LDS-DMA pipeline (MODE 2 of conv_dma_kernel)
+    if (!gcssl_f32_storage(dtype) && use_dma() && dma3) {             // LDS-DMA pipeline (MODE 2 of conv_dma_kernel)
 #define DMA3(T) do { \
         if (Cin < 64) {                                        /* 8-channel first layer: a K tile spans several taps */ \
             if (big) GCSSL_LAUNCH((conv_dma_kernel<T, 128, 64, 2, 2, 2, true>), grid, dim3(256), 0, st, p); \
@@ -3361,8 +3484,9 @@ int gcssl_conv3x3_fwd(int dtype, const void* x, int ldx, const void* w, const fl
 #undef DMA3
         return gcssl_launch_status();
     }
-    GCSSL_DISPATCH(dtype, if (big) GCSSL_LAUNCH((conv_fwd_kernel<T, 128, 64, 3>), grid, dim3(NT), 0, st, p);
-                          else GCSSL_LAUNCH((conv_fwd_kernel<T, 64, 64, 3>), grid, dim3(NT), 0, st, p));
+    set_mm_scales(p, true);
+    GCSSL_DISPATCH_CONV(dtype, if (big) GCSSL_LAUNCH((conv_fwd_kernel<T, 128, 64, 3, MM>), grid, dim3(NT), 0, st, p);
+                               else GCSSL_LAUNCH((conv_fwd_kernel<T, 64, 64, 3, MM>), grid, dim3(NT), 0, st, p));
     return gcssl_launch_status();
 }
 
@@ -3388,8 +3512,8 @@ int gcssl_conv3x3_wgrad(int dtype, const void* x, int ldx, const void* dy, int l
     const int nsplit = gcssl_conv3x3_wgrad_splits(N, H, W, Cin, Cout);
     if (nsplit <= 0) return GCSSL_EBADSHAPE;
     if (ldx < Cin || lddy < Cout) return GCSSL_EBADSHAPE;
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    const int kv = dtype == GCSSL_F32 ? 4 : 8;
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
+    const int kv = gcssl_f32_storage(dtype) ? 4 : 8;
     if (ldx % kv || lddy % kv || !aligned16(x) || !aligned16(dy)) return GCSSL_EALIGN;
     ConvParams p{}; p.x = x; p.w = dy; p.y = slab; p.ldx = ldx; p.ldw = lddy;
     p.xcd_remap = wgrad_xcd();
@@ -3398,13 +3522,14 @@ int gcssl_conv3x3_wgrad(int dtype, const void* x, int ldx, const void* dy, int l
     p.M = N * H * W;
     if (!fill_bytes(p, (size_t)N * H * W * ldx, (size_t)N * H * W * lddy, kv == 4 ? 4 : 2)) return GCSSL_EBADSHAPE;
     const int nkt = (p.M + 63) / 64;
-    p.ktiles_per_split = ((nkt + nsplit - 1) / nsplit) * (64 / (dtype == GCSSL_F32 ? BKOf<float>::v : BKOf<bf16_t>::v));
+    p.ktiles_per_split = ((nkt + nsplit - 1) / nsplit) * (64 / (gcssl_f32_storage(dtype) ? BKOf<float>::v : BKOf<bf16_t>::v));
+    set_mm_scales(p, false);
     hipStream_t st = (hipStream_t)stream;
     const int bm = Cout >= 128 ? 128 : 64, bn = Cin >= 128 ? 128 : 64;
     const bool smallc = Cin == 8;
     dim3 grid(Cout / bm, smallc ? 1 : 9 * (Cin / bn), nsplit);
-#define WG(T, A, B, S) GCSSL_LAUNCH((conv_wgrad_kernel<T, A, B, S, 3>), grid, dim3(NT), 0, st, p)
-    GCSSL_DISPATCH(dtype,
+#define WG(T, A, B, S) GCSSL_LAUNCH((conv_wgrad_kernel<T, A, B, S, 3, MM>), grid, dim3(NT), 0, st, p)
+    GCSSL_DISPATCH_CONV(dtype,
         if (smallc) { if (bm == 128) WG(T, 128, 128, true); else WG(T, 64, 128, true); }
         else if (bm == 128 && bn == 128) WG(T, 128, 128, false); else if (bm == 128) WG(T, 128, 64, false);
         else if (bn == 128) WG(T, 64, 128, false); else WG(T, 64, 64, false));

@@ -154,7 +154,9 @@ class StepEngine:
             raise ValueError("img size must be a power of two >= 32 (the reference raises below 32: SURVEY §0)")
         self.B, self.S, self.c = batch, size, n_critic
         self.dev = torch.device(device)
-        self.code = _lib.dtype_code(dtype)
+        self.code = _lib.dtype_code(dtype)                          # storage dtype of activations / every non-conv kernel
+        self.mma = _lib.mma_code(dtype)                             # what the conv entry points get: != code in the split modes
+        self.mode = _lib.dtype_name(self.mma)
         self.T = _lib.torch_dtype(self.code)
         self.lr, self.betas = lr, betas
         self.delta_scale, self.lambda_gp, self.lambda_iou = delta_scale, lambda_gp, lambda_iou
@@ -169,10 +171,12 @@ class StepEngine:
         # scale is B hw / 8 (32 at B=256, 32x32: peak ~4e3 of the 65504 ceiling, a few % of the entries below the normal
         # range), and fp16 stores saturate instead of producing inf (common.h).  Powers of two: exact.
         f16 = self.code == _lib.F16
+        x3h = self.mma == _lib.F32_F16X3            # fp16 halves of fp32 operands: the same range argument, but nothing is STORED
+        #                                             in fp16, so the scale only has to keep the peaks under 65504 at conversion
         pow2 = lambda v: float(2 ** round(math.log2(max(v, 1.0))))
         hw5 = (size // 16 - 1) ** 2
-        self.loss_scale_d = float(os.environ.get("GCSSL_LOSS_SCALE_D", pow2(batch * hw5 / 8.0) if f16 else 1.0))
-        self.loss_scale_g = float(os.environ.get("GCSSL_LOSS_SCALE_G", pow2(batch * size * size) if f16 else 1.0))
+        self.loss_scale_d = float(os.environ.get("GCSSL_LOSS_SCALE_D", pow2(batch * hw5 / 8.0) if f16 else pow2(batch * hw5) if x3h else 1.0))
+        self.loss_scale_g = float(os.environ.get("GCSSL_LOSS_SCALE_G", pow2(batch * size * size) if (f16 or x3h) else 1.0))
         self.keep_clipped_grads = keep_clipped_grads     # write g*clip_coef back like clip_grad_norm_ does (not needed to step)
         _lib.lib()                                                  # fail loudly now if the HIP library is missing
         _lib.call_nostream("gcssl_init")                            # dynamic-LDS opt-ins, before any graph capture
@@ -277,6 +281,8 @@ class StepEngine:
 
     def _conv(self, label: str, flops: float, fn, *args, _bytes=None, **kw):
         """_bytes: (algorithmic, stored) bytes of the launch when its argument list does not show them (fused launches)"""
+        if self.mma != self.code and fn in ops.CONV_FNS:
+            kw["dt"] = self.mma                                     # split-precision modes: fp32 tensors, 3 x 16-bit MFMA contraction
         if self.probe is None:
             return fn(*args, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -326,7 +332,7 @@ class StepEngine:
         ho, c = (hi // 2, cout) if kind == "fwd" else (hi, cin)
         need = n_full
         for n in ns:
-            need = max(need, n * ops.conv_splits(kind, self.code, n, hi, cin, cout))
+            need = max(need, n * ops.conv_splits(kind, self.mma, n, hi, cin, cout))
         buf = torch.empty(need, ho, ho, c, device=self.dev, dtype=torch.float32)
         z = buf[:n_full]
         self._zcap[z.data_ptr()] = (buf.numel(), n_full)
@@ -340,7 +346,7 @@ class StepEngine:
         if grad and not self.grad_slabs:                           # (A/B knob GCSSL_GRAD_SLABS=0: gradient chains keep atomics)
             return 1, 0
         if key not in self._splits:
-            ks = ops.conv_splits(kind, self.code, n, hi, cin, cout)
+            ks = ops.conv_splits(kind, self.mma, n, hi, cin, cout)
             per = n * z.shape[1] * z.shape[2] * z.shape[3]
             # (the fused InstanceNorm kernels that add the slabs handle maps up to 16x16 -- 8x8 for the double backward;
             # larger ones keep the atomic form)
@@ -1051,12 +1057,13 @@ class StepEngine:
 
     # ------------------------------------------------------------------------------------------ iteration
     def run_iteration(self, pred, gt, delta_true, pred_box, refine_fn, alphas=None, masks=None, on_critic=None,
-                      next_forward: bool = False):
+                      next_forward: bool = False, next_pred=None):
         """Enqueue one full iteration (n_critic D steps + 1 G step); no host sync, nothing read back.
 
         next_forward (GraphedIteration's pipelined single-GPU form, device-drawn masks only): the iteration's batched generator
         forward has ALREADY run (by the previous call, or a prologue); this call instead ends its generator branch with the
-        NEXT iteration's batched forward -- right behind the generator update, beside the rest of the critic's work."""
+        NEXT iteration's batched forward -- right behind the generator update, beside the rest of the critic's work -- on
+        `next_pred`, the next iteration's input (default: this one's, a fixed batch)."""
         branch = self.overlap_g and self.batch_g and self.probe is None and self.allreduce is None
         sn_early = branch and self.overlap_g >= 2
         if sn_early:
@@ -1115,7 +1122,7 @@ class StepEngine:
                     # software pipelining across iterations: G's weights are final for this iteration, the critic steps have
                     # taken their deltas (ev_pre) and the backward has read the activations, so the NEXT iteration's batched
                     # forward can overwrite them now -- beside the last critic step's gradient work and the value-only forward
-                    self.g_forward_all(pred, None)
+                    self.g_forward_all(pred if next_pred is None else next_pred, None)
             if next_forward:
                 torch.cuda.current_stream().wait_event(ev_gm)
             else:
@@ -1181,11 +1188,26 @@ class GraphedIteration:
     step are captured once (torch.cuda.CUDAGraph == hipGraph on ROCm; our ctypes launches go to the capturing stream)
     and replayed.  Single-GPU runs are ONE graph per iteration.  With data parallelism the iteration is cut where a
     collective's result is needed: only the all-reduce launches and the stream waits sit between the segments, the
-    clip+Adam updates are captured at the head of the segment that consumes them.  Inputs are static device tensors; alpha and dropout masks are drawn on the
-    device inside the graph (torch's graph-safe Philox / the counter-based mask kernel), so every replay differs."""
+    clip+Adam updates are captured at the head of the segment that consumes them.  alpha and dropout masks are drawn on the
+    device inside the graph (the counter-based generators keyed by the device-side step count), so every replay differs.
+
+    Inputs.  The captured launches read the four tensors given here (`pred, gt, delta_true, pred_box`: static device buffers).
+    ``replay()`` with no arguments re-runs the iteration on whatever they hold -- bench.py's fixed synthetic batch.  A training
+    loop feeds a new batch per iteration with ``replay(batch=(pred, gt, delta_true, pred_box), next_pred=<pred of the NEXT
+    batch>)``: `batch` is copied into the static buffers, and `next_pred` into a second static buffer that the PIPELINED forms'
+    trailing generator forward reads (those forms end replay i with the batched generator forward of iteration i + 1, so they
+    need that input one replay early).  A replay that was not told its successor's input -- or one that follows an eager
+    `run_iteration` / a load of new weights -- cannot be pipelined into: the next replay then first re-runs the forward on its own
+    batch (the prologue graph), which is correct and costs one generator forward.  GCSSL_CHECK_STAGING=1 verifies (host sync)
+    that a batch's `pred` is what the previous replay was given as `next_pred`."""
 
     def __init__(self, eng: "StepEngine", pred, gt, delta_true, pred_box, refine_fn):
         self.eng = eng
+        self.inputs = (pred, gt, delta_true, pred_box)
+        self.pred_next = pred.clone()                              # what the pipelined forms' trailing generator forward reads
+        self._staged = False                                       # did the previous replay get its successor's input?
+        self._primed, self.pipelined = False, False
+        self._check_staging = os.environ.get("GCSSL_CHECK_STAGING", "0") != "0"
         self.fused_update = eng.allreduce is None
         # A capture must not depend on host-side state that differs between capture time and replay time.  With
         # keep_clipped_grads the updates leave the CLIPPED gradient in the bucket (clip_grad_norm_ semantics), so every
@@ -1221,7 +1243,7 @@ class GraphedIteration:
                 eng._d_dirty = True                               # (capture-time host state must not skip the re-packs)
                 if not self.pipelined:
                     eng._g_dirty = True
-                eng.run_iteration(pred, gt, delta_true, pred_box, refine_fn, next_forward=self.pipelined)
+                eng.run_iteration(pred, gt, delta_true, pred_box, refine_fn, next_forward=self.pipelined, next_pred=self.pred_next)
             # GCSSL_TWO_STREAM (default on, pipelined form only): the same launches in the same dependency order as FOUR LINEAR
             # graphs on two streams instead of one graph with a parallel branch --
             #   this stream:  [Ca: critic steps 0..c-2, d_pre of the last]  [Cb: last critic step, value-only forward]
@@ -1252,7 +1274,7 @@ class GraphedIteration:
                     self.c_a = capture(seg_a)
                     self.c_b = capture(lambda: (eng.d_main(), eng.d_update(), eng.g_critic(pred)))
                     pool = pool_g
-                    self.g_b = capture(lambda: (eng.g_update(), eng.g_forward_all(pred, None)))
+                    self.g_b = capture(lambda: (eng.g_update(), eng.g_forward_all(self.pred_next, None)))
                 finally:
                     eng._in_g_branch = False
                 self.ev_cb = self.ev_gb = None
@@ -1296,14 +1318,16 @@ class GraphedIteration:
         #   side:            [g_main ...................]                   join^
         # GCSSL_DP_BRANCH=0: the round-2 schedule (generator halves serial under the critic's all-reduces).
         self.dp_branch = eng.batch_g and os.environ.get("GCSSL_DP_BRANCH", "1") != "0"
-        # GCSSL_DP_PIPELINE (default on): the single-GPU two-stream schedule with the exchanges in it -- the generator's chain
+        # GCSSL_DP_PIPELINE=1 (default OFF since round 4: it issues collectives on TWO RCCL communicators from two streams with
+        # nothing ordering them on the device -- a documented hang hazard that no multi-rank RCCL run has ever exercised; the
+        # default is the single-communicator dp_branch schedule below): the single-GPU two-stream schedule with the exchanges in it -- the generator's chain
         # (backward, all-reduce of ITS gradient on a communicator of its own, update, the NEXT iteration's batched forward) runs
         # whole on the second stream beside the critic's, so no generator launch is left on the critic's stream and the 25-MB
         # exchange never queues in front of a critic exchange:
         #   main: [d_pre0 d_main0] AR(D) [d_pre1] wait [updD d_main1] AR(D) .............. wait(D) [updD g_critic]
         #   side: [g_main] AR'(G) ........................ wait(last d_pre, G) [updG  Gfwd i+1]          (AR' = second process group)
         # The collectives of a group are issued in the same program order on every rank.
-        self.dp_pipeline = (self.dp_branch and os.environ.get("GCSSL_DP_PIPELINE", "1") != "0" and
+        self.dp_pipeline = (self.dp_branch and os.environ.get("GCSSL_DP_PIPELINE", "0") != "0" and
                             getattr(eng.allreduce, "group", "x") != "x" and torch.distributed.is_initialized())
         if self.dp_pipeline:
             c = eng.c
@@ -1324,7 +1348,7 @@ class GraphedIteration:
                     self.upd_main.append(capture(lambda: (eng.d_update(gs), eng.d_main())))
                 self.upd_crit = capture(lambda: (eng.d_update(gs), eng.g_critic(pred)))
                 pool = pool_g
-                self.g_b = capture(lambda: (eng.g_update(gs), eng.g_forward_all(pred, None)))
+                self.g_b = capture(lambda: (eng.g_update(gs), eng.g_forward_all(self.pred_next, None)))
             finally:
                 eng._in_g_branch = False
             return
@@ -1359,13 +1383,40 @@ class GraphedIteration:
         self.upd_crit = capture(lambda: (eng.d_update(gs), eng.g_critic(pred)))
         self.upd_g = capture(lambda: eng.g_update(gs))
 
-    def replay(self):
+    def _stage(self, batch, next_pred) -> None:
+        """Copy a new batch / the next batch's generator input into the static buffers (on the caller's stream, which every
+        launch of the replay is ordered behind) and decide whether the pending pipelined forward is this iteration's."""
         eng = self.eng
+        if batch is not None:
+            if self.pipelined and self._staged and self._check_staging and not torch.equal(self.pred_next, batch[0]):
+                raise RuntimeError("GraphedIteration.replay: this batch's pred is not what the previous replay got as next_pred")
+            for dst, src in zip(self.inputs, batch):
+                if src is not dst:
+                    dst.copy_(src, non_blocking=True)
+        if not self.pipelined:
+            return
+        # the forward the previous replay left pending is usable iff it ran on THIS iteration's input with the current weights
+        # and nothing has overwritten its activations since: the previous replay was told this batch (or both run on the
+        # unchanged static buffers), and no eager iteration / generator forward touched the engine in between
+        ok = self._primed and eng._gall_valid and (self._staged if batch is not None else not self._staged)
+        if next_pred is not None:
+            self.pred_next.copy_(next_pred, non_blocking=True)
+        elif batch is not None or self._staged:
+            self.pred_next.copy_(self.inputs[0], non_blocking=True)   # no successor announced: assume the same batch again
+        self._staged = next_pred is not None
+        self._primed = ok
+
+    def replay(self, batch=None, next_pred=None):
+        """One iteration.  batch: optional (pred, gt, delta_true, pred_box) for this iteration; next_pred: the NEXT iteration's
+        generator input, for the pipelined forms (class docstring)."""
+        eng = self.eng
+        self._stage(batch, next_pred)
         if self.fused_update and getattr(self, "two_stream", False):
             main, side = torch.cuda.current_stream(), self.side
             if not self._primed:
-                self.prologue.replay()                            # the first iteration's batched generator forward
+                self.prologue.replay()                            # this iteration's batched generator forward (first replay / re-prime)
                 self._primed = True
+            eng._gall_valid = True                                # (host flag: every replay leaves the next iteration's forward pending)
             ev0 = torch.cuda.Event(); ev0.record(main)            # (Gb(i-1) and Cb(i-1) are ordered in front of this: see the tail)
             side.wait_event(ev0)
             with torch.cuda.stream(side):
@@ -1382,17 +1433,20 @@ class GraphedIteration:
             main.wait_event(ev_gb)                                # the caller's stream sees the whole iteration
             return
         if self.fused_update:
-            if getattr(self, "pipelined", False) and not self._primed:
-                self.prologue.replay()                            # the first iteration's batched generator forward
+            if self.pipelined and not self._primed:
+                self.prologue.replay()                            # this iteration's batched generator forward (first replay / re-prime)
                 self._primed = True
+            if self.pipelined:
+                eng._gall_valid = True                            # (host flag: the replay leaves the next iteration's forward pending)
             for g in self.graphs:
                 g.replay()
             return
         if getattr(self, "dp_pipeline", False):
             main, side = torch.cuda.current_stream(), self.side
             if not self._primed:
-                self.prologue.replay()                            # the first iteration's batched generator forward
+                self.prologue.replay()                            # this iteration's batched generator forward (first replay / re-prime)
                 self._primed = True
+            eng._gall_valid = True                                # (host flag: every replay leaves the next iteration's forward pending)
             ev0 = torch.cuda.Event(); ev0.record(main)            # (the previous replay ended with main behind its g_b)
             side.wait_event(ev0)
             with torch.cuda.stream(side):

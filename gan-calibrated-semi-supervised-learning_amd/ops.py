@@ -70,12 +70,14 @@ def prep_c5_weight(w, wp):
 
 
 # ---- conv k4 s2 p1
-def conv_fwd(x, wf, y, cin, cout, bias=None, gscale=None, group_n=0, act=0, split_stride=0):
+def conv_fwd(x, wf, y, cin, cout, bias=None, gscale=None, group_n=0, act=0, split_stride=0, dt=None):
     """y may be fp32 while x is bf16 (pre-InstanceNorm tensors are kept in fp32).  split_stride > 0: a K-split launch
-    stores its partial sums in fp32 slabs y + k*split_stride instead of adding atomically (see conv_splits)."""
+    stores its partial sums in fp32 slabs y + k*split_stride instead of adding atomically (see conv_splits).
+    dt: conv dtype code when it is not the tensors' own -- _lib.F32_F16X3 / F32_BF16X3, the split-precision MFMA modes on
+    fp32 tensors (the same keyword on conv_dgrad / conv_wgrad / conv3_fwd / conv3_wgrad)."""
     N, Hi, Wi, _ = x.shape
     out_f32 = 1 if (y.dtype == torch.float32 and x.dtype != torch.float32) else 0
-    call("gcssl_conv4x4s2_fwd", code(x), x, _ld(x), wf, bias, gscale, group_n, y, _ld(y), N, Hi, Wi, cin, cout, act,
+    call("gcssl_conv4x4s2_fwd", code(x) if dt is None else dt, x, _ld(x), wf, bias, gscale, group_n, y, _ld(y), N, Hi, Wi, cin, cout, act,
          out_f32, int(split_stride))
 
 
@@ -106,11 +108,11 @@ def conv_in_act_fwd(x, wf, a, mean, rstd, cin, cout, bias=None, gscale=None, gro
          _ld(apre) if apre is not None else 0, int(apre_n0), N, Hi, Wi, cin, cout, LRELU)
 
 
-def conv_dgrad(dy, wt, dx, cin, cout, gscale=None, group_n=0, split_stride=0):
+def conv_dgrad(dy, wt, dx, cin, cout, gscale=None, group_n=0, split_stride=0, dt=None):
     """dx: [N][Hi][Wi][>=cin] (fp32 output allowed whatever dy's dtype), dy: [N][Hi/2][Wi/2][>=cout]."""
     N, Hi, Wi, _ = dx.shape
     out_f32 = 1 if (dx.dtype == torch.float32 and dy.dtype != torch.float32) else 0
-    call("gcssl_conv4x4s2_dgrad", code(dy), dy, _ld(dy), wt, gscale, group_n, dx, _ld(dx), N, Hi, Wi, cin, cout, out_f32,
+    call("gcssl_conv4x4s2_dgrad", code(dy) if dt is None else dt, dy, _ld(dy), wt, gscale, group_n, dx, _ld(dx), N, Hi, Wi, cin, cout, out_f32,
          int(split_stride))
 
 
@@ -167,9 +169,9 @@ def wgrad_splits(N, Hi, Wi, cin, cout) -> int:
     return r
 
 
-def conv_wgrad(x, dy, slab, cin, cout):
+def conv_wgrad(x, dy, slab, cin, cout, dt=None):
     N, Hi, Wi, _ = x.shape
-    call("gcssl_conv4x4s2_wgrad", code(x), x, _ld(x), dy, _ld(dy), slab, N, Hi, Wi, cin, cout)
+    call("gcssl_conv4x4s2_wgrad", code(x) if dt is None else dt, x, _ld(x), dy, _ld(dy), slab, N, Hi, Wi, cin, cout)
 
 
 def wgrad_reduce(slab, nsplit, dw, cout, cin, cin_real, coef=None, cscale=None, u=None, v=None, nrank=0,
@@ -416,11 +418,11 @@ class Prep3Batch:
         call("gcssl_conv3x3_prep_weights", self.dt, self.n, self._w, self._wf, self._wt, self._co, self._ci, self._cp)
 
 
-def conv3_fwd(x, w, y, cin, cout, bias=None):
+def conv3_fwd(x, w, y, cin, cout, bias=None, dt=None):
     """3x3 s1 p1 conv (or, with the rotated-transposed pack and swapped channel counts, its data gradient)."""
     N, H, W, _ = x.shape
     out_f32 = 1 if (y.dtype == torch.float32 and x.dtype != torch.float32) else 0
-    call("gcssl_conv3x3_fwd", code(x), x, _ld(x), w, bias, y, _ld(y), N, H, W, cin, cout, out_f32)
+    call("gcssl_conv3x3_fwd", code(x) if dt is None else dt, x, _ld(x), w, bias, y, _ld(y), N, H, W, cin, cout, out_f32)
 
 
 def conv3_wgrad_splits(N, H, cin, cout) -> int:
@@ -430,9 +432,9 @@ def conv3_wgrad_splits(N, H, cin, cout) -> int:
     return r
 
 
-def conv3_wgrad(x, dy, slab, cin, cout):
+def conv3_wgrad(x, dy, slab, cin, cout, dt=None):
     N, H, W, _ = x.shape
-    call("gcssl_conv3x3_wgrad", code(x), x, _ld(x), dy, _ld(dy), slab, N, H, W, cin, cout)
+    call("gcssl_conv3x3_wgrad", code(x) if dt is None else dt, x, _ld(x), dy, _ld(dy), slab, N, H, W, cin, cout)
 
 
 class Reduce3Batch:
@@ -478,3 +480,7 @@ def mlp_head_fwd(feat, w1t, b1, w2t, b2, w3, b3, delta_scale, h1, h2, traw, delt
 def mlp_head_bwd(gdelta, traw, h1, h2, feat, w1, w2, w3, delta_scale, train, dp1, dp2, dp3, dfeat, dw1, db1, dw2, db2, dw3, db3):
     call("gcssl_mlp_head_bwd", gdelta, traw, h1, h2, feat, w1, w2, w3, float(delta_scale), int(bool(train)), dp1, dp2, dp3,
          dfeat, dw1, db1, dw2, db2, dw3, db3, feat.shape[0])
+
+
+#: the wrappers that take the conv dtype keyword `dt` (StepEngine injects its split-precision code into these)
+CONV_FNS = (conv_fwd, conv_dgrad, conv_wgrad, conv3_fwd, conv3_wgrad)

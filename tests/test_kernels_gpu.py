@@ -163,6 +163,73 @@ def test_conv_wgrad(ops, dt, tol, N, Hi, Cin, CinP, Cout):
     assert rel_err(dw2.cpu(), ref - corr) < tol_w
 
 
+# ---- split-precision conv modes (fp32 tensors; operands split hi + lo into 16-bit halves inside the kernel, 3 MFMAs per K step).
+# Against fp64 on UN-rounded fp32 operands: what is left is the dropped lo*lo term and the halves' own rounding -- fp16x3 keeps
+# 22 mantissa bits per operand (fp32-grade: the bound is the fp32 mode's), bf16x3 16 bits (2^-17 per operand, averaged over K).
+X3 = [("fp16x3", 2e-5), ("bf16x3", 6e-5)]
+X3_CASES = [c for c in CONV_CASES if c[0] <= 768 and c[1] <= 64] + [(768, 16, 64, 64, 128)]
+
+
+@pytest.mark.parametrize("mode,tol", X3)
+@pytest.mark.parametrize("N,Hi,Cin,CinP,Cout", X3_CASES)
+def test_conv_split_precision(ops, mode, tol, N, Hi, Cin, CinP, Cout):
+    lib = load_pkg("_lib")
+    code, f32 = lib.mma_code(mode), torch.float32
+    x = rnd(N, Cin, Hi, Hi, seed=1)
+    w = rnd(Cout, Cin, 4, 4, seed=2, scale=0.05)
+    b = rnd(Cout, seed=3, scale=0.1)
+    group_n = (N + 2) // 3
+    gs = torch.tensor([1.3, 0.7, 2.1])[: (N + group_n - 1) // group_n]
+    wf, wt = packed_weights(ops, w, f32, CinP)
+    xd = nhwc(x, f32, CinP)
+    # forward (with the activation epilogue, and the linear form the dispatcher may split over K: atomics / slabs)
+    y = torch.full((N, Hi // 2, Hi // 2, Cout), float("nan"), device="cuda")
+    ops.conv_fwd(xd, wf, y, CinP, Cout, bias=b.cuda(), gscale=gs.cuda(), group_n=group_n, act=1, dt=code)
+    lin = F.conv2d(x.double(), w.double(), None, 2, 1) * gs[torch.arange(N) // group_n].view(-1, 1, 1, 1).double() + b.view(1, -1, 1, 1).double()
+    assert rel_err(nchw(y), F.leaky_relu(lin, 0.2)) < tol
+    z = torch.full((N, Hi // 2, Hi // 2, Cout), float("nan"), device="cuda")
+    ops.conv_fwd(xd, wf, z, CinP, Cout, bias=b.cuda(), gscale=gs.cuda(), group_n=group_n, dt=code)
+    assert rel_err(nchw(z), lin) < tol
+    ks = ops.conv_splits("fwd", code, N, Hi, CinP, Cout)
+    if ks > 1:
+        slabs = torch.full((ks, N, Hi // 2, Hi // 2, Cout), float("nan"), device="cuda")
+        ops.conv_fwd(xd, wf, slabs[0], CinP, Cout, bias=b.cuda(), gscale=gs.cuda(), group_n=group_n, split_stride=slabs[0].numel(), dt=code)
+        assert rel_err(nchw(slabs.sum(0)), lin) < tol
+    # data gradient
+    dy = rnd(N, Cout, Hi // 2, Hi // 2, seed=4)
+    dyd = nhwc(dy, f32)
+    dx = torch.zeros(N, Hi, Hi, CinP, device="cuda")
+    ops.conv_dgrad(dyd, wt, dx, CinP, Cout, gscale=torch.tensor([0.9], device="cuda"), group_n=N, dt=code)
+    ref = F.conv_transpose2d(dy.double(), w.double(), None, 2, 1)
+    assert rel_err(nchw(dx)[:, :Cin], ref * 0.9) < tol
+    if CinP > Cin:
+        assert float(dx[..., Cin:].abs().max()) == 0.0
+    # weight gradient
+    ns = ops.wgrad_splits(N, Hi, Hi, CinP, Cout)
+    slab = torch.full((ns, Cout, 16, CinP), float("nan"), device="cuda")
+    ops.conv_wgrad(xd, dyd, slab, CinP, Cout, dt=code)
+    dw = torch.full((Cout, Cin, 4, 4), float("nan"), device="cuda")
+    ops.wgrad_reduce(slab, ns, dw, Cout, CinP, Cin)
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), conv2d_weight(x.double(), (Cout, Cin, 4, 4), dy.double(), 2, 1)) < tol
+
+
+def test_conv_split_precision_small_magnitudes(ops):
+    """fp16 halves have fp16's exponent range: operands far below 1 lose their lo bits to subnormals unless the engine's static
+    scales (loss scale on gradients, 2^6 on weights inside the kernel) keep them up.  Pinned here: gradients of magnitude 1e-3
+    (what a critic backward tensor looks like after the split modes' loss scale) still contract to fp32-grade accuracy."""
+    lib = load_pkg("_lib")
+    code = lib.mma_code("fp16x3")
+    N, Hi, Cin, Cout = 24, 16, 64, 128
+    w = rnd(Cout, Cin, 4, 4, seed=2, scale=0.05)
+    _, wt = packed_weights(ops, w, torch.float32, Cin)
+    dy = rnd(N, Cout, Hi // 2, Hi // 2, seed=4, scale=1e-3)
+    dx = torch.zeros(N, Hi, Hi, Cin, device="cuda")
+    ops.conv_dgrad(nhwc(dy, torch.float32), wt, dx, Cin, Cout, dt=code)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dx), F.conv_transpose2d(dy.double(), w.double(), None, 2, 1)) < 1e-4
+
+
 @pytest.mark.parametrize("dt,tol", DTS)
 @pytest.mark.parametrize("N,H,C,act", [(3, 8, 128, 1), (2, 2, 512, 1), (2, 32, 64, 2), (4, 4, 256, 2), (3, 16, 128, 1),
                                        (2, 64, 64, 2)])     # 64x64: beyond the LDS-resident form -> stats/finalize/apply

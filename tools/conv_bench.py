@@ -1,12 +1,15 @@
 """Standalone launcher of ONE conv configuration (for rocprofv3 --pmc / timing experiments).
-usage: python tools/conv_bench.py {fwd|fwd16|fwd_in|dgrad|wgrad} N Hi Cin Cout [dtype] [reps]
+usage: python tools/conv_bench.py {fwd|fwd16|fwd_in|dgrad|wgrad} N Hi Cin Cout [bf16|fp16|fp32|fp16x3|bf16x3] [reps]
 (fwd_in: the one-launch conv + InstanceNorm + LeakyReLU form, 16-bit activation + fp32 statistics out)"""
 import importlib, sys, time, torch
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 ops = importlib.import_module("gan-calibrated-semi-supervised-learning_amd.ops")
 kind, N, Hi, Cin, Cout = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[sys.argv[6] if len(sys.argv) > 6 else "bf16"]
+mode = sys.argv[6] if len(sys.argv) > 6 else "bf16"
+_lib = importlib.import_module("gan-calibrated-semi-supervised-learning_amd._lib")
+dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "fp16x3": torch.float32, "bf16x3": torch.float32}[mode]
+kw = {"dt": _lib.mma_code(mode)} if mode in _lib.SPLIT_MODES else {}      # split-precision modes: fp32 tensors, 3 x 16-bit MFMA
 reps = int(sys.argv[7]) if len(sys.argv) > 7 else 20
 x = (torch.rand(N, Hi, Hi, Cin, device="cuda") * 2 - 1).to(dt)
 dy = (torch.rand(N, Hi // 2, Hi // 2, Cout, device="cuda") * 2 - 1).to(dt)
@@ -20,11 +23,11 @@ slab = torch.empty(ns, Cout, 16, Cin, device="cuda")
 a16 = torch.empty(N, Hi // 2, Hi // 2, Cout, device="cuda", dtype=dt)
 mean = torch.empty(N, Cout, device="cuda"); rstd = torch.empty(N, Cout, device="cuda")
 def run():
-    if kind == "fwd": ops.conv_fwd(x, wf, y, Cin, Cout)
+    if kind == "fwd": ops.conv_fwd(x, wf, y, Cin, Cout, **kw)
     elif kind == "fwd16": ops.conv_fwd(x, wf, a16, Cin, Cout, act=1)          # 16-bit output + LeakyReLU (the norm-less first layers)
     elif kind == "fwd_in": ops.conv_in_act_fwd(x, wf, a16, mean, rstd, Cin, Cout)
-    elif kind == "dgrad": ops.conv_dgrad(dy, wt, dx, Cin, Cout)
-    else: ops.conv_wgrad(x, dy, slab, Cin, Cout)
+    elif kind == "dgrad": ops.conv_dgrad(dy, wt, dx, Cin, Cout, **kw)
+    else: ops.conv_wgrad(x, dy, slab, Cin, Cout, **kw)
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -33,4 +36,4 @@ for _ in range(reps): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 fl = 2.0 * N * (Hi // 2) ** 2 * Cout * 16 * Cin
-print(f"{kind} N={N} Hi={Hi} Cin={Cin} Cout={Cout} {dt}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF/s  {ops.last_kernel()}")
+print(f"{kind} N={N} Hi={Hi} Cin={Cin} Cout={Cout} {mode}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF/s  {ops.last_kernel()}")
