@@ -34,7 +34,10 @@ sys.path.insert(0, str(ROOT))
 PKG = "gan-calibrated-semi-supervised-learning_amd"
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}      # dense, /opt/skills/guides/MI355X_MICROARCH.md:42-43
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3,       # dense, /opt/skills/guides/MI355X_MICROARCH.md:42-43
+                    # split-precision modes: every algorithmic multiply-add is THREE 16-bit MFMA multiply-adds (hi*hi + lo*hi +
+                    # hi*lo), so the roof of the algorithmic FLOP rate is a third of the 16-bit pipe's
+                    "fp16x3": 2500.0 / 3, "bf16x3": 2500.0 / 3}
 F_D = {32: 0.0535e9, 64: 0.2141e9, 128: 0.8564e9}       # forward FLOPs / image
 F_G = {32: 0.2029e9, 64: 0.8116e9, 128: 3.2464e9}
 T = torch.from_numpy
@@ -254,7 +257,7 @@ def engine_mod_roofline_bound(label):
 
 
 def dtype_symbol(dtype):
-    return {"bf16": "__bf16", "fp16": "_Float16", "fp32": "float"}[dtype]
+    return {"bf16": "__bf16", "fp16": "_Float16", "fp32": "float", "fp16x3": "float", "bf16x3": "float"}[dtype]
 
 
 def main():
@@ -265,8 +268,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--size", type=int, default=32)
     ap.add_argument("--n_critic", type=int, default=2)
-    ap.add_argument("--dtype", default=os.environ.get("GCSSL_BENCH_DTYPE", "bf16"), choices=["bf16", "fp16", "fp32"],
-                    help="MFMA operand type of the headline (BASELINE configs[1] names bf16)")
+    ap.add_argument("--dtype", default=os.environ.get("GCSSL_BENCH_DTYPE", "bf16"), choices=["bf16", "fp16", "fp32", "fp16x3", "bf16x3"],
+                    help="MFMA operand type of the headline (BASELINE configs[1] names bf16); fp16x3 / bf16x3: fp32 tensors, operands "
+                         "split hi + lo inside the conv kernels, 3 MFMAs per K step (the parity-grade throughput modes)")
     ap.add_argument("--generator", default="unet", choices=["unet", "simple"],
                     help="generator_type (cgan/cgan_train_enhanced.py:26-31); the headline config is the default U-Net")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")

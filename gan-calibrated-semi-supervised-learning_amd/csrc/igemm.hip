@@ -117,7 +117,7 @@ template <int ROWS> struct MMajor<f16_t, ROWS> : MMajor16<f16_t, ROWS> {};
 // ------------------------------------------------------------------------------------------
 // SPLIT-PRECISION tiles (MM = 1: fp16 hi + lo, MM = 2: bf16 hi + lo; the "fp16x3" / "bf16x3" modes).  Tensors stay fp32 in
 // HBM exactly as in the fp32 parity mode; a loaded 4-float vector is split ONCE, on its way into LDS, into
-//   hi = rne16(x * s),  lo = rne16(x * s - hi)         (s: a power of two per operand, exact; undone in the epilogue)
+//   hi = rne16(x),  lo = rne16(x - hi)
 // and the 32 real K elements of a tile row become one 128-byte row [hi k0..31 | lo k0..31] -- the 16-bit KMajor16 / MMajor16
 // layouts with four physical 16-deep K steps (0, 1 = hi; 2, 3 = lo).  The contraction then runs on the 2.5-PFLOP/s 16-bit
 // MFMA pipe as THREE products per real K step, A_hi B_hi + A_lo B_hi + A_hi B_lo (A_lo B_lo is below fp32's own rounding),
@@ -128,11 +128,33 @@ template <int ROWS> struct MMajor<f16_t, ROWS> : MMajor16<f16_t, ROWS> {};
 template <int MM> struct SplitH;
 template <> struct SplitH<1> { typedef f16_t type; };
 template <> struct SplitH<2> { typedef bf16_t type; };
-template <typename H> __device__ __forceinline__ void split4(const float4& v, float s, uint2& hi, uint2& lo) {
-    const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
-    hi.x = pack2<H>(x0, x1); hi.y = pack2<H>(x2, x3);
-    lo.x = pack2<H>(x0 - Bits16<H>::dec(hi.x), x1 - Bits16<H>::dec(hi.x >> 16));
-    lo.y = pack2<H>(x2 - Bits16<H>::dec(hi.y), x3 - Bits16<H>::dec(hi.y >> 16));
+// 4 floats -> 4 hi + 4 lo halves, 5 vector instructions per PAIR: v_cvt_pk_{f16,bf16}_f32 (RNE), two widenings, one
+// v_pk_add_f32, one v_cvt_pk.  No clamp: an operand beyond fp16's range becomes inf, its residual -inf, the product NaN -- loud
+// (the engine's finite checks), where a saturated value would be silently wrong; the static scales keep operands in range.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <typename H> struct Half2;
+template <> struct Half2<f16_t> {
+    typedef __attribute__((ext_vector_type(2))) _Float16 V;
+    __device__ static __forceinline__ f32x2 widen(V h) { return __builtin_convertvector(h, f32x2); }
+};
+template <> struct Half2<bf16_t> {
+    typedef __attribute__((ext_vector_type(2))) __bf16 V;
+    __device__ static __forceinline__ f32x2 widen(V h) {
+        const unsigned u = __builtin_bit_cast(unsigned, h);
+        f32x2 r = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xFFFF0000u)};
+        return r;
+    }
+};
+template <typename H> __device__ __forceinline__ void split2(f32x2 x, unsigned& hi, unsigned& lo) {
+    typedef typename Half2<H>::V V;
+    const V h = __builtin_convertvector(x, V);
+    const V l = __builtin_convertvector(x - Half2<H>::widen(h), V);
+    hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
+}
+template <typename H> __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
+    f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+    split2<H>(a, hi.x, lo.x);
+    split2<H>(b, hi.y, lo.y);
 }
 template <typename H, int ROWS> struct KMajorSplit {
     static constexpr int BK = 32;                             // REAL K elements per tile (fp32 in memory)
@@ -142,9 +164,9 @@ template <typename H, int ROWS> struct KMajorSplit {
     uint4 d[ROWS * 8];
     __device__ static int swz(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
     // chunk: which 4-float vector of the row's 32 (0..7)
-    __device__ void store_vec(int row, int chunk, const Vec16<float>& v, float s) {
+    __device__ void store_vec(int row, int chunk, const Vec16<float>& v) {
         uint2 hi, lo;
-        split4<H>(v.v, s, hi, lo);
+        split4<H>(v.v, hi, lo);
         uint2* b = reinterpret_cast<uint2*>(d);
         b[swz(row, chunk >> 1) * 2 + (chunk & 1)] = hi;
         b[swz(row, 4 + (chunk >> 1)) * 2 + (chunk & 1)] = lo;
@@ -161,9 +183,9 @@ template <typename H, int ROWS> struct MMajorSplit {
     typedef typename Frag16<H>::type Frag;
     __attribute__((aligned(16))) unsigned char d[64 * STRIDE];   // k-rows 0..31: hi, 32..63: lo
     // chunk: which 4-row vector of k-row k (rows 4 chunk .. 4 chunk + 3)
-    __device__ void store_vec(int k, int chunk, const Vec16<float>& v, float s) {
+    __device__ void store_vec(int k, int chunk, const Vec16<float>& v) {
         uint2 hi, lo;
-        split4<H>(v.v, s, hi, lo);
+        split4<H>(v.v, hi, lo);
         *reinterpret_cast<uint2*>(d + k * STRIDE + chunk * 8) = hi;
         *reinterpret_cast<uint2*>(d + (k + 32) * STRIDE + chunk * 8) = lo;
     }
@@ -187,12 +209,6 @@ template <int ROWS> struct KTile<float, ROWS, 2> { typedef KMajorSplit<bf16_t, R
 template <typename T, int ROWS, int MM> struct MTile { typedef MMajor<T, ROWS> type; };
 template <int ROWS> struct MTile<float, ROWS, 1> { typedef MMajorSplit<f16_t, ROWS> type; };
 template <int ROWS> struct MTile<float, ROWS, 2> { typedef MMajorSplit<bf16_t, ROWS> type; };
-// store a fetched vector into a tile: the split tiles take the operand's power-of-two pre-scale
-template <class Tile, class V> __device__ __forceinline__ auto tile_store(Tile& t, int r, int c, const V& v, float s)
-    -> decltype(t.store_vec(r, c, v, s)) { t.store_vec(r, c, v, s); }
-template <class Tile, class V> __device__ __forceinline__ auto tile_store(Tile& t, int r, int c, const V& v, ...)
-    -> decltype(t.store_vec(r, c, v)) { t.store_vec(r, c, v); }
-
 // Branch-free gather loads.  hipcc turns `ok ? load(p) : 0` into an exec-mask branch per load (each with its own
 // vmcnt drain), which serialises the whole tile fetch; a raw buffer load with an out-of-range offset returns 0 in
 // hardware instead, so every lane always issues the load and validity is a single v_cndmask on the offset.
@@ -357,8 +373,8 @@ struct ConvParams {
                                           // output BEFORE the activation backward: gcssl_dot_accum folded in), nullable
     int kcap;                             // timing experiment (GCSSL_KCAP, 3x3 persistent form only; results are garbage): walk only the
                                           // first kcap K steps of every tile -- the K volume a Winograd F(2x2,3x3) GEMM stage would have
-    float mm_ascale, mm_bscale, mm_oscale; // split-precision forms (MM != 0): power-of-two pre-scales of the two operands on their way
-                                          // into LDS and their inverse product, applied to the accumulators in the epilogue
+    float mm_oscale;                      // split-precision forms (MM != 0): the packed weights carry a power-of-two pre-scale
+                                          // (gcssl_prep_conv_weights with a split dtype); its inverse, applied in the epilogue
     void* in_apre; int ld_apre, apre_n0;  // optional second output: the activation WITHOUT dropout for samples n >= apre_n0
                                           // ([N - apre_n0][Ho*Wo][ld_apre]): what the backward rebuilds xhat from
 };
@@ -367,21 +383,29 @@ struct ConvParams {
 // forward: y[m][co] = act( gscale[g(m)] * sum_{tap,ci} x[n, 2oy-1+ky, 2ox-1+kx, ci] Wf[co][tap][ci] + bias[co] )
 // GEMM M = N*Ho*Wo, N = Cout, K = 16*Cin
 // ------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int KS = 4, int MM = 0>
-__global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
+// WM x WN waves (default 2 x 2 = the 256 threads of NT; the split-precision forms also run 4 x 2: a K step of theirs is issue-bound
+// -- MFMA phase, then split + LDS stores -- and with two waves per SIMD inside a workgroup one wave's VALU work runs under the other's MFMAs)
+template <typename T, int BM, int BN, int KS = 4, int MM = 0, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(WM * WN * 64, MM ? (WM * WN >= 8 ? 4 : 2) : 1) void conv_fwd_kernel(ConvParams p) {
     typedef Geo<KS> G;
+    constexpr int NT = WM * WN * 64;
     constexpr int BK = BKOf<T>::v;
     constexpr int KV = Elem<T>::KV, CH = BK / KV, RPT = NT / CH;   // rows covered per pass
     constexpr int NVA = BM / RPT, NVB = BN / RPT;
-    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(NVA >= 1 && NVB >= 1 && TM >= 1 && TN >= 1, "tile too small for this many waves");
     __shared__ typename KTile<T, BM, MM>::type As[2];
     __shared__ typename KTile<T, BN, MM>::type Bs[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
     const T* x = static_cast<const T*>(p.x);
     const T* w = static_cast<const T*>(p.w);
-    const int chunk = tid % CH, row_t = tid / CH;
+    // split tiles: a 16-lane group of ds_write_b64 (banks mod 32 = a 128-byte window) must not hold two rows whose hi (or lo)
+    // halves share a 64-byte half-row: rows R and R + 1 do (same swizzle), rows R and R + 8 do not (their swizzle differs by 4
+    // chunks) -- so lanes 8-15 of a group take row R + 8 instead of R + 1 (SQ_LDS_BANK_CONFLICT: a third of the LDS cycles before)
+    const int chunk = tid % CH;
+    const int row_t = MM ? (((tid >> 4) & 7) + 8 * ((tid >> 3) & 1) + 16 * (tid >> 7)) : tid / CH;
     const int K = KS == 4 ? 16 * p.Cin : p.wk;
     const int Ho = p.Hi / G::ST, Wo = p.Wi / G::ST;
 
@@ -407,22 +431,24 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
     unsigned wrow[NVB];
 #pragma unroll
     for (int j = 0; j < NVB; ++j) { const int co = n0 + row_t + j * RPT; wrow[j] = co < p.Cout ? (unsigned)(co * K * ES) : OOB; }
-    Vec16<T> ra[1][NVA], rb[1][NVB];
-    auto gload = [&](Vec16<T> (&qa)[NVA], Vec16<T> (&qb)[NVB], int k0) {
+    Vec16<T> ra[MM ? 2 : 1][NVA], rb[MM ? 2 : 1][NVB];
+    // live = false: a K tile past the end of this workgroup's range -- every offset out of range, the loads return zeros
+    // without touching memory (the split-precision pipeline issues its loads unconditionally: see its loop)
+    auto gload = [&](Vec16<T> (&qa)[NVA], Vec16<T> (&qb)[NVB], int k0, bool live = true) {
         const int k = k0 + chunk * KV;
         const int tap = k >> p.lgCin, ci = k & (p.Cin - 1);
         const int tapoff = ((G::ky(tap) * p.Wi + G::kx(tap)) * p.ldx + ci) * ES;
 #pragma unroll
         for (int i = 0; i < NVA; ++i)
-            qa[i] = bload<T>(xr, ((rowmask[i] >> tap) & 1u) ? (unsigned)(rowoff[i] + tapoff) : OOB);
+            qa[i] = bload<T>(xr, (live && ((rowmask[i] >> (tap & 31)) & 1u)) ? (unsigned)(rowoff[i] + tapoff) : OOB);
 #pragma unroll
-        for (int j = 0; j < NVB; ++j) qb[j] = bload<T>(wr, wrow[j] + (unsigned)(k * ES));
+        for (int j = 0; j < NVB; ++j) qb[j] = bload<T>(wr, live ? wrow[j] + (unsigned)(k * ES) : OOB);
     };
     auto lstore = [&](const Vec16<T> (&qa)[NVA], const Vec16<T> (&qb)[NVB], int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) tile_store(As[buf], row_t + i * RPT, chunk, qa[i], p.mm_ascale);
+        for (int i = 0; i < NVA; ++i) As[buf].store_vec(row_t + i * RPT, chunk, qa[i]);
 #pragma unroll
-        for (int j = 0; j < NVB; ++j) tile_store(Bs[buf], row_t + j * RPT, chunk, qb[j], p.mm_bscale);
+        for (int j = 0; j < NVB; ++j) Bs[buf].store_vec(row_t + j * RPT, chunk, qb[j]);
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -440,6 +466,45 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
     // landing in one register set (issued a whole iteration ago) and tile t+2 is being issued into the other.
     // (A two-tiles-ahead variant with a second register set was measured 1.5-1.9x SLOWER on the 128-wide tiles: it
     //  pushed them to 130-194 VGPRs and the lost occupancy cost more than the extra overlap bought.)
+    if constexpr (MM != 0) {
+        // split-precision forms: TWO K tiles of loads in flight (the second register set) -- these kernels are paced by their
+        // fill rate = bytes in flight / latency (fp32 operands: twice the bytes of a 16-bit tile), and their MFMA phase is three
+        // times as long, so a tile issued two steps ahead has landed when its turn to be split and stored comes
+        // Every load / split / LDS store of the loop is UNCONDITIONAL (tiles past the end load zeros from out-of-range offsets):
+        // a load behind a branch makes the compiler's s_waitcnt vmcnt assume it was not issued, so the split of the older tile
+        // waited for the tile issued a moment ago as well -- one exposed memory latency per K step (round 4: 2 us per step).
+        if (p.dbg) {                                               // timing experiments (GCSSL_X3_DEBUG; results are garbage):
+            const bool nold = p.dbg & 1, nomma = p.dbg & 2, nost = p.dbg & 4;   // 1 no global loads, 2 no MFMA phase, 4 no split + LDS stores
+            gload(ra[0], rb[0], t_beg * BK);
+            gload(ra[1], rb[1], (t_beg + 1) * BK, t_beg + 1 < t_end);
+            lstore(ra[0], rb[0], 0); lstore(ra[1], rb[1], 1); __syncthreads();
+            for (int t = t_beg; t < t_end; t += 2) {
+                if (!nold) gload(ra[0], rb[0], (t + 2) * BK, t + 2 < t_end);
+                if (!nomma) mma_slab<TM, TN>(As[0], Bs[0], wm0, wn0, lane, acc);
+                if (!nost) lstore(ra[1], rb[1], 1);
+                __syncthreads();
+                if (!nold) gload(ra[1], rb[1], (t + 3) * BK, t + 3 < t_end);
+                if (!nomma) mma_slab<TM, TN>(As[1], Bs[1], wm0, wn0, lane, acc);
+                if (!nost) lstore(ra[0], rb[0], 0);
+                __syncthreads();
+            }
+        } else
+        if (t_beg < t_end) {
+            gload(ra[0], rb[0], t_beg * BK);
+            gload(ra[1], rb[1], (t_beg + 1) * BK, t_beg + 1 < t_end);
+            lstore(ra[0], rb[0], 0); __syncthreads();
+            for (int t = t_beg; t < t_end; t += 2) {
+                gload(ra[0], rb[0], (t + 2) * BK, t + 2 < t_end);
+                mma_slab<TM, TN>(As[0], Bs[0], wm0, wn0, lane, acc);
+                lstore(ra[1], rb[1], 1);
+                __syncthreads();
+                gload(ra[1], rb[1], (t + 3) * BK, t + 3 < t_end);
+                if (t + 1 < t_end) mma_slab<TM, TN>(As[1], Bs[1], wm0, wn0, lane, acc);
+                lstore(ra[0], rb[0], 0);
+                __syncthreads();
+            }
+        }
+    } else
     if (t_beg < t_end) {
         gload(ra[0], rb[0], t_beg * BK); lstore(ra[0], rb[0], 0); __syncthreads();
         for (int t = t_beg; t < t_end; ++t) {
@@ -450,31 +515,53 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
             __syncthreads();
         }
     }
-    // epilogue (out_f32: the pre-norm tensor z stays fp32 in bf16 mode, see norm.hip)
+    // epilogue (out_f32: the pre-norm tensor z stays fp32 in bf16 mode, see norm.hip).  Everything the stores depend on is
+    // loaded FIRST (per-row group scale, per-column bias): a load between two stores cannot be hoisted by the compiler (the output
+    // may alias it), and one dependent load -> wait -> store round trip per row was most of a short-K launch (round 4: the
+    // split-precision modes run this kernel's K loop 3x faster than the fp32 MFMA did, and 32 such round trips per wave showed)
     T* y = static_cast<T*>(p.y);
     float* y32 = static_cast<float*>(p.y);
+    float sc[TM][16];
+    const float osc = MM ? p.mm_oscale : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[i][r] = osc;
+    if (p.gscale) {                                 // ONE uniform branch; inside it every lane loads (rows past M: the last sample's
+#pragma unroll                                      // group), so the loads go out back to back behind a single wait
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = min(m0 + wm0 + 32 * i + crow(r, lane), p.M - 1);
+                sc[i][r] = osc * p.gscale[(int)(((float)(m >> p.lgHoWo) + 0.5f) * p.inv_group_n)];
+            }
+    }
+    float bcol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn0 + 32 * j + (lane & 31);
+        bcol[j] = (p.bias && co < p.Cout && (p.ksplit <= 1 || ks == 0)) ? p.bias[co] : 0.f;
+    }
+    float* yk = y32 + (p.ksplit > 1 ? (size_t)ks * p.split_stride : 0);
+    const bool f32o = p.out_f32 || std::is_same<T, float>::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm0 + 32 * i + crow(r, lane);
             if (m >= p.M) continue;
-            float s = MM ? p.mm_oscale : 1.f;
-            if (p.gscale) s *= p.gscale[(m >> p.lgHoWo) / p.group_n];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int co = n0 + wn0 + 32 * j + (lane & 31);
                 if (co >= p.Cout) continue;
-                float v = acc[i][j][r] * s;
+                float v = acc[i][j][r] * sc[i][r] + bcol[j];
                 if (p.ksplit > 1) {                       // linear epilogue only: partial sums add up, bias once
-                    if (p.bias && ks == 0) v += p.bias[co];
-                    if (p.split_stride) y32[(size_t)ks * p.split_stride + (size_t)m * p.ldy + co] = v;
+                    if (p.split_stride) yk[(size_t)m * p.ldy + co] = v;
                     else atomicAdd(y32 + (size_t)m * p.ldy + co, v);
                     continue;
                 }
-                if (p.bias) v += p.bias[co];
                 if (p.act == 1) v = lrelu_f(v);
-                if (p.out_f32) y32[(size_t)m * p.ldy + co] = v;
+                if (f32o) y32[(size_t)m * p.ldy + co] = v;
                 else Elem<T>::st(y + (size_t)m * p.ldy + co, v);
             }
         }
@@ -485,12 +572,14 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(ConvParams p) {
 // One launch z-slice per output parity class (py,px); per class M = N*Ho*Wo, N = Cin, K = 4*Cout.
 //   ky = 1-py+2ty, oy = iy' + py - ty   (iy = 2 iy' + py), same in x.
 // ------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int MM = 0>
-__global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
+template <typename T, int BM, int BN, int MM = 0, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(WM * WN * 64, MM ? (WM * WN >= 8 ? 4 : 2) : 1) void conv_dgrad_kernel(ConvParams p) {
+    constexpr int NT = WM * WN * 64;
     constexpr int BK = BKOf<T>::v;
     constexpr int KV = Elem<T>::KV, CH = BK / KV, RPT = NT / CH;
     constexpr int NVA = BM / RPT, NVB = BN / RPT;
-    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(NVA >= 1 && NVB >= 1 && TM >= 1 && TN >= 1, "tile too small for this many waves");
     __shared__ typename KTile<T, BM, MM>::type As[2];
     __shared__ typename KTile<T, BN, MM>::type Bs[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -498,10 +587,14 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
     const int cls = p.ksplit > 1 ? (int)blockIdx.z / p.ksplit : (int)blockIdx.z;
     const int ks = p.ksplit > 1 ? (int)blockIdx.z % p.ksplit : 0;
     const int py = cls >> 1, px = cls & 1;
-    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
     const T* dy = static_cast<const T*>(p.x);
     const T* wt = static_cast<const T*>(p.w);
-    const int chunk = tid % CH, row_t = tid / CH;
+    // split tiles: a 16-lane group of ds_write_b64 (banks mod 32 = a 128-byte window) must not hold two rows whose hi (or lo)
+    // halves share a 64-byte half-row: rows R and R + 1 do (same swizzle), rows R and R + 8 do not (their swizzle differs by 4
+    // chunks) -- so lanes 8-15 of a group take row R + 8 instead of R + 1 (SQ_LDS_BANK_CONFLICT: a third of the LDS cycles before)
+    const int chunk = tid % CH;
+    const int row_t = MM ? (((tid >> 4) & 7) + 8 * ((tid >> 3) & 1) + 16 * (tid >> 7)) : tid / CH;
     const int Ho = p.Hi >> 1, Wo = p.Wi >> 1;
     const int K = 4 * p.Cout;
 
@@ -526,24 +619,24 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
     unsigned wrow[NVB];
 #pragma unroll
     for (int j = 0; j < NVB; ++j) { const int ci = n0 + row_t + j * RPT; wrow[j] = ci < p.Cin ? (unsigned)(ci * 16 * p.Cout * ES) : OOB; }
-    Vec16<T> ra[1][NVA], rb[1][NVB];
-    auto gload = [&](Vec16<T> (&qa)[NVA], Vec16<T> (&qb)[NVB], int k0) {
+    Vec16<T> ra[MM ? 2 : 1][NVA], rb[MM ? 2 : 1][NVB];
+    auto gload = [&](Vec16<T> (&qa)[NVA], Vec16<T> (&qb)[NVB], int k0, bool live = true) {      // (live: see conv_fwd_kernel)
         const int k = k0 + chunk * KV;
         const int t = k >> p.lgCout, co = k & (p.Cout - 1);
-        const int ty = t >> 1, tx = t & 1;
+        const int ty = (t >> 1) & 1, tx = t & 1;
         const int tap = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
         const int tapoff = (co - (ty * Wo + tx) * p.ldx) * ES;
 #pragma unroll
         for (int i = 0; i < NVA; ++i)
-            qa[i] = bload<T>(xr, ((rowmask[i] >> t) & 1u) ? (unsigned)(rowoff[i] + tapoff) : OOB);
+            qa[i] = bload<T>(xr, (live && ((rowmask[i] >> (t & 31)) & 1u)) ? (unsigned)(rowoff[i] + tapoff) : OOB);
 #pragma unroll
-        for (int j = 0; j < NVB; ++j) qb[j] = bload<T>(wr, wrow[j] + (unsigned)((tap * p.Cout + co) * ES));
+        for (int j = 0; j < NVB; ++j) qb[j] = bload<T>(wr, live ? wrow[j] + (unsigned)((tap * p.Cout + co) * ES) : OOB);
     };
     auto lstore = [&](const Vec16<T> (&qa)[NVA], const Vec16<T> (&qb)[NVB], int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) tile_store(As[buf], row_t + i * RPT, chunk, qa[i], p.mm_ascale);
+        for (int i = 0; i < NVA; ++i) As[buf].store_vec(row_t + i * RPT, chunk, qa[i]);
 #pragma unroll
-        for (int j = 0; j < NVB; ++j) tile_store(Bs[buf], row_t + j * RPT, chunk, qb[j], p.mm_bscale);
+        for (int j = 0; j < NVB; ++j) Bs[buf].store_vec(row_t + j * RPT, chunk, qb[j]);
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -559,6 +652,29 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
     // landing in one register set (issued a whole iteration ago) and tile t+2 is being issued into the other.
     // (A two-tiles-ahead variant with a second register set was measured 1.5-1.9x SLOWER on the 128-wide tiles: it
     //  pushed them to 130-194 VGPRs and the lost occupancy cost more than the extra overlap bought.)
+    if constexpr (MM != 0) {
+        // split-precision forms: TWO K tiles of loads in flight (the second register set) -- these kernels are paced by their
+        // fill rate = bytes in flight / latency (fp32 operands: twice the bytes of a 16-bit tile), and their MFMA phase is three
+        // times as long, so a tile issued two steps ahead has landed when its turn to be split and stored comes
+        // Every load / split / LDS store of the loop is UNCONDITIONAL (tiles past the end load zeros from out-of-range offsets):
+        // a load behind a branch makes the compiler's s_waitcnt vmcnt assume it was not issued, so the split of the older tile
+        // waited for the tile issued a moment ago as well -- one exposed memory latency per K step (round 4: 2 us per step).
+        if (t_beg < t_end) {
+            gload(ra[0], rb[0], t_beg * BK);
+            gload(ra[1], rb[1], (t_beg + 1) * BK, t_beg + 1 < t_end);
+            lstore(ra[0], rb[0], 0); __syncthreads();
+            for (int t = t_beg; t < t_end; t += 2) {
+                gload(ra[0], rb[0], (t + 2) * BK, t + 2 < t_end);
+                mma_slab<TM, TN>(As[0], Bs[0], wm0, wn0, lane, acc);
+                lstore(ra[1], rb[1], 1);
+                __syncthreads();
+                gload(ra[1], rb[1], (t + 3) * BK, t + 3 < t_end);
+                if (t + 1 < t_end) mma_slab<TM, TN>(As[1], Bs[1], wm0, wn0, lane, acc);
+                lstore(ra[0], rb[0], 0);
+                __syncthreads();
+            }
+        }
+    } else
     if (t_beg < t_end) {
         gload(ra[0], rb[0], t_beg * BK); lstore(ra[0], rb[0], 0); __syncthreads();
         for (int t = t_beg; t < t_end; ++t) {
@@ -569,6 +685,25 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
             __syncthreads();
         }
     }
+    // (epilogue: the per-row group scales are loaded before any store -- see conv_fwd_kernel)
+    float sc[TM][16];
+    const float osc = MM ? p.mm_oscale : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[i][r] = osc;
+    if (p.gscale) {                                 // ONE uniform branch; inside it every lane loads (rows past M: the last sample's
+#pragma unroll                                      // group), so the loads go out back to back behind a single wait
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = min(m0 + wm0 + 32 * i + crow(r, lane), p.M - 1);
+                sc[i][r] = osc * p.gscale[(int)(((float)(m >> p.lgHoWo) + 0.5f) * p.inv_group_n)];
+            }
+    }
+    float* y32 = static_cast<float*>(p.y);
+    float* yk = y32 + (p.ksplit > 1 ? (size_t)ks * p.split_stride : 0);
+    const bool f32o = p.out_f32 || std::is_same<T, float>::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -578,18 +713,16 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(ConvParams p) {
             const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
             const int iy = 2 * (rem >> p.lgWo) + py, ix = 2 * (rem & (Wo - 1)) + px;
             const size_t pix = (size_t)(n * p.Hi + iy) * p.Wi + ix;
-            float s = MM ? p.mm_oscale : 1.f;
-            if (p.gscale) s *= p.gscale[n / p.group_n];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int ci = n0 + wn0 + 32 * j + (lane & 31);
                 if (ci >= p.Cin) continue;
-                const float v = acc[i][j][r] * s;
+                const float v = acc[i][j][r] * sc[i][r];
                 if (p.ksplit > 1) {
-                    if (p.split_stride) static_cast<float*>(p.y)[(size_t)ks * p.split_stride + pix * p.ldy + ci] = v;
-                    else atomicAdd(static_cast<float*>(p.y) + pix * p.ldy + ci, v);
+                    if (p.split_stride) yk[pix * p.ldy + ci] = v;
+                    else atomicAdd(y32 + pix * p.ldy + ci, v);
                 }
-                else if (p.out_f32) static_cast<float*>(p.y)[pix * p.ldy + ci] = v;
+                else if (f32o) y32[pix * p.ldy + ci] = v;
                 else Elem<T>::st(static_cast<T*>(p.y) + pix * p.ldy + ci, v);
             }
         }
@@ -1114,7 +1247,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
 // ------------------------------------------------------------------------------------------
 // SMALLC (first layers, Cin padded to 8): the N tile is all 16 taps x 8 channels (BN must be 128).
 template <typename T, int BM, int BN, bool SMALLC, int KS = 4, int MM = 0>
-__global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
+__global__ __launch_bounds__(NT, MM ? 2 : 1) void conv_wgrad_kernel(ConvParams p) {
     typedef Geo<KS> G;
     constexpr int BK = BKOf<T>::v;
     constexpr int KV = Elem<T>::KV;
@@ -1156,13 +1289,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
 
     constexpr int ES = (int)sizeof(T);
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), dr = make_rsrc(p.w, p.w_bytes);
-    Vec16<T> ra[1][NVA], rb[1][NVB];
-    auto gload = [&](Vec16<T> (&qa)[NVA], Vec16<T> (&qb)[NVB], int k0) {
+    Vec16<T> ra[MM ? 2 : 1][NVA], rb[MM ? 2 : 1][NVB];
+    auto gload = [&](Vec16<T> (&qa)[NVA], Vec16<T> (&qb)[NVB], int k0, bool live = true) {      // (live: see conv_fwd_kernel)
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int v = tid + i * NT, kr = v / CHA, c = v % CHA;
             const int k = k0 + kr;                                 // rows k >= Ktot fall outside the dy buffer -> 0
-            qa[i] = bload<T>(dr, k < Ktot ? (unsigned)((k * p.ldw + co0 + c * KV) * ES) : OOB);
+            qa[i] = bload<T>(dr, (live && k < Ktot) ? (unsigned)((k * p.ldw + co0 + c * KV) * ES) : OOB);
         }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
@@ -1173,15 +1306,15 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
             bool tap_ok = true;
             if (SMALLC) { const int tp = (c * KV) >> 3; kyy = G::ky(tp); kxx = G::kx(tp); coff = (c * KV) & 7; tap_ok = tp < G::TAPS; }
             const int iy = G::ST * (rem >> p.lgWo) - 1 + kyy, ix = G::ST * (rem & (Wo - 1)) - 1 + kxx;
-            const bool ok = tap_ok && k < Ktot && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const bool ok = live && tap_ok && k < Ktot && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             qb[i] = bload<T>(xr, ok ? (unsigned)((((n * p.Hi + iy) * p.Wi + ix) * p.ldx + coff) * ES) : OOB);
         }
     };
     auto lstore = [&](const Vec16<T> (&qa)[NVA], const Vec16<T> (&qb)[NVB], int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) { const int v = tid + i * NT; tile_store(As[buf], v / CHA, v % CHA, qa[i], p.mm_ascale); }
+        for (int i = 0; i < NVA; ++i) { const int v = tid + i * NT; As[buf].store_vec(v / CHA, v % CHA, qa[i]); }
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) { const int v = tid + i * NT; tile_store(Bs[buf], v / CHB, v % CHB, qb[i], p.mm_bscale); }
+        for (int i = 0; i < NVB; ++i) { const int v = tid + i * NT; Bs[buf].store_vec(v / CHB, v % CHB, qb[i]); }
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1190,6 +1323,23 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(ConvParams p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (MM != 0) {                                   // two K tiles of loads in flight (see conv_fwd_kernel)
+        if (kt_beg < kt_end) {
+            gload(ra[0], rb[0], kt_beg * BK);
+            gload(ra[1], rb[1], (kt_beg + 1) * BK, kt_beg + 1 < kt_end);
+            lstore(ra[0], rb[0], 0); __syncthreads();
+            for (int t = kt_beg; t < kt_end; t += 2) {
+                gload(ra[0], rb[0], (t + 2) * BK, t + 2 < kt_end);
+                mma_slab<TM, TN>(As[0], Bs[0], wm0, wn0, lane, acc);
+                lstore(ra[1], rb[1], 1);
+                __syncthreads();
+                gload(ra[1], rb[1], (t + 3) * BK, t + 3 < kt_end);
+                if (t + 1 < kt_end) mma_slab<TM, TN>(As[1], Bs[1], wm0, wn0, lane, acc);
+                lstore(ra[0], rb[0], 0);
+                __syncthreads();
+            }
+        }
+    } else
     if (kt_beg < kt_end) {
         gload(ra[0], rb[0], kt_beg * BK); lstore(ra[0], rb[0], 0); __syncthreads();
         for (int t = kt_beg; t < kt_end; ++t) {
@@ -1884,12 +2034,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedBatch b) {
 // fp32 PyTorch-layout weight [Cout][Cin][4][4] -> packed operand layouts in T
 template <typename T>
 __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wt,
-                                   int Cout, int Cin, int CinP) {
+                                   int Cout, int Cin, int CinP, float scale) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // over [Cout][16][CinP]
     const size_t total = (size_t)Cout * 16 * CinP;
     if (idx >= total) return;
     const int ci = idx % CinP, tap = (idx / CinP) % 16, co = idx / ((size_t)CinP * 16);
-    const float val = ci < Cin ? w[((size_t)co * Cin + ci) * 16 + tap] : 0.f;
+    const float val = ci < Cin ? w[((size_t)co * Cin + ci) * 16 + tap] * scale : 0.f;
     if (wf) Elem<T>::st(wf + idx, val);
     if (wt) Elem<T>::st(wt + ((size_t)ci * 16 + tap) * Cout + co, val);
 }
@@ -1903,7 +2053,7 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 //                                             degrees and the channel roles swapped (no separate dgrad kernel)
 // ------------------------------------------------------------------------------------------
 struct Prep3Layer { const float* w; void* wf; void* wt; int Cout, Cin, CinP, wkf, wkt; };
-struct Prep3Batch { Prep3Layer l[8]; };
+struct Prep3Batch { Prep3Layer l[8]; float scale; };
 template <typename T>
 __global__ __launch_bounds__(256) void prep3_weight_batch_kernel(Prep3Batch b) {
     const Prep3Layer& L = b.l[blockIdx.y];
@@ -1914,12 +2064,12 @@ __global__ __launch_bounds__(256) void prep3_weight_batch_kernel(Prep3Batch b) {
         if (idx < nf) {
             const int co = (int)(idx / L.wkf), k = (int)(idx % L.wkf);
             const int tap = k / L.CinP, ci = k % L.CinP;
-            Elem<T>::st(wf + idx, (tap < 9 && ci < L.Cin) ? L.w[((size_t)co * L.Cin + ci) * 9 + tap] : 0.f);
+            Elem<T>::st(wf + idx, (tap < 9 && ci < L.Cin) ? L.w[((size_t)co * L.Cin + ci) * 9 + tap] * b.scale : 0.f);
         } else {
             const size_t j = idx - nf;
             const int ci = (int)(j / L.wkt), k = (int)(j % L.wkt);
             const int tap = k / L.Cout, co = k % L.Cout;
-            Elem<T>::st(wt + j, tap < 9 ? L.w[((size_t)co * L.Cin + ci) * 9 + (8 - tap)] : 0.f);
+            Elem<T>::st(wt + j, tap < 9 ? L.w[((size_t)co * L.Cin + ci) * 9 + (8 - tap)] * b.scale : 0.f);
         }
     }
 }
@@ -2035,7 +2185,7 @@ void launch_dma(const ConvParams& p, dim3 grid, bool smallk, hipStream_t st) {
 
 // several layers per launch (blockIdx.y = layer): the critic is re-packed after every optimiser step
 struct PrepLayer { const float* w; void* wf; void* wt; int Cout, Cin, CinP; };
-struct PrepBatch { PrepLayer l[8]; int nl; const float* w5; float* w5p; int C5; };   // w5: the critic head's [1][C5][4][4] -> fp32 [16][C5] (nullable)
+struct PrepBatch { PrepLayer l[8]; int nl; const float* w5; float* w5p; int C5; float scale; };   // w5: the critic head's [1][C5][4][4] -> fp32 [16][C5] (nullable)
 // 16 consecutive fp32 values of an LDS row -> 16 consecutive T in global memory (32 or 64 bytes, vector stores)
 template <typename T> __device__ __forceinline__ void store16(T* dst, const float* src);
 template <> __device__ __forceinline__ void store16<float>(float* dst, const float* src) {
@@ -2081,7 +2231,7 @@ __global__ __launch_bounds__(256) void prep_weight_batch_kernel(PrepBatch b) {
         const size_t total = (size_t)L.Cout * 16 * L.CinP;
         for (size_t idx = (size_t)blockIdx.x * blockDim.x + tid; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
             const int ci = idx % L.CinP, tap = (idx / L.CinP) % 16, co = idx / ((size_t)L.CinP * 16);
-            const float val = ci < L.Cin ? L.w[((size_t)co * L.Cin + ci) * 16 + tap] : 0.f;
+            const float val = ci < L.Cin ? L.w[((size_t)co * L.Cin + ci) * 16 + tap] * b.scale : 0.f;
             if (wf) Elem<T>::st(wf + idx, val);
             if (wt) Elem<T>::st(wt + ((size_t)ci * 16 + tap) * L.Cout + co, val);
         }
@@ -2097,7 +2247,7 @@ __global__ __launch_bounds__(256) void prep_weight_batch_kernel(PrepBatch b) {
             for (int i = 0; i < 4; ++i) {               // one co: 64 ci x 16 taps = 4 KB contiguous
                 const float4 v = reinterpret_cast<const float4*>(L.w + ((size_t)(co0 + i) * L.Cin + ci0) * 16)[tid];
                 float* row = tile + (i * 16 + tp) * 65 + ci;       // tile[(co, tap)][ci]
-                row[0] = v.x; row[65] = v.y; row[130] = v.z; row[195] = v.w;
+                row[0] = v.x * b.scale; row[65] = v.y * b.scale; row[130] = v.z * b.scale; row[195] = v.w * b.scale;
             }
             __syncthreads();
             const int r = tid >> 2, c0 = (tid & 3) * 16;            // row r = (co, tap): 64 ci = 128 B (bf16)
@@ -2114,7 +2264,7 @@ __global__ __launch_bounds__(256) void prep_weight_batch_kernel(PrepBatch b) {
                 const int f = tid + 256 * i, co = f >> 4, piece = f & 15;
                 const float4 v = reinterpret_cast<const float4*>(L.w + ((size_t)(co0 + co) * L.Cin + ci0) * 16)[piece];
                 float* col = tile + (piece * 4) * 65 + co;          // tile[k = ci_local*16 + tap][co]
-                col[0] = v.x; col[65] = v.y; col[130] = v.z; col[195] = v.w;
+                col[0] = v.x * b.scale; col[65] = v.y * b.scale; col[130] = v.z * b.scale; col[195] = v.w * b.scale;
             }
             __syncthreads();
             const int r = tid >> 2, c0 = (tid & 3) * 16;            // row r = (ci_local, tap): 64 co = 128 B (bf16)
@@ -2124,10 +2274,17 @@ __global__ __launch_bounds__(256) void prep_weight_batch_kernel(PrepBatch b) {
     }
 }
 
+int x3_waves() {       // waves per workgroup of the split-precision 128 x 64 tiles: 8 = forward 4 x 2 (default), 16 = the data gradient too, 4 = 2 x 2 (A/B)
+    static const int v = [] { const char* e = getenv("GCSSL_X3_WAVES"); return e ? atoi(e) : 8; }();
+    return v;
+}
 template <typename T, int BM, int BN, int MM = 0>
 int launch_fwd(const ConvParams& p, hipStream_t st) {
     if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
+    if constexpr (MM != 0 && BM == 128 && BN == 64) {
+        if (x3_waves() >= 8) { GCSSL_LAUNCH((conv_fwd_kernel<T, BM, BN, 4, MM, 4, 2>), grid, dim3(512), 0, st, p); return gcssl_launch_status(); }
+    }
     if (Is16<T>::v && use_dma()) launch_dma<typename Op16<T>::type, BM, BN, 0>(p, grid, p.Cin < 64, st);
     else GCSSL_LAUNCH((conv_fwd_kernel<T, BM, BN, 4, MM>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
@@ -2136,18 +2293,25 @@ template <typename T, int BM, int BN, int MM = 0>
 int launch_dgrad(const ConvParams& p, hipStream_t st) {
     if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cin + BN - 1) / BN, 4 * (p.ksplit > 1 ? p.ksplit : 1));
+    if constexpr (MM != 0 && BM == 128 && BN == 64) {
+        if (x3_waves() == 16) { GCSSL_LAUNCH((conv_dgrad_kernel<T, BM, BN, MM, 4, 2>), grid, dim3(512), 0, st, p); return gcssl_launch_status(); }   // (A/B only: neutral)
+    }
     if (Is16<T>::v && use_dma()) launch_dma<typename Op16<T>::type, BM, BN, 1>(p, grid, false, st);
     else GCSSL_LAUNCH((conv_dgrad_kernel<T, BM, BN, MM>), grid, dim3(NT), 0, st, p);
     return gcssl_launch_status();
 }
-// split-precision forms: the weights (B operand of the forward / data-gradient GEMMs) are pre-scaled by 2^6 on their way into
-// LDS -- N(0, 0.02) entries land at O(1), where the fp16 lo part keeps all its bits (below 6e-5 it would be subnormal) -- and the
-// accumulators are scaled back in the epilogue.  Exact (powers of two).  GCSSL_X3_WSCALE: log2 of the factor (experiments).
-void set_mm_scales(ConvParams& p, bool weights_b) {
+// split-precision forms: the PACKED weights (B operand of the forward / data-gradient GEMMs) carry a factor 2^6 -- N(0, 0.02)
+// entries land at O(1), where the fp16 lo half keeps all its bits (below 6e-5 it would be subnormal) -- put there by the pack
+// kernels when they are called with a split dtype; the conv epilogues scale the accumulators back.  Exact (powers of two).
+// GCSSL_X3_WSCALE: log2 of the factor (experiments).
+float x3_wscale() {
     static const int lg = [] { const char* e = getenv("GCSSL_X3_WSCALE"); return e ? atoi(e) : 6; }();
-    p.mm_ascale = 1.f;
-    p.mm_bscale = weights_b ? (float)(1 << lg) : 1.f;
-    p.mm_oscale = 1.f / p.mm_bscale;
+    return (float)(1 << lg);
+}
+void set_mm_scales(ConvParams& p, bool weights_b) {
+    p.mm_oscale = weights_b ? 1.f / x3_wscale() : 1.f;
+    static const int dbg = [] { const char* e = getenv("GCSSL_X3_DEBUG"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
 }
 
 int check_geom(int N, int Hi, int Wi, int Cin, int Cout) {
@@ -2444,9 +2608,51 @@ __global__ __launch_bounds__(256) void conv_fwd_c8_kernel(ConvParams p, int ntil
 // (A/B knob: GCSSL_C8_FWD=0 sends these shapes back to the generic tiles)
 bool c8_fwd_on() { static const bool v = [] { const char* e = getenv("GCSSL_C8_FWD"); return !(e && e[0] == '0'); }(); return v; }
 
+// Tile plan of the split-precision forms.  Their operands are fp32 in memory (twice the bytes of a 16-bit tile per K element) and
+// every kernel of this file is paced by its LDS fill rate, so FLOP per filled byte decides: 128x128 tiles (32 FLOP/B) where the
+// column count allows, 128x64 (21) else, 64x64 (10.7) only for first layers; small-M launches fill the chip by splitting K (the
+// outputs of this mode are fp32 and every epilogue but the first layers' is linear).  Returns the tile code (2 = 128x128,
+// 1 = 128x64, 0 = 64x64) and sets *ks.  mult: 4 parity classes for the dgrad form.  GCSSL_X3_TILE / GCSSL_X3_KS: force (experiments).
+int x3_plan(long M, int ncols, int nk, int mult, bool split_ok, int* ks) {
+    static const int ftile = [] { const char* e = getenv("GCSSL_X3_TILE"); return e ? atoi(e) : -1; }();
+    static const int fks = [] { const char* e = getenv("GCSSL_X3_KS"); return e ? atoi(e) : 0; }();
+    static const long want = [] { const char* e = getenv("GCSSL_X3_WGS"); return e ? atol(e) : 384L; }();
+    // measured (tools/x3_ab.sh, n = 768 critic shapes): 128x64 beats 128x128 on every forward (8 waves: 62.7 / 68.3 / 72.6 us against
+    // 69.6 / 84.1 / 83.3 for c2 / c3 / c4) and ties on the data gradients -- the launches are issue- and skeleton-bound, not
+    // fill-bound, so the extra workgroups in flight are worth more than the FLOP per byte; 128x128 stays behind GCSSL_X3_TILE=2
+    int tile = (ncols >= 64 && M >= 128) ? 1 : 0;
+    if (ftile >= 0 && (ftile <= tile || (ftile == 2 && ncols >= 128 && M >= 128))) tile = ftile;
+    const int bm = tile ? 128 : 64, bn = tile == 2 ? 128 : 64;
+    const long tiles = mult * ((M + bm - 1) / bm) * ((ncols + bn - 1) / bn);
+    int k = 1;
+    if (split_ok && ksplit_max() > 1 && tiles < want && nk >= 16) {
+        k = (int)((want + tiles - 1) / tiles);
+        if (k > ksplit_max()) k = ksplit_max();
+        while (k > 1 && nk / k < 8) --k;
+    }
+    if (fks > 0 && split_ok) { k = fks; while (k > 1 && nk / k < 4) --k; }
+    *ks = k;
+    return tile;
+}
 template <typename T, int MM = 0>
 int dispatch_fwd(ConvParams p, hipStream_t st) {
     if (MM) set_mm_scales(p, true);
+    if constexpr (MM != 0) {
+        const int nk = 16 * p.Cin / 32;
+        int ks = 1;
+        const int tile = p.Cin < 64 ? 0 : x3_plan(p.M, p.Cout, nk, 1, p.act == 0, &ks);
+        if (p.Cin >= 64) {
+            p.ksplit = ks;
+            if (ks > 1) {
+                p.ktiles_per_split = (nk + ks - 1) / ks;
+                int rc = zero_output(p, p.M, p.Cout, st);
+                if (rc) return rc;
+            }
+            if (tile == 2) return launch_fwd<T, 128, 128, MM>(p, st);
+            if (tile == 1) return launch_fwd<T, 128, 64, MM>(p, st);
+            return launch_fwd<T, 64, 64, MM>(p, st);
+        }
+    }
     if constexpr (Is16<T>::v) {
         const int Wo = p.Wi / 2;
         if (p.Cin == 8 && p.Cout == 64 && (Wo == 16 || Wo == 32 || Wo == 64) && (p.Hi / 2) % (128 / Wo) == 0 && c8_fwd_on() &&
@@ -2690,6 +2896,22 @@ template <typename O, int OUT> void launch_dgrad_img(const ConvParams& p, hipStr
 template <typename T, int MM = 0>
 int dispatch_dgrad(ConvParams p, hipStream_t st) {
     if (MM) set_mm_scales(p, true);
+    if constexpr (MM != 0) {
+        if (p.Cin >= 64) {
+            const int nk = 4 * p.Cout / 32;
+            int ks = 1;
+            const int tile = x3_plan(p.M, p.Cin, nk, 4, true, &ks);
+            p.ksplit = ks;
+            if (ks > 1) {
+                p.ktiles_per_split = (nk + ks - 1) / ks;
+                int rc = zero_output(p, (long)p.N * p.Hi * p.Wi, p.Cin, st);
+                if (rc) return rc;
+            }
+            if (tile == 2) return launch_dgrad<T, 128, 128, MM>(p, st);
+            if (tile == 1) return launch_dgrad<T, 128, 64, MM>(p, st);
+            return launch_dgrad<T, 64, 64, MM>(p, st);
+        }
+    }
     if constexpr (Is16<T>::v) {
         // the 64 <- 128 layer on 16 x 16 maps, fp32 dx, >= 3 samples per CU: dy maps resident in LDS (dgrad_img_kernel)
         if (p.out_f32 && !p.split_stride && p.ldy % 4 == 0 && aligned16(p.y) && p.y_bytes && !forced_tile() && dgrad_img_on(p)) {
@@ -3412,6 +3634,7 @@ int gcssl_prep_conv_weights(int dtype, int nl, const float* const* w, void* cons
     if ((w5 != nullptr) != (w5p != nullptr) || (w5 && C5 <= 0)) return GCSSL_EBADSHAPE;
     PrepBatch b{};
     b.nl = nl; b.w5 = w5; b.w5p = w5p; b.C5 = C5;
+    b.scale = (dtype == GCSSL_F32_F16X3 || dtype == GCSSL_F32_BF16X3) ? x3_wscale() : 1.f;       // (the head conv's w5p is never scaled)
     size_t mx = 0;
     for (int i = 0; i < nl; ++i) {
         if (!w[i] || (!wf[i] && !wt[i])) return GCSSL_ENULL;
@@ -3422,8 +3645,8 @@ int gcssl_prep_conv_weights(int dtype, int nl, const float* const* w, void* cons
     }
     unsigned gx = (unsigned)((mx + 4095) / 4096); if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;     // one 4096-element tile per pass
     dim3 grid(gx, nl + (w5 ? 1 : 0), 2);
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    GCSSL_DISPATCH(dtype, GCSSL_LAUNCH(prep_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b));
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
+    GCSSL_DISPATCH_CONV(dtype, GCSSL_LAUNCH(prep_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b));
     return gcssl_launch_status();
 }
 
@@ -3433,8 +3656,9 @@ int gcssl_prep_conv_weight(int dtype, const float* w, void* wf, void* wt, int Co
     if (Cout <= 0 || Cin <= 0 || CinP < Cin) return GCSSL_EBADSHAPE;
     const size_t total = (size_t)Cout * 16 * CinP;
     dim3 grid((unsigned)((total + 255) / 256));
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    GCSSL_DISPATCH(dtype, GCSSL_LAUNCH(prep_weight_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, w, (T*)wf, (T*)wt, Cout, Cin, CinP));
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
+    const float wscale = (dtype == GCSSL_F32_F16X3 || dtype == GCSSL_F32_BF16X3) ? x3_wscale() : 1.f;
+    GCSSL_DISPATCH_CONV(dtype, GCSSL_LAUNCH(prep_weight_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, w, (T*)wf, (T*)wt, Cout, Cin, CinP, wscale));
     return gcssl_launch_status();
 }
 
@@ -3570,8 +3794,9 @@ int gcssl_conv3x3_prep_weights(int dtype, int nl, const float* const* w, void* c
     }
     unsigned gx = (unsigned)((mx + 1023) / 1024); if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
     dim3 grid(gx, nl);
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    GCSSL_DISPATCH(dtype, GCSSL_LAUNCH(prep3_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b));
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
+    b.scale = (dtype == GCSSL_F32_F16X3 || dtype == GCSSL_F32_BF16X3) ? x3_wscale() : 1.f;
+    GCSSL_DISPATCH_CONV(dtype, GCSSL_LAUNCH(prep3_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b));
     return gcssl_launch_status();
 }
 

@@ -563,7 +563,7 @@ class StepEngine:
         if self._prep_d_batch is None:
             self._prep_d_batch = ops.PrepBatch(
                 [(self.D.views[self.d_wkey(i)], self.d_wf[l], self.d_wt[l], cout, cin, _pad8(cin))
-                 for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX))], self.code,
+                 for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX))], self.mma,
                 c5=(self.D.views["model.11.weight"], self.d_w5p))         # the head's fp32 re-pack rides on the same launch
         self._prep_d_batch.run()
         self._d_dirty = False
@@ -581,7 +581,7 @@ class StepEngine:
             for k, (cint, coutt) in enumerate(G_UP):
                 key = f"up{k + 1}.model.0.weight" if k < 3 else "up4.0.weight"
                 layers.append((self.G.views[key], self.gu_wf[k], self.gu_wt[k], cint, coutt, coutt))
-            self._prep_g_batch = ops.PrepBatch(layers, self.code)
+            self._prep_g_batch = ops.PrepBatch(layers, self.mma)
         self._prep_g_batch.run()
         self._g_dirty = False
 

@@ -107,7 +107,7 @@ class SimpleGenerator:
         if self._prep is None:
             V = self.eng.G.views
             self._prep = ops.Prep3Batch([(V[self._w(j)[0]], self.wf[j], self.wt[j], cout, cin, self.cinp[j])
-                                         for j, (cin, cout) in enumerate(GS_CONV)], self.eng.code)
+                                         for j, (cin, cout) in enumerate(GS_CONV)], self.eng.mma)
         self._prep.run()
         self.w1t.copy_(self.eng.G.views["regressor.2.weight"].t())
         self.w2t.copy_(self.eng.G.views["regressor.5.weight"].t())

@@ -180,7 +180,9 @@ def test_conv_split_precision(ops, mode, tol, N, Hi, Cin, CinP, Cout):
     b = rnd(Cout, seed=3, scale=0.1)
     group_n = (N + 2) // 3
     gs = torch.tensor([1.3, 0.7, 2.1])[: (N + group_n - 1) // group_n]
-    wf, wt = packed_weights(ops, w, f32, CinP)
+    wf = torch.empty(Cout, 16, CinP, device="cuda")                 # packed FOR THE MODE: the pack carries the modes' 2^6 weight scale
+    wt = torch.empty(CinP, 16, Cout, device="cuda")
+    ops.prep_conv_weight(w.cuda(), wf, wt, Cout, Cin, CinP, code)
     xd = nhwc(x, f32, CinP)
     # forward (with the activation epilogue, and the linear form the dispatcher may split over K: atomics / slabs)
     y = torch.full((N, Hi // 2, Hi // 2, Cout), float("nan"), device="cuda")
@@ -222,7 +224,8 @@ def test_conv_split_precision_small_magnitudes(ops):
     code = lib.mma_code("fp16x3")
     N, Hi, Cin, Cout = 24, 16, 64, 128
     w = rnd(Cout, Cin, 4, 4, seed=2, scale=0.05)
-    _, wt = packed_weights(ops, w, torch.float32, Cin)
+    wt = torch.empty(Cin, 16, Cout, device="cuda")
+    ops.prep_conv_weight(w.cuda(), None, wt, Cout, Cin, Cin, code)
     dy = rnd(N, Cout, Hi // 2, Hi // 2, seed=4, scale=1e-3)
     dx = torch.zeros(N, Hi, Hi, Cin, device="cuda")
     ops.conv_dgrad(nhwc(dy, torch.float32), wt, dx, Cin, Cout, dt=code)

@@ -15,7 +15,7 @@ x = (torch.rand(N, Hi, Hi, Cin, device="cuda") * 2 - 1).to(dt)
 dy = (torch.rand(N, Hi // 2, Hi // 2, Cout, device="cuda") * 2 - 1).to(dt)
 w = torch.randn(Cout, Cin, 4, 4, device="cuda") * 0.05
 wf = torch.empty(Cout, 16, Cin, device="cuda", dtype=dt); wt = torch.empty(Cin, 16, Cout, device="cuda", dtype=dt)
-ops.prep_conv_weight(w, wf, wt, Cout, Cin, Cin, ops.code(wf))
+ops.prep_conv_weight(w, wf, wt, Cout, Cin, Cin, kw.get('dt', ops.code(wf)))
 y = torch.empty(N, Hi // 2, Hi // 2, Cout, device="cuda", dtype=torch.float32)
 dx = torch.empty(N, Hi, Hi, Cin, device="cuda", dtype=torch.float32)
 ns = ops.wgrad_splits(N, Hi, Hi, Cin, Cout)
