@@ -51,6 +51,13 @@ def parse_header(path: Path = HEADER):
     return protos
 
 
+def abi_revision_of_header(path: Path = HEADER) -> int:
+    m = re.search(r"#define\s+GCSSL_ABI_REVISION\s+(\d+)", path.read_text())
+    if not m:
+        raise RuntimeError(f"{path} does not define GCSSL_ABI_REVISION")
+    return int(m.group(1))
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP sources for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU).
     One object per source, compiled in parallel (igemm.hip alone is most of the time), then linked."""
@@ -102,6 +109,11 @@ def lib():
         for name, (ret, argtypes) in _protos.items():
             fn = getattr(_lib, name)          # AttributeError here == header/ABI mismatch: fail loudly
             fn.restype, fn.argtypes = ret, argtypes
+        want = abi_revision_of_header()
+        have = _lib.gcssl_abi_revision()
+        if have != want:
+            raise RuntimeError(f"libgcssl_hip.so implements ABI revision {have}, include/gcssl.h declares {want}: rebuild "
+                               f"(python -c 'import __graft_entry__ as g; g.build()')")
     return _lib
 
 

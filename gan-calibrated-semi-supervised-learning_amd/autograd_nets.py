@@ -401,6 +401,7 @@ class _SimpleHost:
     def __init__(self, params: dict, B: int, S: int, code: int, scale: float, dev):
         from .engine import FlatParams
         self.B, self.S, self.code, self.T, self.dev = B, S, code, _lib.torch_dtype(code), dev
+        self.mma = code                                              # (conv dtype code == storage code: the module API has no split modes)
         self.delta_scale, self.seed = scale, 0
         self.G = FlatParams(params, list(params.keys()), dev)
         self.ws = self.ws_g = torch.empty(2 * B * 512, device=dev, dtype=F32)    # (the step engine keeps a separate one for the generator)

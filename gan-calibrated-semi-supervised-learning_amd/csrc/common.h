@@ -147,7 +147,9 @@ __device__ __forceinline__ void sat_commit(unsigned* sat, int n) { if (sat && n)
 // ---- which kernel did the last conv dispatcher launch?  (bench.py's roofline names the rocprofv3 symbol of its dominant
 // launch: the dispatchers pick a template instantiation per shape, so the host records the expression it launched.)
 extern const char* g_gcssl_last_kernel;
-#define GCSSL_LAUNCH(kern, ...) do { g_gcssl_last_kernel = #kern; hipLaunchKernelGGL(kern, __VA_ARGS__); } while (0)
+extern long g_gcssl_last_grid;            // ... and its grid size in workgroups (tools/prof_labels.py joins a label to its rocprofv3 launches by both)
+#define GCSSL_LAUNCH(kern, grid, ...) do { g_gcssl_last_kernel = #kern; const dim3 gcssl_g_ = (grid);          \
+        g_gcssl_last_grid = (long)gcssl_g_.x * gcssl_g_.y * gcssl_g_.z; hipLaunchKernelGGL(kern, gcssl_g_, __VA_ARGS__); } while (0)
 
 // ---- wave / block reductions (wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {

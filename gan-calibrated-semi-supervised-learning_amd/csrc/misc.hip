@@ -880,6 +880,7 @@ __global__ void uncast_kernel(const T* __restrict__ x, float* __restrict__ y, si
 #define GRID1(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256), 0, (hipStream_t)stream
 
 const char* g_gcssl_last_kernel = nullptr;     // (common.h: set by GCSSL_LAUNCH in every translation unit of the library)
+long g_gcssl_last_grid = 0;
 
 extern "C" {
 
@@ -1078,7 +1079,7 @@ int gcssl_head_bwd(const float* g_delta, const float* traw, const float* pooled,
     return gcssl_launch_status();
 }
 
-// loss_acc must be zeroed by the caller; afterwards loss = 1 + *loss_acc
+// *loss_acc is STORED (one workgroup walks the batch: no atomics, no fill in front); afterwards loss = 1 + *loss_acc
 int gcssl_eiou_fwd_bwd(const float* pred_box, const float* delta, const float* delta_true, int B, float lambda_iou,
                        float* g_delta, float* calibrated, float* loss_acc, void* stream) {
     if (!pred_box || !delta || !delta_true || !g_delta || !calibrated || !loss_acc) return GCSSL_ENULL;
@@ -1116,6 +1117,7 @@ extern "C" int gcssl_init_recrop();
 /* One-time device-side set-up (dynamic-LDS opt-ins).  Call once per process with a GPU present and BEFORE capturing any
  * of the entry points into a hipGraph; the entry points also do it lazily on first use. */
 const char* gcssl_last_kernel() { return g_gcssl_last_kernel ? g_gcssl_last_kernel : ""; }
+int gcssl_last_grid() { return (int)g_gcssl_last_grid; }
 
 int gcssl_init() {
     int rc = gcssl_init_norm();
@@ -1153,6 +1155,9 @@ int gcssl_uncast(int dtype, const void* x, float* y, long n, void* stream) {
     return gcssl_launch_status();
 }
 
-const char* gcssl_version(void) { return "gcssl-hip 0.1 (gfx950)"; }
+const char* gcssl_version(void) { return "gcssl-hip 0.4 (gfx950)"; }
+// ABI revision: bumped whenever an existing entry point's argument list or a constant's meaning changes (a ctypes / C caller
+// built against another revision of include/gcssl.h must refuse to run: _lib.py checks it against GCSSL_ABI_REVISION)
+int gcssl_abi_revision(void) { return 4; }
 
 }  // extern "C"

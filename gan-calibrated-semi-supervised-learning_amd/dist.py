@@ -47,23 +47,44 @@ def force_dp() -> bool:
 
 
 class GradAverager:
-    """all-reduce(sum)/world of a flat gradient buffer, in place.  Callable, used as ``StepEngine(allreduce=...)``."""
+    """all-reduce(sum)/world of a flat gradient buffer, in place.  Callable, used as ``StepEngine(allreduce=...)``.
 
-    def __init__(self, group=None):
+    compress="bf16" (or GCSSL_AR_DTYPE=bf16): the bucket crosses the wire as bf16 -- half the bytes over xGMI (the
+    ring time of the 11 MB + 11 MB + 25 MB per iteration is 0.55 ms at 8 GPUs against a 1.9 ms step).  The fp32 bucket is
+    rounded into a bf16 staging buffer, RCCL sums in bf16, the result is widened back over the bucket: every summand carries
+    a relative rounding of 2^-9 and the ring adds log-depth more -- measured 4e-3 of the gradient's norm at world 2
+    (tests/test_dist_cpu.py), below what the bf16 compute mode itself leaves on a gradient (1e-2), far above the fp32
+    modes' 1e-6: a throughput option for the 16-bit modes, not for the parity modes."""
+
+    def __init__(self, group=None, compress: Optional[str] = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        compress = compress if compress is not None else os.environ.get("GCSSL_AR_DTYPE", "")
+        if compress not in ("", "fp32", "bf16"):
+            raise ValueError(f"GradAverager: compress must be 'bf16' or unset, got {compress!r}")
+        self.compress = compress == "bf16"
+        self._stage = {}                       # data_ptr of a bucket -> its bf16 staging buffer
+
+    def _staged(self, flat: torch.Tensor) -> torch.Tensor:
+        b = self._stage.get(flat.data_ptr())
+        if b is None or b.numel() != flat.numel():
+            b = self._stage[flat.data_ptr()] = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+        return b
 
     def __call__(self, flat: torch.Tensor) -> None:
         if self.world == 1 and not force_dp():
             return
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.mul_(1.0 / self.world)
+        self.finish(self.start(flat), flat)
 
     # split form: the collective runs on the backend's own stream (RCCL) / thread (gloo) while the caller keeps launching
     # work that does not need the result; finish() orders the caller's stream behind it.
     def start(self, flat: torch.Tensor):
         if self.world == 1 and not force_dp():
             return None
+        if self.compress:
+            b = self._staged(flat)
+            b.copy_(flat)                                            # fp32 -> bf16 (RNE) on the caller's stream, in front of the collective
+            return (dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True), b)
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self, handle, flat: torch.Tensor, scale: bool = True) -> None:
@@ -71,7 +92,12 @@ class GradAverager:
         folds it into its fused clip+Adam launch: StepEngine._grad_scale)."""
         if handle is None:
             return
-        handle.wait()
+        if isinstance(handle, tuple):
+            work, b = handle
+            work.wait()
+            flat.copy_(b)                                            # the bf16 sum, widened back over the fp32 bucket
+        else:
+            handle.wait()
         if scale:
             flat.mul_(1.0 / self.world)
 

@@ -299,13 +299,15 @@ class StepEngine:
         if rec is None:
             algo, stored = _bytes or _algorithmic_bytes(label, args, 4 if self.code == _lib.F32 else 2)
             rec = self.probe[label] = {"events": [], "flops": flops, "bytes": algo, "stored": stored,
-                                       "kernel": ops.last_kernel()}      # the template expression the dispatcher launched
+                                       "kernel": ops.last_kernel(),      # the template expression the dispatcher launched
+                                       "grid": ops.last_grid()}          # ... and its workgroup count (tools/prof_labels.py)
         rec["events"].append((e0, e1, e2))
 
     def probe_summary(self):
         """-> {label: (n_launches, mean_ms, flops_per_launch, algorithmic_bytes_per_launch, stored_bytes_per_launch, kernel,
         mean_ms_chained)} (synchronises).  kernel: the kernel template expression of the label's launch (gcssl_last_kernel);
-        mean_ms_chained: per launch inside the back-to-back repeats (enable_probe(repeats=...)), else None."""
+        mean_ms_chained: per launch inside the back-to-back repeats (enable_probe(repeats=...)), else None.
+        self.probe_grids (set here): {label: workgroups of the label's launch}."""
         torch.cuda.synchronize()
 
         def robust(ts):
@@ -316,6 +318,7 @@ class StepEngine:
             keep = [t for t in ts if t <= 3.0 * med] or ts
             return sum(keep) / max(len(keep), 1)
         out = {}
+        self.probe_grids = {k: rec.get("grid", 0) for k, rec in (self.probe or {}).items()}
         for k, rec in (self.probe or {}).items():
             ev = rec["events"]
             rep = [b.elapsed_time(c) / self.probe_repeats for _, b, c in ev if c is not None]

@@ -352,6 +352,11 @@ def gp_norm(g, B, lambda_gp, nrm, coef, gp_sum, scaled=None, sat=None):
          code(scaled) if scaled is not None else 0, scaled, sat)
 
 
+def last_grid() -> int:
+    """workgroups of the most recent GCSSL_LAUNCH of this process (gcssl_last_grid)"""
+    return int(_lib.lib().gcssl_last_grid())
+
+
 def last_kernel() -> str:
     """the kernel template expression the most recent conv entry point launched (gcssl_last_kernel)"""
     return _lib.lib().gcssl_last_kernel().decode()

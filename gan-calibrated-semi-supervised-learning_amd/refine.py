@@ -53,9 +53,10 @@ class ImageAtlas:
         return cls([np.asarray(Image.open(p).convert("RGB")) for p in paths], device)
 
 
-def apply_delta_eval(pred_bboxes: torch.Tensor, deltas: torch.Tensor) -> torch.Tensor:
+def apply_delta_eval(pred_bboxes: torch.Tensor, deltas: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """apply_delta_to_bbox(pred, delta, training=False) (cgan/losses.py:108-150) as one launch."""
-    out = torch.empty_like(pred_bboxes)
+    if out is None:
+        out = torch.empty_like(pred_bboxes)
     call("gcssl_apply_delta_eval", pred_bboxes, deltas, out, pred_bboxes.shape[0])
     return out
 
@@ -85,3 +86,37 @@ def get_refined_patch_batch(atlas: ImageAtlas, img_idx: torch.Tensor, pred_bboxe
     paths and everything on the device.  Returns (B, 3, img_size, img_size) fp32 with no autograd edge to deltas_pred."""
     refined = apply_delta_eval(pred_bboxes.detach().float().contiguous(), deltas_pred.detach().float().contiguous())
     return recrop(atlas, img_idx, refined, pred_bboxes.detach().float(), img_size, fallback_patches, status)
+
+
+class RefineStage:
+    """The re-crop stage as the engine's ``refine_fn(delta, k)`` with every buffer preallocated, so that the whole call is two
+    kernel launches on static pointers -- capturable into GraphedIteration's hipGraphs (the reference's step
+    contains this stage twice per critic step and once per generator step, cgan/cgan_train_enhanced.py:313-315,358-360).
+
+    ``img_idx`` / ``pred_box`` / ``fallback`` are STATIC device tensors (the batch's source-image indices, predicted boxes and
+    pred patches): a training loop that replays graphs refills them in place, as it does the engine's other inputs.  One output
+    buffer per call slot k (critic steps 0..n_critic-1, generator step n_critic): slot n_critic's patch is read by the
+    value-only critic forward long after the call, beside the next critic step's calls."""
+
+    def __init__(self, atlas: ImageAtlas, img_idx: torch.Tensor, pred_box: torch.Tensor, img_size: int, n_slots: int,
+                 fallback: Optional[torch.Tensor] = None, max_side: Optional[int] = None):
+        B, dev = pred_box.shape[0], pred_box.device
+        self.atlas, self.S = atlas, int(img_size)
+        self.img_idx = img_idx.to(torch.int32).contiguous()
+        self.pred_box = pred_box.detach().float().contiguous()
+        self.fallback = fallback
+        self.max_side = int(max_side if max_side is not None else atlas.max_side)
+        self.boxes = [torch.empty(B, 4, device=dev) for _ in range(n_slots)]
+        self.out = [torch.empty(B, 3, self.S, self.S, device=dev) for _ in range(n_slots)]
+        # (one coefficient-table workspace per slot: the generator step's call may run beside a critic step's on another stream)
+        n = _lib.lib().gcssl_recrop_ws_ints(B, self.S, self.max_side)
+        if n < 0:
+            raise RuntimeError(f"gcssl_recrop_ws_ints({B}, {self.S}, {self.max_side}) -> {_lib.ERRORS.get(n, n)}")
+        self.ws = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(n_slots)]
+
+    def __call__(self, delta: torch.Tensor, k: int) -> torch.Tensor:
+        a = self.atlas
+        apply_delta_eval(self.pred_box, delta, out=self.boxes[k])
+        call("gcssl_recrop_patches", a.data, a.data.numel(), a.off, a.w, a.h, self.img_idx, self.boxes[k], self.pred_box,
+             self.fallback, self.out[k], None, self.ws[k], self.pred_box.shape[0], self.S, self.max_side, 0)
+        return self.out[k]

@@ -30,12 +30,31 @@ extern "C" {
 #define GCSSL_F32 0
 #define GCSSL_BF16 1
 #define GCSSL_F16 2
+/* Split-precision conv modes (round 4): tensors are fp32 in memory exactly as with GCSSL_F32 -- every non-conv entry point
+ * is called with GCSSL_F32 -- and only the conv contractions differ: operands are split hi + lo into 16-bit halves on their
+ * way into LDS and contracted with THREE 16-bit MFMAs per K step (hi*hi + lo*hi + hi*lo, fp32 accumulate): 22 (fp16) / 16
+ * (bf16) mantissa bits per operand on the 2.5-PFLOP/s pipe instead of the 157-TFLOP/s exact-fp32 MFMA.  Accepted by
+ * gcssl_conv4x4s2_{fwd,dgrad,wgrad}, their *_splits probes, gcssl_conv3x3_{fwd,wgrad} and the weight-pack entry points
+ * (gcssl_prep_conv_weight[s], gcssl_conv3x3_prep_weights: a pack made with a split dtype carries the modes' 2^6 weight
+ * pre-scale, which the conv epilogues undo -- pack and conv must be called with the same dtype).  GCSSL_F32_F16X3 needs its
+ * operands inside fp16's range (the engine's static loss scales see to the gradients); nothing is clamped: an overflow is a
+ * NaN, not a saturated value.  Reference arithmetic these modes reproduce to fp32 grade: cgan/models.py:222-258,
+ * cgan/losses.py:185-233 (pure fp32). */
+#define GCSSL_F32_F16X3 3
+#define GCSSL_F32_BF16X3 4
 
+/* Revision of THIS header's contract: argument lists and constants.  gcssl_abi_revision() of the loaded library must equal
+ * it (round 3 changed a dozen argument lists in place under an unchanged version string: ADVICE r3). */
+#define GCSSL_ABI_REVISION 4
+int gcssl_abi_revision(void);
 const char* gcssl_version(void);
 /* The kernel template expression the most recent conv entry point of THIS process launched (as written at its launch site:
  * e.g. "(conv_dma_kernel<O, 128, 128, 0, 4, 2, false, 8, 4, false, true>)"; O / T = the operand type of `dtype`).  The
  * dispatchers choose an instantiation per shape; bench.py uses this to name the rocprofv3 symbol of its dominant launch. */
 const char* gcssl_last_kernel(void);
+/* ... and the number of workgroups of that launch (tools/prof_labels.py matches a label to its rocprofv3 launches by kernel
+ * name AND grid size). */
+int gcssl_last_grid(void);
 /* One-time device-side set-up (dynamic-LDS opt-ins of the kernels that use > 64 KB).  Call once per process with a GPU
  * present and before capturing entry points into a hipGraph (they also do it lazily on first use, which a capture in
  * progress may refuse). */

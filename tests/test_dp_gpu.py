@@ -117,6 +117,58 @@ def test_graphed_overlapped_allreduce_matches_eager(gtype):
     mp.spawn(_run_graphed, args=(2, _free_port(), gtype), nprocs=2, join=True)
 
 
+def _run_graphed_bench_shape(rank, world, port, pipeline, compress):
+    """the data-parallel graph schedule at the BENCH shape -- 256 samples per rank, bf16, n_critic = 2 -- on two
+    ranks (gloo, sharing cuda:0): `pipeline` 0 = the default single-communicator dp_branch schedule, 1 = the two-communicator
+    pipelined one (GCSSL_DP_PIPELINE=1, opt-in since round 4).  Three replays against three eager iterations of a twin engine on
+    the same ranks: finite, the optimiser step counts, no weight further apart than Adam's steps allow, and -- the property
+    data parallelism rests on -- the replicas of BOTH ranks bit-identical after every exchange form."""
+    import importlib
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), GCSSL_DIST_BACKEND="gloo", GCSSL_SINGLE_DEVICE="1", GCSSL_DP_PIPELINE=str(pipeline))
+    dist_mod = importlib.import_module(PKG + ".dist")
+    synth = importlib.import_module(PKG + ".synth")
+    engine = importlib.import_module(PKG + ".engine")
+    dist_mod.init_from_env()
+    T = torch.from_numpy
+    seed, Bt, S, c = 31, 512, 32, 2
+    g = {k: T(v) for k, v in synth.generator_state(seed).items()}
+    d = {k: T(v) for k, v in synth.discriminator_state(seed).items()}
+    inp = synth.step_inputs(seed, Bt, S, c, tag="dpbench")
+    sh = lambda a: dist_mod.shard(T(a), rank, world).contiguous().cuda()
+    refined = [sh(x) for x in inp["refined"]]
+    call = (sh(inp["pred"]), sh(inp["gt"]), sh(inp["delta_true"]), sh(inp["pred_box"]), lambda delta, k: refined[k])
+    mk = lambda: engine.StepEngine(g, d, batch=Bt // world, size=S, n_critic=c, dtype="bf16", device="cuda:0", seed=77 + rank,
+                                   allreduce=dist_mod.GradAverager(compress=compress), keep_clipped_grads=False)
+    eager, graphed = mk(), mk()
+    gi = engine.GraphedIteration(graphed, *call)
+    assert not gi.fused_update and gi.dp_pipeline == bool(pipeline)
+    for _ in range(3):
+        eager.run_iteration(*call)
+        gi.replay()
+    torch.cuda.synchronize()
+    lr = 2e-4
+    for name, a, b, steps in (("D", eager.D.p, graphed.D.p, 6), ("G", eager.G.p, graphed.G.p, 3)):
+        assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all()), name
+        assert float((a - b).abs().max()) <= 2.2 * lr * steps, (name, float((a - b).abs().max()))
+    assert float(graphed.D.state[0]) == 6.0 and float(graphed.G.state[0]) == 3.0
+    assert graphed.saturations() == {"critic": 0, "generator": 0}
+    for eng in (eager, graphed):                                   # replicas stay identical without ever exchanging weights
+        for flat in (eng.D.p, eng.G.p):
+            mine = flat.cpu()
+            both = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(both, mine)
+            assert torch.equal(both[0], both[1])
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("pipeline,compress", [(0, None), (1, None), (0, "bf16")])
+def test_graphed_dp_schedule_at_bench_shape(pipeline, compress):
+    mp.spawn(_run_graphed_bench_shape, args=(2, _free_port(), pipeline, compress), nprocs=2, join=True)
+
+
 def _run_rccl_one_rank(rank, world, port):
     """The data-parallel schedule on the REAL backend (nccl == RCCL) with one rank: process group, RCCL communicator, async
     all-reduces between the captured graph segments (GCSSL_FORCE_DP=1 makes a world of 1 take that path) -- against the

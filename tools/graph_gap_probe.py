@@ -1,5 +1,5 @@
 """GPU-side gaps between graph launches (run under rocprofv3 --kernel-trace, then tools/prof_timeline.py).
-usage: python tools/graph_gap_probe.py {critic_only|critic_first|full|no_events} [iterations]"""
+usage: python tools/graph_gap_probe.py {critic_only|gen_only|critic_first|full|no_events} [iterations]"""
 import importlib, os, sys, time
 from pathlib import Path
 import torch
@@ -19,6 +19,8 @@ t0 = time.perf_counter()
 for _ in range(iters):
     if mode == "critic_only":
         gi.c_a.replay(); gi.c_b.replay()
+    elif mode == "gen_only":                       # the generator's chain alone (results are garbage after the first: timing only)
+        gi.g_a.replay(); gi.g_b.replay()
     elif mode == "full":
         gi.replay()
     elif mode == "no_events":                      # both chains free-running (results are garbage: timing only)
