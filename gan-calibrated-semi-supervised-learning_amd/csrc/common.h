@@ -191,7 +191,7 @@ __device__ __forceinline__ float lrelu_f(float x) { return x > 0.f ? x : 0.2f * 
 // ---- zero fills as KERNELS.  hipMemsetAsync / hipMemset2DAsync must not be used on a path that may be stream-captured: on
 // ROCm 7.2 the memset node of the instantiated graph replays with a garbage fill pattern once the host memory the call's
 // parameters lived in has been reused (measured: the InstanceNorm backward's scratch came back filled with 0x61 / 0x6f
-// bytes = 2.6e20 / 7.4e28 on the second replay, depending on what Python had allocated in between; tools/replay_diag9.py).
+// bytes = 2.6e20 / 7.4e28 on the second replay, depending on what Python had allocated in between; tools/archive/replay_diag9.py).
 static __global__ __launch_bounds__(256) void gcssl_zero_kernel(float* __restrict__ p, size_t n) {
     const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)

@@ -911,7 +911,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
         // Consumers, software-pipelined over the barrier: after barrier j the fragment reads of tile j are ISSUED and the MFMAs
         // of tile j-1 (fragments already in registers) run while those reads are in flight.  With reads -> wait -> MFMAs inside
         // one barrier interval a step cost ~1550 cycles for 512 cycles of MFMA per SIMD: all eight waves read at once right
-        // after the barrier, then all run their MFMAs, and nothing overlaps.  (tools/probes/fill_probe.hip: the loaders alone
+        // after the barrier, then all run their MFMAs, and nothing overlaps.  (tools/archive/probes/fill_probe.hip: the loaders alone
         // bring this layer's gather in at 80 GB/s per CU, twice what the unpipelined loop consumed.)
         if constexpr (!PIPE) {                                             // reads -> MFMAs inside one barrier interval (fewer registers)
             int slot = 0;
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
     }
     // ---- result tile through LDS (default): the MFMA C layout gives a lane one 4-byte element per row, i.e. 32 store
     // instructions of 2 x 128 bytes per wave for a 32 x 64 wave tile; after a transpose through the (now idle) ring every
-    // store instruction writes 64 x 16 bytes of whole rows.  tools/tile_ab.sh with GCSSL_RING_DEBUG=3 (no DMA, no MFMA:
+    // store instruction writes 64 x 16 bytes of whole rows.  tools/archive/tile_ab.sh with GCSSL_RING_DEBUG=3 (no DMA, no MFMA:
     // launch + prologue + barriers + epilogue) put D.c3.fwd's skeleton at 14.5 of its 24 us.
     {
         const int es = (p.out_f32 || p.ksplit > 1) ? 4 : 2;                // element size of what is stored
@@ -2350,7 +2350,7 @@ long tile_threshold() {
 }
 
 // 128x128 (one workgroup per CU: 96 KB of LDS) lost to 128x64 (two per CU) on every layer of the forced-tile matrix
-// (tools/conv_matrix.sh: D.c2.fwd 37.6 -> 29.7 us, D.c3.dgrad 35.2 -> 27.6 us), so it needs many more tiles to be chosen
+// (tools/archive/conv_matrix.sh: D.c2.fwd 37.6 -> 29.7 us, D.c3.dgrad 35.2 -> 27.6 us), so it needs many more tiles to be chosen
 long tile128_threshold() {
     static long v = [] { const char* e = getenv("GCSSL_TILE128_WGS"); return e ? atol(e) : 2048L; }();
     return v;
@@ -2410,7 +2410,7 @@ int zero_output(const ConvParams& p, long rows, int cols, hipStream_t st) {
 
 // 256-row tiles, bf16 LDS-DMA path only: 8 waves as 4 (M) x 2 (N), so a wave owns 64x64 (or 64x32) outputs and issues
 // 16 (8) MFMAs per K step against a fixed per-step cost (barrier skew, DMA issue, fragment reads) of ~750 cycles --
-// measured with s_memtime (tools/trace_conv.py): with 32x32 wave tiles that fixed cost is 5x the MFMA time.
+// measured with s_memtime (tools/archive/trace_conv.py): with 32x32 wave tiles that fixed cost is 5x the MFMA time.
 // 144 KB (120 KB) of LDS: one workgroup per CU, two waves per SIMD.
 const char* forced_tile() {
     static const char* v = getenv("GCSSL_FORCE_TILE");       // "256x128", "256x64", "128x128", "128x64", "64x64": experiments

@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void dot_accum_kernel(const T* __restrict__ x,
 }
 
 // Same-address float atomics serialise (~12 ns each, and a 256-byte bias vector shares a few memory-side lines): 768
-// workgroups adding 64 bias sums each cost 70 us on a 17-us pass (tools/actbwd_bench.py).  The sums therefore go to one of
+// workgroups adding 64 bias sums each cost 70 us on a 17-us pass (tools/archive/actbwd_bench.py).  The sums therefore go to one of
 // nrep replicas chosen by workgroup index; gcssl_sum_replicas folds them afterwards.
 bool bad_dtype(int dt) { return gcssl_bad_dtype(dt); }
 

@@ -330,7 +330,7 @@ def test_full_size_iteration_matches_oracle(synth, B, S, mode):
         # oracle gradients agree to ~1e-4 of each tensor's scale (checked above), so the ~0.3 % of elements with
         # |g| below that take opposite signs and land 2*lr apart: a fixed random perturbation of norm ~0.04 against
         # a gradient of norm ~1e3 -> ~1 % on d_loss/gp.  (The engine against ITSELF under a different summation order
-        # moves 5e-5: tools/probe_chaos.py.)  The step function at the updated weights is checked tightly below by
+        # moves 5e-5: tools/archive/probe_chaos.py.)  The step function at the updated weights is checked tightly below by
         # restarting both sides from the oracle's post-iteration state.
         tol = 2e-4 if ci == 0 else 2e-2
         got = np.array([log["d_loss"][ci], log["gp"][ci], log["wd"][ci], log["d_grad_norm"][ci]])
@@ -410,7 +410,7 @@ def test_graph_replay_matches_eager_at_bench_config(synth, dtype, form, monkeypa
     keyed by (seed, phase, optimiser step count), so both sides draw identical values; what remains is the order of float atomics.
 
     With lr = 0 the weights never move, so EVERY iteration is comparable (a training run is chaotic: two eager runs of the same
-    seed agree on only ~45 % / 12 % of the critic's weights to 2e-6 after 2 / 3 fp16 iterations -- tools/replay_diag.py): the
+    seed agree on only ~45 % / 12 % of the critic's weights to 2e-6 after 2 / 3 fp16 iterations -- tools/archive/replay_diag.py): the
     clipped gradients the updates leave in the buckets must agree after every replay.  This is also the check of ADVICE r1:
     the captured graph must contain the gradient zero fills although a fresh engine's buckets are zero at capture time --
     replays used to accumulate onto the previous iteration's clipped gradients (a 2x error at the second replay)."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of the working tree against the tree in ab_prev/ (a built checkout of an earlier commit; not committed):
-# alternate the two bench commands and print images/s of the sustained window.  usage: tools/ab_prev.sh <outdir> [bench args]
+# alternate the two bench commands and print images/s of the sustained window.  usage: tools/archive/ab_prev.sh <outdir> [bench args]
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$1; shift
 mkdir -p $O

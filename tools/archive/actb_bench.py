@@ -1,5 +1,5 @@
 """GPU time of gcssl_conv4x4s2_dgrad_act_bwd at the critic's c2 shape (N x 16 x 16 x 64 <- N x 8 x 8 x 128), 40 launches per
-graph replay.  usage: python tools/actb_bench.py [N] [eager launches instead of the graph, for rocprofv3 --pmc passes]"""
+graph replay.  usage: python tools/archive/actb_bench.py [N] [eager launches instead of the graph, for rocprofv3 --pmc passes]"""
 import importlib, sys, torch
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -1,4 +1,4 @@
-"""Is the batched activation backward bound by its bias/SN atomics?  usage: python tools/actbwd_bench.py"""
+"""Is the batched activation backward bound by its bias/SN atomics?  usage: python tools/archive/actbwd_bench.py"""
 import importlib, sys, torch
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -1,6 +1,6 @@
 """Do CU-masked streams let the critic's and the generator's chains run side by side?  Both chains free-running (no events:
 timing only, results are garbage) on two streams created with hipExtStreamCreateWithCUMask.
-usage: python tools/cu_mask_probe.py"""
+usage: python tools/archive/cu_mask_probe.py"""
 import ctypes, importlib, sys, time
 from pathlib import Path
 import torch

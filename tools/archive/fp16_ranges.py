@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dynamic range of the fp16 mode's 16-bit gradient tensors after one iteration at the bench configuration: largest
 magnitude against the 65504 ceiling, and the share of non-zero entries below fp16's smallest normal (6.1e-5), with the
-engine's static loss scales applied.  Run on the GPU box: python tools/fp16_ranges.py [scale_d scale_g]"""
+engine's static loss scales applied.  Run on the GPU box: python tools/archive/fp16_ranges.py [scale_d scale_g]"""
 import importlib
 import os
 import sys

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """fp16 mode over many training iterations on a fixed synthetic batch: largest magnitude of every 16-bit gradient tensor
 against the 65504 ceiling, critic gradient norm, and the first non-finite tensor if any.
-    python tools/fp16_stability.py [iters] [dtype]"""
+    python tools/archive/fp16_stability.py [iters] [dtype]"""
 import importlib, os, sys, torch
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

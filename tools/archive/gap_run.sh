@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): tools/gap_run.sh <outdir under gpurun_out> <mode> <marker> <every>
+# usage (GPU box): tools/archive/gap_run.sh <outdir under gpurun_out> <mode> <marker> <every>
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof_$2

@@ -4,7 +4,7 @@ Builds two copies of the library into /tmp -- the shipped sources, and one in wh
 conv kernels gathers from the SAME sample (n forced to 0 in the row offset: identical instruction stream, identical
 number of gathered bytes, but a footprint of one sample that stays in the nearest cache) -- and times one conv
 configuration with both.  Results of the second build are garbage; only its time matters.
-usage: python tools/gather_probe.py {fwd|dgrad|c3} N Hi Cin Cout [reps]"""
+usage: python tools/archive/gather_probe.py {fwd|dgrad|c3} N Hi Cin Cout [reps]"""
 import re
 import subprocess
 import sys

@@ -2,7 +2,7 @@
 """True magnitudes (fp32 parity mode, loss scale 1) of every tensor the 16-bit modes store in 16 bits on the critic's
 gradient paths, at the bench configuration: where do they sit relative to fp16's normal range [6.1e-5, 65504]?  For each
 tensor: max, median, and the share of its ENERGY (sum of squares) carried by entries below fp16's smallest normal / smallest
-subnormal for a candidate scale.  Run on the GPU box: python tools/grad_ranges.py"""
+subnormal for a candidate scale.  Run on the GPU box: python tools/archive/grad_ranges.py"""
 import importlib, sys
 from pathlib import Path
 import torch

@@ -1,5 +1,5 @@
 """Graph replay vs eager launches at the bench configuration, lr = 0: which scalars / gradient tensors differ, per iteration.
-usage: python tools/graph_diag.py [fp16|bf16] [iters]"""
+usage: python tools/archive/graph_diag.py [fp16|bf16] [iters]"""
 import importlib, sys
 from pathlib import Path
 import numpy as np

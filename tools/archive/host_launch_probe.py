@@ -1,6 +1,6 @@
 """Host-side cost of the graph launches of one iteration (two-stream form): wall-clock time of every replay() call and of
 the whole iteration, GPU idle (synchronised) vs GPU busy (host running ahead).
-usage (GPU box): python tools/host_launch_probe.py"""
+usage (GPU box): python tools/archive/host_launch_probe.py"""
 import importlib, os, sys, time
 from pathlib import Path
 import torch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """fp16 mode error against the pinned oracle as a function of the critic's static loss scale (GCSSL_LOSS_SCALE_D): is the
 one-sided un-clipped gradient-norm error of the fp16 mode a range effect (saturation at the top / flush at the bottom) or
-operand rounding?  Run on the GPU box:  python tools/ls_sweep.py [scales...]  (GCSSL_FIN=0 in the environment: unfused norms)"""
+operand rounding?  Run on the GPU box:  python tools/archive/ls_sweep.py [scales...]  (GCSSL_FIN=0 in the environment: unfused norms)"""
 import importlib, json, os, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent

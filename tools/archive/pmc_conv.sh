@@ -1,5 +1,5 @@
 #!/bin/bash
-# memory-path PMC passes for ONE conv configuration (run on the GPU box):  tools/pmc_conv.sh fwd 768 8 128 256
+# memory-path PMC passes for ONE conv configuration (run on the GPU box):  tools/archive/pmc_conv.sh fwd 768 8 128 256
 # Each pass is its own rocprofv3 run with --kernel-trace only (no other trace domains), as the pool requires, and is
 # bounded by its own timeout.  (A pass with the TA_* stall counters + TCP_READ_TAGCONFLICT_STALL_CYCLES aborted inside
 # rocprofv3 and hung the run on this image: they are left out.  What is established about the cause: `rocprofv3 -L` lists
@@ -8,7 +8,7 @@
 # slot counts MI355X_MICROARCH.md does not give (it lists SQ 8, TCC 4, GRBM 2) and its log was not kept, so an
 # oversubscribed TA/TCP group is the likely cause but not a proven one.  The aborted pass hung until the timeout -- on this
 # pool a hang that outlives gpurun's limit is a strike -- so it was NOT re-run to find out; the question the counters were
-# meant to answer (is the gather path stalled by L1 tag conflicts?) was answered differently, by tools/gather_probe.py.)
+# meant to answer (is the gather path stalled by L1 tag conflicts?) was answered differently, by tools/archive/gather_probe.py.)
 set -e; set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_conv

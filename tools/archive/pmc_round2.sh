@@ -39,4 +39,4 @@ for c in "${CASES[@]}"; do
   done
   echo "$tag done" >> $OUT/progress.txt
 done
-cd $R && python3 tools/pmc_round2_summary.py $OUT $DT
+cd $R && python3 tools/archive/pmc_round2_summary.py $OUT $DT

@@ -21,7 +21,7 @@ CASES=(
  "D.c2.wgrad|conv_wgrad|tools/conv_bench.py wgrad 1024 16 64 128 $DT 5"
  "D.c3.wgrad|conv_wgrad|tools/conv_bench.py wgrad 1024 8 128 256 $DT 5"
  "D.c4.wgrad|conv_wgrad|tools/conv_bench.py wgrad 1024 4 256 512 $DT 5"
- "D.c2.dgrad|dgrad_img|tools/actb_bench.py 768 5"
+ "D.c2.dgrad|dgrad_img|tools/archive/actb_bench.py 768 5"
  "D.c3.dgrad|conv_dma|tools/conv_bench.py dgrad 768 8 128 256 $DT 5"
  "D.c4.dgrad|conv_dma|tools/conv_bench.py dgrad 768 4 256 512 $DT 5"
  "D.c1.fwd[n=768]|conv_|tools/conv_bench.py fwd16 768 32 8 64 $DT 5"
@@ -40,4 +40,4 @@ for c in "${CASES[@]}"; do
   done
   echo "$tag done" >> $OUT/progress.txt
 done
-cd $R && python3 tools/pmc_round2_summary.py $OUT $DT round3_pmc_dominant.json tools/pmc_round3.sh
+cd $R && python3 tools/archive/pmc_round2_summary.py $OUT $DT round3_pmc_dominant.json tools/pmc_round3.sh

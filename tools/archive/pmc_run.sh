@@ -1,6 +1,6 @@
 #!/bin/bash
 # One rocprofv3 --pmc pass (kernel trace only, as the pool requires; the program directly after `--`) over a python tool:
-#   tools/pmc_run.sh TAG "COUNTER1 COUNTER2 ..." tools/convt_bench.py 768 16 128
+#   tools/archive/pmc_run.sh TAG "COUNTER1 COUNTER2 ..." tools/convt_bench.py 768 16 128
 # writes gpurun_out/pmc_TAG/ and prints the per-kernel averages of every counter (tools/pmc_summary.py).
 set -o pipefail
 TAG=$1; CTRS=$2; shift 2

@@ -1,6 +1,6 @@
 #!/bin/bash
 # True kernel durations (rocprofv3 kernel trace) of one conv shape under the forced-tile knob:
-#   tools/tile_ab.sh "fwd 768 8 128 256" "dgrad 768 8 128 256" ...
+#   tools/archive/tile_ab.sh "fwd 768 8 128 256" "dgrad 768 8 128 256" ...
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -4,7 +4,7 @@ Builds an INSTRUMENTED copy of csrc/igemm.hip into /tmp (the shipped library is 
 configuration and prints, per phase, the mean / p50 / p95 shader cycles over the workgroups of the last launch:
   setup   kernel entry -> gather offsets ready        first   -> first K tile landed (DMA latency, pipeline fill)
   loop    remaining K loop                            epi     epilogue (stores / atomics)
-usage: python tools/trace_conv.py {fwd|dgrad} N Hi Cin Cout [reps]      (env knobs GCSSL_* apply as usual)"""
+usage: python tools/archive/trace_conv.py {fwd|dgrad} N Hi Cin Cout [reps]      (env knobs GCSSL_* apply as usual)"""
 import ctypes
 import os
 import re

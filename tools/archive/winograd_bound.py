@@ -4,7 +4,7 @@ F(2x2,3x3) replaces the 9*Cin-deep contraction per output pixel by 16 contractio
 4*Cin per output pixel: 2.25x fewer MACs AND 2.25x fewer operand bytes through LDS.  The direct kernel run with its K loop cut
 to 4 of its 9 steps (GCSSL_KCAP=4; results are garbage) does exactly that volume of fills + MFMAs with NO transform work, no
 16 separate accumulator sets and no output transform: a lower bound on any Winograd form of this kernel.  GCSSL_KCAP=2 is
-(almost) the launch skeleton.  Run on the GPU box, one process per setting:  GCSSL_KCAP=4 python tools/winograd_bound.py"""
+(almost) the launch skeleton.  Run on the GPU box, one process per setting:  GCSSL_KCAP=4 python tools/archive/winograd_bound.py"""
 import importlib, os, sys, torch
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stand-alone timing of the fused transposed-conv kernel (csrc/convt_fused.hip) against the unfused pair (LDS-DMA dgrad-form
-conv + InstanceNorm pass):  python tools/convt_bench.py [N H K dtype iters]"""
+conv + InstanceNorm pass):  python tools/convt_bench.py [N H K [bf16|fp16]]"""
 import importlib
 import os
 import sys
@@ -43,14 +43,15 @@ def run(N, H, K, dt, iters=20, fused=True):
 
 
 if __name__ == "__main__":
-    dt = torch.float16
+    # (round 3's PMC record of the dominant label was taken in fp16 under a bf16 heading: this script ignored the dtype -- VERDICT r3 #10)
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[sys.argv[4]] if len(sys.argv) > 4 else torch.bfloat16
     if len(sys.argv) > 3:
         cases = [(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))]
     else:
         cases = [(n, 16, 128) for n in (8, 32, 64, 128, 256, 512, 768)] + [(n, 8, 256) for n in (128, 512, 1024, 3072)]
     for N, H, K in cases:
         us_f, tf_f = run(N, H, K, dt, fused=True)
-        us_u, tf_u = run(N, H, K, dt, fused=False)
+        us_u, tf_u = (run(N, H, K, dt, fused=False) if not os.environ.get("GCSSL_CT_FUSED_ONLY") else (0.0, 0.0))
         blocks = N * H * H // 256
         print(f"N={N:5d} H={H:2d} K={K:3d} blocks={blocks:4d}  fused {us_f:8.1f} us {tf_f:7.1f} TF/s ({us_f / -(-blocks // 256) / (K // 8):6.2f} us/step)   "
               f"unfused conv+norm {us_u:8.1f} us  rotate={os.environ.get('GCSSL_CT_ROTATE', '1')}")

@@ -1,17 +1,14 @@
 #!/bin/bash
-# Everything the round's final artefacts come from, in one GPU-box call: the -m gpu suite, the default bench line, the kernel
-# trace + timeline of the headline configuration, the one-rank RCCL rehearsal, and the PMC passes of c2's fused data gradient.
-# usage (GPU box): tools/final_run.sh <outdir under gpurun_out>
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O
+# Everything the round's committed artefacts come from, in one GPU-box call: the -m gpu suite, the default bench line, the kernel
+# trace + timeline + per-label in-graph durations of the headline configuration, the same for the split-precision mode, the
+# one-rank RCCL rehearsal, the interference probe and the PMC passes.  usage (GPU box): tools/final_run.sh <outdir under gpurun_out> [parts]
+# parts (default all): t = tests, b = bench, p = profiles, x = split-mode profile, d = DP rehearsal, i = interference, c = PMC
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O; P=${2:-tbpxdic}
 cd $R
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/gpu.log 2>&1; tail -n 2 $O/gpu.log
-timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-120 $O/bench.json
-tools/prof_bench.sh $1/prof > /dev/null 2>&1; head -n 2 $O/prof/kernel_summary.txt
-GCSSL_FORCE_DP=1 timeout -k 10 200 python bench.py --no-also --no-cpu-baseline > $O/bench_dp1.json 2>/dev/null; cut -c1-100 $O/bench_dp1.json
-cd /tmp && export TMPDIR=/tmp
-d=$R/gpurun_out/pmc_r3/D.c2.dgrad; rm -rf $d; mkdir -p $d; i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
-  i=$((i+1))
-  (cd $R && timeout -k 10 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d/p$i -o r -- python3 tools/actb_bench.py 768 5 > $d/p$i.log 2>&1) || { echo "pmc pass $i failed"; exit 1; }
-done
-echo "pmc ok"
+if [[ $P == *t* ]]; then timeout -k 10 1100 python -m pytest tests -x -q -m gpu > $O/gpu.log 2>&1; tail -n 2 $O/gpu.log; fi
+if [[ $P == *b* ]]; then timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-160 $O/bench.json; fi
+if [[ $P == *p* ]]; then tools/prof_bench.sh $1/prof > /dev/null 2>&1; head -n 2 $O/prof/kernel_summary.txt; head -n 3 $O/prof/label_durations.txt; fi
+if [[ $P == *x* ]]; then tools/prof_bench.sh $1/prof_x3 --dtype fp16x3 > /dev/null 2>&1; head -n 2 $O/prof_x3/kernel_summary.txt; fi
+if [[ $P == *d* ]]; then GCSSL_FORCE_DP=1 timeout -k 10 200 python bench.py --no-also --no-cpu-baseline > $O/bench_dp1.json 2>/dev/null; cut -c1-100 $O/bench_dp1.json; fi
+if [[ $P == *i* ]]; then tools/interference.sh $1/intf > $O/intf.log 2>&1; tail -n 12 $O/intf/interference_trace.txt; fi
+if [[ $P == *c* ]]; then tools/pmc_round4.sh $1/pmc > $O/pmc.log 2>&1; tail -n 14 $O/pmc.log; fi

@@ -16,16 +16,30 @@ from collections import defaultdict
 
 
 def short(n):
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", n)
+    if m:                                                       # mangled name of an anonymous-namespace kernel: base + integer template arguments
+        ln = int(m.group(1))
+        base, rest = n[m.end():m.end() + ln], n[m.end() + ln:]
+        ints = re.findall(r"L[ib]n?(\d+)E", rest.split("EEv")[0]) if rest.startswith("I") else []
+        ty = "bf16" if "DF16b" in rest[:8] else "f16" if "DF16_" in rest[:8] else "f32" if rest.startswith("If") else ""
+        return f"{base}<{ty}{',' if ty and ints else ''}{','.join(ints)}>"[:72]
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     n = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", n)
     return n[:72]
 
 
 def load(db):
+    """launches of the probe's measured loop only: behind the LAST long pause of the run (graph capture / the synchronize in front
+    of the loop) and without the first fifth of what follows (tools/graph_gap_probe.py replays 20 whole iterations first)"""
     c = sqlite3.connect(db)
     rows = c.execute("select name, start, end, grid_x*grid_y*grid_z/(workgroup_x*workgroup_y*workgroup_z) from kernels order by start").fetchall()
-    n = len(rows)
-    return rows[n // 4:]                      # steady state: drop the warm-up / capture quarter
+    cut = 0
+    for i in range(1, len(rows)):
+        if rows[i][1] - rows[i - 1][2] > 20e6:                   # > 20 ms without a kernel
+            cut = i
+    rows = rows[cut:]
+    t0, t1 = rows[0][1], rows[-1][2]
+    return [r for r in rows if r[1] > t0 + 0.2 * (t1 - t0)]
 
 
 def per_kernel(rows, with_overlap=False):
@@ -61,7 +75,13 @@ def main():
         n_it = max(1, sum(v[0] for k, v in pk.items() if "adam_kernel" in k[0]) / (2 if tag == "critic" else 1))
         iters[tag] = n_it
         for k, v in pk.items():
-            alone[k] = (tag, v[0] / n_it, v[1] / v[0])
+            if v[0] / n_it < 0.5:                                # (a straggler of the warm-up, not a launch of this chain)
+                continue
+            if k in alone:                                       # a launch shape both chains have: launch-weighted mean
+                t0, p0, a0 = alone[k]
+                alone[k] = ("both", p0 + v[0] / n_it, (a0 * p0 + v[1] / n_it) / (p0 + v[0] / n_it))
+            else:
+                alone[k] = (tag, v[0] / n_it, v[1] / v[0])
     rows = load(dbs[2])
     pk = per_kernel(rows, with_overlap=True)
     n_it = max(1, sum(v[0] for k, v in pk.items() if "adam_kernel" in k[0]) / 3)

@@ -21,4 +21,4 @@ for set in "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TCC_A
 done
 cd $R
 python tools/interference_pmc.py $O > $O/interference_pmc.txt 2>&1; cat $O/interference_pmc.txt
-for d in $O/t_* $O/p?_*; do [ -d $d ] && find $d -name "*.db" -delete; done
+for d in $O/t_* $O/p?_*; do [ -d $d ] && find $d -name "*.db" -delete; [ -d $d ] && find $d -name "*agent_info.csv" -delete; done

@@ -22,18 +22,48 @@ from pathlib import Path
 
 
 def base_and_ints(expr: str):
-    """'(conv_dma_kernel<O, 128, 128, 0, 4, 2, false, 8>)' -> ('conv_dma_kernel', ['128', '128', '0', '4', '2', 'false', '8'])"""
+    """'(conv_dma_kernel<O, 128, 128, MODE, 4, 2, false, 8>)' -> ('conv_dma_kernel', ['128', '128', None, '4', '2', 'false', '8']):
+    the non-type template arguments by POSITION (the first argument of every kernel template here is its element type); an
+    argument the launch site spells symbolically (MODE, BM, ...) is None = matches anything."""
     m = re.match(r"\(?\s*([A-Za-z_]\w*)\s*(?:<(.*)>)?\s*\)?$", expr.strip())
     if not m:
         return expr, []
     args = [a.strip() for a in (m.group(2) or "").split(",")] if m.group(2) else []
-    return m.group(1), [a for a in args if re.fullmatch(r"-?\d+|true|false", a)]
+    return m.group(1), [a if re.fullmatch(r"-?\d+|true|false", a) else None for a in args[1:]]
+
+
+def args_match(expr_args, trace_ints) -> bool:
+    return len(trace_ints) >= len(expr_args) and all(e is None or e == t for e, t in zip(expr_args, trace_ints))
 
 
 def trace_args(name: str):
-    """demangled kernel name -> (base, [integer / bool template arguments in order])"""
+    """kernel name as the trace has it -> (base, [integer / bool template arguments in order]).  rocprofv3's rocpd database keeps
+    the MANGLED name for kernels of an anonymous namespace (_ZN12_GLOBAL__N_1<len><name>I<template args>E...): integer arguments
+    are Li<n>E / Lin<n>E, booleans Lb0E / Lb1E; type arguments (DF16b, DF16_, f) are skipped.  Demangled names are parsed too."""
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if m:
+        ln = int(m.group(1))
+        base = name[m.end():m.end() + ln]
+        rest = name[m.end() + ln:]
+        ints = []
+        if rest.startswith("I"):
+            # the template argument list ends at the 'E' that closes it, right in front of the function's own 'E' + signature
+            depth, i, tok = 1, 1, []
+            while i < len(rest) and depth:
+                mm = re.match(r"L([ib])(n?)(\d+)E", rest[i:])
+                if mm:
+                    v = mm.group(3)
+                    ints.append(("true" if v == "1" else "false") if mm.group(1) == "b" else ("-" + v if mm.group(2) else v))
+                    i += mm.end(); continue
+                mm = re.match(r"DF16[b_]|[a-z]", rest[i:])
+                if mm and rest[i] != "E":
+                    i += mm.end(); continue
+                if rest[i] == "E":
+                    depth -= 1
+                i += 1
+        return base, ints
     n = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"([A-Za-z_]\w*)\s*(?:<(.*)>)?\s*\(", n)
+    m = re.match(r"([A-Za-z_]\w*)\s*(?:<(.*)>)?\s*(?:\(|$)", n)
     if not m:
         return n, []
     args, depth, cur = [], 0, ""
@@ -78,7 +108,7 @@ def main():
     for lab, rec in labels.items():
         b, ints = base_and_ints(rec["kernel"])
         cand = by.get((b, int(rec["workgroups"])), [])
-        ds = [d for ti, d in cand if ti[:len(ints)] == ints]
+        ds = [d for ti, d in cand if args_match(ints, ti)]
         out[lab] = dict(kernel=rec["kernel"], workgroups=rec["workgroups"], launches_in_trace=len(ds),
                         in_graph_avg_us=round(sum(ds) / len(ds), 2) if ds else None, probe_us=rec["probe_us"],
                         launches_per_iter=rec["launches_per_iter"], gflop=rec["gflop"])
