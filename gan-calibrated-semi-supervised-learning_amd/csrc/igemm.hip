@@ -375,6 +375,7 @@ struct ConvParams {
                                           // first kcap K steps of every tile -- the K volume a Winograd F(2x2,3x3) GEMM stage would have
     float mm_oscale;                      // split-precision forms (MM != 0): the packed weights carry a power-of-two pre-scale
                                           // (gcssl_prep_conv_weights with a split dtype); its inverse, applied in the epilogue
+    float* fin_z; int ld_fin_z;           // conv_fwd_kernel's FIN form (split-precision modes): the fp32 pre-norm tensor is STILL stored (nullable)
     void* in_apre; int ld_apre, apre_n0;  // optional second output: the activation WITHOUT dropout for samples n >= apre_n0
                                           // ([N - apre_n0][Ho*Wo][ld_apre]): what the backward rebuilds xhat from
 };
@@ -385,7 +386,10 @@ struct ConvParams {
 // ------------------------------------------------------------------------------------------
 // WM x WN waves (default 2 x 2 = the 256 threads of NT; the split-precision forms also run 4 x 2: a K step of theirs is issue-bound
 // -- MFMA phase, then split + LDS stores -- and with two waves per SIMD inside a workgroup one wave's VALU work runs under the other's MFMAs)
-template <typename T, int BM, int BN, int KS = 4, int MM = 0, int WM = 2, int WN = 2>
+// FIN (split-precision forms, fp32 tensors): InstanceNorm + LeakyReLU in the epilogue, as in conv_dma_kernel's FIN forms -- the tile
+// holds BM / (H*W) whole samples -- but with fp32 outputs and the pre-norm z STILL written (p.fin_z, nullable): the fp32 backward
+// kernels read z; what the fusion removes is the separate norm launch and its read of z.
+template <typename T, int BM, int BN, int KS = 4, int MM = 0, int WM = 2, int WN = 2, bool FIN = false>
 __global__ __launch_bounds__(WM * WN * 64, MM ? (WM * WN >= 8 ? 4 : 2) : 1) void conv_fwd_kernel(ConvParams p) {
     typedef Geo<KS> G;
     constexpr int NT = WM * WN * 64;
@@ -541,6 +545,57 @@ __global__ __launch_bounds__(WM * WN * 64, MM ? (WM * WN >= 8 ? 4 : 2) : 1) void
     for (int j = 0; j < TN; ++j) {
         const int co = n0 + wn0 + 32 * j + (lane & 31);
         bcol[j] = (p.bias && co < p.Cout && (p.ksplit <= 1 || ks == 0)) ? p.bias[co] : 0.f;
+    }
+    if constexpr (FIN) {
+        // (host: fp32 tensors, no K split, H*W <= 64 divides BM, Cout % 4 == 0, 16-byte aligned rows)
+        constexpr int RS = BN * 4;                                   // LDS tile row stride (bytes): the operand tiles are done with
+        static_assert(sizeof(As) + sizeof(Bs) >= (size_t)BM * RS, "result tile must fit the operand tiles");
+        __shared__ float fin_stat[(BM / 4) * BN * 2];              // (mu, rstd) per (sample of the tile, column)
+        unsigned char* lds = reinterpret_cast<unsigned char*>(&As[0]);
+        const int lgHW = p.lgHoWo, HW = 1 << lgHW, nsamp = BM >> lgHW;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + 32 * i + crow(r, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    *reinterpret_cast<float*>(lds + row * RS + (wn0 + 32 * j + (lane & 31)) * 4) = acc[i][j][r] * sc[i][r] + bcol[j];
+            }
+        __syncthreads();
+        const int s0 = m0 >> lgHW;
+        const float inv_hw = 1.f / (float)HW;
+        for (int q = tid; q < nsamp * BN; q += NT) {                 // one (sample, column) per thread: exact two-pass statistics
+            const int sidx = q / BN, c = q % BN;
+            const unsigned char* colp = lds + (sidx << lgHW) * RS + c * 4;
+            float sum = 0.f;
+            for (int r = 0; r < HW; ++r) sum += *reinterpret_cast<const float*>(colp + r * RS);
+            const float mu = sum * inv_hw;
+            float m2 = 0.f;
+            for (int r = 0; r < HW; ++r) { const float d = *reinterpret_cast<const float*>(colp + r * RS) - mu; m2 += d * d; }
+            const float rs = 1.0f / sqrtf(m2 * inv_hw + 1e-5f);
+            fin_stat[q * 2] = mu; fin_stat[q * 2 + 1] = rs;
+            const int n = s0 + sidx, cg = n0 + c;
+            if (n < p.N && cg < p.Cout) { p.in_mean[(size_t)n * p.Cout + cg] = mu; p.in_rstd[(size_t)n * p.Cout + cg] = rs; }
+        }
+        __syncthreads();
+        float* az = static_cast<float*>(p.y);                        // the activation
+        float* zz = p.fin_z;                                         // the pre-norm values (nullable)
+        constexpr int CPR = BN / 4;                                  // 16-byte chunks per tile row
+        for (int cix = tid; cix < BM * CPR; cix += NT) {
+            const int row = cix / CPR, ch = cix % CPR, m = m0 + row, col0 = n0 + ch * 4;
+            if (m >= p.M || col0 >= p.Cout) continue;
+            const float4 v = *reinterpret_cast<const float4*>(lds + row * RS + ch * 16);
+            const float4* st4 = reinterpret_cast<const float4*>(fin_stat + ((row >> lgHW) * BN + ch * 4) * 2);
+            const float4 q0 = st4[0], q1 = st4[1];                   // (mu, rs) x 4 columns
+            float4 o;
+            o.x = lrelu_f((v.x - q0.x) * q0.y); o.y = lrelu_f((v.y - q0.z) * q0.w);
+            o.z = lrelu_f((v.z - q1.x) * q1.y); o.w = lrelu_f((v.w - q1.z) * q1.w);
+            if (zz) *reinterpret_cast<float4*>(zz + (size_t)m * p.ld_fin_z + col0) = v;
+            *reinterpret_cast<float4*>(az + (size_t)m * p.ldy + col0) = o;
+        }
+        return;
     }
     float* yk = y32 + (p.ksplit > 1 ? (size_t)ks * p.split_stride : 0);
     const bool f32o = p.out_f32 || std::is_same<T, float>::value;
@@ -3350,6 +3405,43 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
     if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
     GCSSL_DISPATCH_CONV(dtype, return (dispatch_fwd<T, MM>(p, st)));
     return GCSSL_EBADDTYPE;
+}
+
+// ---- split-precision modes: forward conv + InstanceNorm + LeakyReLU in one launch on fp32 tensors (conv_fwd_kernel's FIN form:
+// 128 x 64 tiles, 8 waves).  Served when a 128-row tile holds whole samples (H*W/4 <= 64 output pixels), the tiles fill the chip
+// without a K split (the statistics need complete sums) and Cin, Cout >= 64.  z (nullable) still receives the pre-norm values.
+static bool fin_x3_shape(int N, int Hi, int Wi, int Cin, int Cout) {
+    static const bool on = [] { const char* e = getenv("GCSSL_X3_FIN"); return !(e && e[0] == '0'); }();
+    static const long min_wgs = [] { const char* e = getenv("GCSSL_X3_FIN_WGS"); return e ? atol(e) : 192L; }();
+    const int HW = (Hi / 2) * (Wi / 2);
+    const long M = (long)N * HW;
+    return on && HW <= 64 && HW >= 4 && Cin >= 64 && Cout >= 64 && M >= 128 && ((M + 127) / 128) * (Cout / 64) >= min_wgs;
+}
+int gcssl_conv4x4s2_in_act_x3_ok(int dtype, int N, int Hi, int Wi, int Cin, int Cout) {
+    int rc = check_geom(N, Hi, Wi, Cin, Cout);
+    if (rc) return rc;
+    if (dtype != GCSSL_F32_F16X3 && dtype != GCSSL_F32_BF16X3) return 0;
+    return fin_x3_shape(N, Hi, Wi, Cin, Cout) ? 1 : 0;
+}
+int gcssl_conv4x4s2_in_act_x3_fwd(int dtype, const void* x, int ldx, const void* wf, const float* bias, const float* gscale, int group_n,
+                                  float* z, int ldz, float* a, int lda, float* mean, float* rstd, int N, int Hi, int Wi, int Cin,
+                                  int Cout, void* stream) {
+    if (!x || !wf || !a || !mean || !rstd) return GCSSL_ENULL;
+    int rc = check_geom(N, Hi, Wi, Cin, Cout);
+    if (rc) return rc;
+    if (dtype != GCSSL_F32_F16X3 && dtype != GCSSL_F32_BF16X3) return GCSSL_EBADDTYPE;
+    if (!fin_x3_shape(N, Hi, Wi, Cin, Cout) || ldx < Cin || lda < Cout || (z && ldz < Cout) || (gscale && group_n <= 0)) return GCSSL_EBADSHAPE;
+    if (ldx % 4 || lda % 4 || (z && ldz % 4) || !aligned16(x) || !aligned16(wf) || !aligned16(a) || (z && !aligned16(z))) return GCSSL_EALIGN;
+    ConvParams p{}; p.x = x; p.w = wf; p.y = a; p.bias = bias; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
+    p.ldx = ldx; p.ldy = lda; p.act = 1; p.in_mean = mean; p.in_rstd = rstd; p.fin_z = z; p.ld_fin_z = ldz;
+    fill_geom(p, N, Hi, Wi, Cin, Cout);
+    if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)Cout * 16 * Cin, 4)) return GCSSL_EBADSHAPE;
+    set_mm_scales(p, true);
+    p.ksplit = 1;
+    dim3 grid((p.M + 127) / 128, (Cout + 63) / 64, 1);
+    if (dtype == GCSSL_F32_F16X3) GCSSL_LAUNCH((conv_fwd_kernel<float, 128, 64, 4, 1, 4, 2, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
+    else GCSSL_LAUNCH((conv_fwd_kernel<float, 128, 64, 4, 2, 4, 2, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
+    return gcssl_launch_status();
 }
 
 // 1 if gcssl_conv4x4s2_in_act_fwd serves these shapes (16-bit dtype, H*W/4 <= 64 output pixels per sample, enough tiles

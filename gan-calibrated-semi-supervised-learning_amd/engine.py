@@ -366,6 +366,13 @@ class StepEngine:
             self._fin_cache[key] = self.code != _lib.F32 and ops.conv_in_act_ok(self.code, n, hi, cin, cout)
         return self._fin_cache[key]
 
+    def _fin_x3(self, n: int, hi: int, cin: int, cout: int) -> bool:
+        """split-precision modes: does the one-launch conv + InstanceNorm + LeakyReLU form on fp32 tensors serve these shapes?"""
+        key = ("x3", n, hi, cin, cout)
+        if key not in self._fin_cache:
+            self._fin_cache[key] = self.mma != self.code and ops.conv_in_act_x3_ok(self.mma, n, hi, cin, cout)
+        return self._fin_cache[key]
+
     def _actb(self, n: int, hi: int, cin: int, cout: int, with_sums: bool) -> bool:
         """does the one-launch dgrad + activation-backward form serve a data gradient of these shapes?"""
         key = ("actb", n, hi, cin, cout, with_sums)
@@ -605,6 +612,12 @@ class StepEngine:
                            self.d_a[l][:n], self.d_mean[l][:n], self.d_rstd[l][:n], cin, cout, bias=bias,
                            gscale=gscale_of_layer(l), group_n=group_n)
                 self._d_zsrc[l] = self.d_a[l]
+            elif self._fin_x3(n, self.S >> l, cin, cout):
+                # split-precision modes: the same fusion on fp32 tensors; z is still stored (the fp32 backward kernels read it)
+                self._conv(f"D.c{l + 1}.fwd[n={n}]", fl, ops.conv_in_act_x3_fwd, self.d_a[l - 1][:n], self.d_wf[l], self.d_z[l][:n],
+                           self.d_a[l][:n], self.d_mean[l][:n], self.d_rstd[l][:n], cin, cout, bias=bias,
+                           gscale=gscale_of_layer(l), group_n=group_n)
+                self._d_zsrc[l] = self.d_z[l]
             else:
                 ns, st = self._split("fwd", self.d_z[l], n, self.S >> l, cin, cout)
                 self._conv(f"D.c{l + 1}.fwd[n={n}]", fl, ops.conv_fwd, self.d_a[l - 1][:n], self.d_wf[l],
@@ -671,6 +684,10 @@ class StepEngine:
                 continue
             if bwd_here:
                 self._g_zsrc[k] = self.g_zd[k]
+            if dmask[k] is None and self._fin_x3(n, S >> k, cin, cout):          # (split-precision modes; down4's output is masked: unfused)
+                self._conv(f"G.down{k + 1}.fwd{tag}", conv_flops(n, S >> k, cin, cout), ops.conv_in_act_x3_fwd, dins[k], self.gd_wf[k],
+                           f.zd[k], douts[k], f.dmean[k], f.drstd[k], cin, cout)
+                continue
             ns, st = self._split("fwd", f.zd[k], n, S >> k, cin, cout)
             self._conv(f"G.down{k + 1}.fwd{tag}", conv_flops(n, S >> k, cin, cout), ops.conv_fwd, dins[k], self.gd_wf[k],
                        f.zd[k], cin, cout, split_stride=st)

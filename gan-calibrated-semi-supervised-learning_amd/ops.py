@@ -108,6 +108,22 @@ def conv_in_act_fwd(x, wf, a, mean, rstd, cin, cout, bias=None, gscale=None, gro
          _ld(apre) if apre is not None else 0, int(apre_n0), N, Hi, Wi, cin, cout, LRELU)
 
 
+def conv_in_act_x3_ok(dt, N, Hi, cin, cout) -> bool:
+    """split-precision modes: does the one-launch conv + InstanceNorm + LeakyReLU form on fp32 tensors serve these shapes?"""
+    r = _lib.call_nostream("gcssl_conv4x4s2_in_act_x3_ok", dt, N, Hi, Hi, cin, cout)
+    if r < 0:
+        raise RuntimeError(f"conv_in_act_x3_ok{(N, Hi, cin, cout)} -> {r}")
+    return bool(r)
+
+
+def conv_in_act_x3_fwd(x, wf, z, a, mean, rstd, cin, cout, bias=None, gscale=None, group_n=0, dt=None):
+    """Conv2d(k4,s2,p1) + InstanceNorm + LeakyReLU(0.2) in one launch on fp32 tensors (split-precision MFMA): a, the statistics and
+    (z not None) the pre-norm values."""
+    N, Hi, Wi, _ = x.shape
+    call("gcssl_conv4x4s2_in_act_x3_fwd", dt, x, _ld(x), wf, bias, gscale, group_n, z, _ld(z) if z is not None else 0, a, _ld(a),
+         mean, rstd, N, Hi, Wi, cin, cout)
+
+
 def conv_dgrad(dy, wt, dx, cin, cout, gscale=None, group_n=0, split_stride=0, dt=None):
     """dx: [N][Hi][Wi][>=cin] (fp32 output allowed whatever dy's dtype), dy: [N][Hi/2][Wi/2][>=cout]."""
     N, Hi, Wi, _ = dx.shape
@@ -488,4 +504,4 @@ def mlp_head_bwd(gdelta, traw, h1, h2, feat, w1, w2, w3, delta_scale, train, dp1
 
 
 #: the wrappers that take the conv dtype keyword `dt` (StepEngine injects its split-precision code into these)
-CONV_FNS = (conv_fwd, conv_dgrad, conv_wgrad, conv3_fwd, conv3_wgrad)
+CONV_FNS = (conv_fwd, conv_dgrad, conv_wgrad, conv3_fwd, conv3_wgrad, conv_in_act_x3_fwd)

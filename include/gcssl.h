@@ -103,6 +103,15 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
  * fp32 slabs y + k*split_stride (no memset, no atomics: float atomics run at 1.3 TB/s chip-wide) and the consumer
  * adds them (gcssl_in_act_fwd nslab); with split_stride = 0 they are added atomically into y, which the call zeroes. */
 int gcssl_conv4x4s2_fwd_splits(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int act, int out_f32);
+/* Split-precision modes (GCSSL_F32_F16X3 / GCSSL_F32_BF16X3; fp32 tensors): nn.Conv2d(k4,s2,p1) + InstanceNorm2d + LeakyReLU(0.2) of
+ * cgan/models.py:236-242 / :57-60 in ONE launch -- a (fp32 activation), mean / rstd ([N][Cout] fp32) and, when z is not NULL, the
+ * fp32 pre-norm values too (the fp32 backward kernels read them).  _ok: 1 if the shapes are served (whole samples per 128-row
+ * tile: H*W/4 <= 64 output pixels; enough tiles without a K split), else 0 -- the caller then keeps gcssl_conv4x4s2_fwd +
+ * gcssl_in_act_fwd. */
+int gcssl_conv4x4s2_in_act_x3_ok(int dtype, int N, int Hi, int Wi, int Cin, int Cout);
+int gcssl_conv4x4s2_in_act_x3_fwd(int dtype, const void* x, int ldx, const void* wf, const float* bias, const float* gscale, int group_n,
+                                  float* z, int ldz, float* a, int lda, float* mean, float* rstd, int N, int Hi, int Wi, int Cin,
+                                  int Cout, void* stream);
 /* Conv2d(k4,s2,p1) + InstanceNorm2d + LeakyReLU(0.2) [+ Dropout(0.5)] as ONE launch -- the whole `conv_block` of
  * cgan/models.py:236-242 (D.c2-c4) / `UNetDown` of :54-66 (G.down2-4) -- for 16-bit dtypes and output maps of <= 64 pixels:
  * a GEMM tile then holds whole samples, the per-(n, c) statistics are taken from the fp32 accumulators inside the conv

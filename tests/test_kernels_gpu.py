@@ -216,6 +216,45 @@ def test_conv_split_precision(ops, mode, tol, N, Hi, Cin, CinP, Cout):
     assert rel_err(dw.cpu(), conv2d_weight(x.double(), (Cout, Cin, 4, 4), dy.double(), 2, 1)) < tol
 
 
+@pytest.mark.parametrize("mode", ["fp16x3", "bf16x3"])
+@pytest.mark.parametrize("N,Hi,Cin,Cout", [(768, 16, 64, 128), (768, 8, 128, 256), (768, 4, 256, 512), (771, 8, 128, 256), (256, 16, 64, 128)])
+def test_conv_in_act_fused_split_precision(ops, mode, N, Hi, Cin, Cout):
+    """The split-precision modes' conv + InstanceNorm + LeakyReLU launch (fp32 tensors) against conv (fp64) -> InstanceNorm ->
+    LeakyReLU: pre-norm values, statistics and activation at the modes' conv tolerance; ragged last tile (N = 771); the
+    activation written into a channel slice of a wider buffer."""
+    lib = load_pkg("_lib")
+    code = lib.mma_code(mode)
+    assert ops.conv_in_act_x3_ok(code, N, Hi, Cin, Cout)
+    tol = 2e-5 if mode == "fp16x3" else 1e-4
+    x = rnd(N, Cin, Hi, Hi, seed=1)
+    w = rnd(Cout, Cin, 4, 4, seed=2, scale=0.05)
+    b = rnd(Cout, seed=3, scale=0.1)
+    group_n = (N + 2) // 3
+    gs = torch.tensor([1.3, 0.7, 2.1])[: (N + group_n - 1) // group_n]
+    wf = torch.empty(Cout, 16, Cin, device="cuda")
+    ops.prep_conv_weight(w.cuda(), wf, None, Cout, Cin, Cin, code)
+    xd = nhwc(x, torch.float32)
+    Ho = Hi // 2
+    z = torch.full((N, Ho, Ho, Cout), float("nan"), device="cuda")
+    wide = torch.full((N, Ho, Ho, Cout + 64), float("nan"), device="cuda")
+    a = wide[..., 64:]
+    mean = torch.full((N, Cout), float("nan"), device="cuda"); rstd = torch.full((N, Cout), float("nan"), device="cuda")
+    ops.conv_in_act_x3_fwd(xd, wf, z, a, mean, rstd, Cin, Cout, bias=b.cuda(), gscale=gs.cuda(), group_n=group_n, dt=code)
+    torch.cuda.synchronize()
+    lin = F.conv2d(x.double(), w.double(), None, 2, 1) * gs[torch.arange(N) // group_n].view(-1, 1, 1, 1).double() + b.view(1, -1, 1, 1).double()
+    mu = lin.mean((2, 3), keepdim=True); var = lin.var((2, 3), unbiased=False, keepdim=True)
+    ref = F.leaky_relu((lin - mu) / torch.sqrt(var + 1e-5), 0.2)
+    assert rel_err(nchw(z), lin) < tol
+    assert rel_err(mean.cpu(), mu.view(N, Cout)) < 10 * tol
+    assert rel_err(rstd.cpu(), (1.0 / torch.sqrt(var + 1e-5)).view(N, Cout)) < 1e-3      # (rstd of a 2x2 map amplifies z's error by rstd^2 sigma)
+    assert rel_err(nchw(a), ref) < 2e-3 if Hi == 4 else rel_err(nchw(a), ref) < 2e-4
+    assert bool(torch.isnan(wide[..., :64]).all())                                        # nothing outside the slice was touched
+    # z = None: only the activation and the statistics
+    a2 = torch.full((N, Ho, Ho, Cout), float("nan"), device="cuda")
+    ops.conv_in_act_x3_fwd(xd, wf, None, a2, mean, rstd, Cin, Cout, bias=b.cuda(), gscale=gs.cuda(), group_n=group_n, dt=code)
+    assert torch.equal(a2, a.contiguous())
+
+
 def test_conv_split_precision_small_magnitudes(ops):
     """fp16 halves have fp16's exponent range: operands far below 1 lose their lo bits to subnormals unless the engine's static
     scales (loss scale on gradients, 2^6 on weights inside the kernel) keep them up.  Pinned here: gradients of magnitude 1e-3
