@@ -3412,7 +3412,9 @@ int gcssl_conv4x4s2_fwd(int dtype, const void* x, int ldx, const void* wf, const
 // without a K split (the statistics need complete sums) and Cin, Cout >= 64.  z (nullable) still receives the pre-norm values.
 static bool fin_x3_shape(int N, int Hi, int Wi, int Cin, int Cout) {
     static const bool on = [] { const char* e = getenv("GCSSL_X3_FIN"); return !(e && e[0] == '0'); }();
-    static const long min_wgs = [] { const char* e = getenv("GCSSL_X3_FIN_WGS"); return e ? atol(e) : 192L; }();
+    // (>= 384 workgroups: D.c4 at n = 768 would run 192 workgroups of 128 K steps each unsplit -- 93 us in the probe, 151 us beside
+    //  the generator's chain, against 68 + 14 us for its two-way K split + norm launch: round 4, profiles/round4_x3_*)
+    static const long min_wgs = [] { const char* e = getenv("GCSSL_X3_FIN_WGS"); return e ? atol(e) : 384L; }();
     const int HW = (Hi / 2) * (Wi / 2);
     const long M = (long)N * HW;
     return on && HW <= 64 && HW >= 4 && Cin >= 64 && Cout >= 64 && M >= 128 && ((M + 127) / 128) * (Cout / 64) >= min_wgs;

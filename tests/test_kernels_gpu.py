@@ -217,7 +217,7 @@ def test_conv_split_precision(ops, mode, tol, N, Hi, Cin, CinP, Cout):
 
 
 @pytest.mark.parametrize("mode", ["fp16x3", "bf16x3"])
-@pytest.mark.parametrize("N,Hi,Cin,Cout", [(768, 16, 64, 128), (768, 8, 128, 256), (768, 4, 256, 512), (771, 8, 128, 256), (256, 16, 64, 128)])
+@pytest.mark.parametrize("N,Hi,Cin,Cout", [(768, 16, 64, 128), (768, 8, 128, 256), (1536, 4, 256, 512), (771, 8, 128, 256), (512, 16, 64, 128)])
 def test_conv_in_act_fused_split_precision(ops, mode, N, Hi, Cin, Cout):
     """The split-precision modes' conv + InstanceNorm + LeakyReLU launch (fp32 tensors) against conv (fp64) -> InstanceNorm ->
     LeakyReLU: pre-norm values, statistics and activation at the modes' conv tolerance; ragged last tile (N = 771); the
