@@ -38,6 +38,20 @@ def _pad8(c: int) -> int:
     return max(8, c)
 
 
+# Side streams are shared by every engine of a process (one per device and role).  HIP deals streams to a small pool of hardware
+# queues round-robin; an engine that creates fresh streams every time ends up, after a few engines in one process, with its side
+# stream on the SAME hardware queue as the compute stream -- the two chains of the iteration then run one after the other.
+# (Round 4: bench.py's fifth configuration, fp16x3, read 57.0k images/s as an `also` entry and 67-69k as a run of its own.)
+_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(dev, role: str, priority: int = 0) -> "torch.cuda.Stream":
+    key = (str(dev), role, priority)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)
+    return _STREAMS[key]
+
+
 def _algorithmic_bytes(label: str, args, es: int):
     """-> (algorithmic, stored) bytes of one conv launch.  Algorithmic is SURVEY.md 8(d)'s definition: the input read once
     + the result written once + the weights read once, every element at the compute dtype's size `es` (a wgrad's result is
@@ -230,7 +244,7 @@ class StepEngine:
         # layer's wgrad + split-K reduce beside the dependent dgrad -> norm-backward chain.  None of these kernels
         # fills 256 CUs on its own.
         self.overlap = int(overlap)
-        self.side = [torch.cuda.Stream(device=dev) for _ in range(2)] if overlap else []
+        self.side = [_side_stream(dev, f"fine{i}") for i in range(2)] if overlap else []
         self._in_g_branch = False
         # ONE coarse branch (round 3): the generator step's own work -- EIoU, backward through the head, the up and the down
         # path, its split-K reduction: ~45 launches, 0.45 ms, none of which fills the chip -- does not depend on the critic
@@ -242,8 +256,8 @@ class StepEngine:
         #  neutral, 120.5k vs 120.4k.  The older fine-grained `overlap` levels stay out of the generator's branch: a fork out of
         #  a captured branch crashed the ROCm 7.2 graph capture; beside it, on the critic's side only, they cost 4.5 %.)
         self.overlap_g = int(os.environ.get("GCSSL_OVERLAP_G", "1")) if allreduce is None else 0
-        self.side_g = torch.cuda.Stream(device=dev) if self.overlap_g else None
-        self.side_sn = torch.cuda.Stream(device=dev) if self.overlap_g >= 2 else None
+        self.side_g = _side_stream(dev, "gen") if self.overlap_g else None
+        self.side_sn = _side_stream(dev, "sn") if self.overlap_g >= 2 else None
         self.probe = None          # {label: {"events": [(start, stop)...], "flops": f}} when profiling is enabled
         self.probe_repeats = 0
 
@@ -1280,7 +1294,7 @@ class GraphedIteration:
             self.two_stream = self.pipelined and os.environ.get("GCSSL_TWO_STREAM", "1") != "0"
             if self.two_stream:
                 c = eng.c
-                self.side = torch.cuda.Stream(device=eng.dev)
+                self.side = _side_stream(eng.dev, "gen")
                 eng._g_dirty = True
                 pool_main, pool = pool, None                       # the generator's graphs replay beside the critic's: own pool
                 self.prologue = capture(lambda: eng.g_forward_all(pred, None))
@@ -1355,7 +1369,7 @@ class GraphedIteration:
                             getattr(eng.allreduce, "group", "x") != "x" and torch.distributed.is_initialized())
         if self.dp_pipeline:
             c = eng.c
-            self.side = torch.cuda.Stream(device=eng.dev)
+            self.side = _side_stream(eng.dev, "gen")
             self.g_avg = type(eng.allreduce)(group=torch.distributed.new_group())    # (collective: every rank builds its engine here)
             self._primed, self.pipelined = False, True
             pool_main, pool = pool, None                                   # the generator's graphs replay beside the critic's: own pool
@@ -1377,7 +1391,7 @@ class GraphedIteration:
                 eng._in_g_branch = False
             return
         if self.dp_branch:
-            self.side = torch.cuda.Stream(device=eng.dev, priority=int(os.environ.get("GCSSL_SIDE_PRIO", "0")))
+            self.side = _side_stream(eng.dev, "gen", int(os.environ.get("GCSSL_SIDE_PRIO", "0")))
             self.gfwd = capture(lambda: eng.g_forward_all(pred, None))
             eng._g_dirty = False
             self.first = capture(lambda: (eng.d_pre(pred, gt, refine_fn, 0, None, None), eng.d_main()))
