@@ -1301,16 +1301,18 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void conv_dma_kernel(ConvParam
 // Both operands arrive row(k)-major with channels contiguous -> MMajor tiles, transposed LDS reads.
 // ------------------------------------------------------------------------------------------
 // SMALLC (first layers, Cin padded to 8): the N tile is all 16 taps x 8 channels (BN must be 128).
-template <typename T, int BM, int BN, bool SMALLC, int KS = 4, int MM = 0>
-__global__ __launch_bounds__(NT, MM ? 2 : 1) void conv_wgrad_kernel(ConvParams p) {
+template <typename T, int BM, int BN, bool SMALLC, int KS = 4, int MM = 0, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(WM * WN * 64, MM ? (WM * WN >= 8 ? 4 : 2) : 1) void conv_wgrad_kernel(ConvParams p) {
     typedef Geo<KS> G;
+    constexpr int NT = WM * WN * 64;                          // (4 x 2 waves: the split-precision forms, see conv_fwd_kernel)
     constexpr int BK = BKOf<T>::v;
     constexpr int KV = Elem<T>::KV;
     static_assert(!SMALLC || BN == 128, "SMALLC covers 16 taps x 8 channels");
     constexpr int CHA = BM / KV, CHB = BN / KV;               // vectors per k-row
     constexpr int NVA = BK * CHA / NT, NVB = BK * CHB / NT;
-    static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 threads");
-    constexpr int TM = BM / 64, TN = BN / 64;
+    static_assert(NVA >= 1 && NVB >= 1, "tile too small for this many threads");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "tile too small for this many waves");
     __shared__ typename MTile<T, BM, MM>::type As[2];
     __shared__ typename MTile<T, BN, MM>::type Bs[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1332,7 +1334,7 @@ __global__ __launch_bounds__(NT, MM ? 2 : 1) void conv_wgrad_kernel(ConvParams p
     const int ntile_ci = SMALLC ? 1 : p.Cin / BN;
     const int tap = SMALLC ? 0 : by / ntile_ci, ci0 = SMALLC ? 0 : (by % ntile_ci) * BN;
     const int ky = G::ky(tap), kx = G::kx(tap);
-    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
     const T* x = static_cast<const T*>(p.x);
     const T* dy = static_cast<const T*>(p.w);
     const int Wo = p.Wi / G::ST;
@@ -3662,11 +3664,16 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
     }
     dim3 grid(Cout / bm, smallc ? 1 : 16 * (Cin / bn), nsplit);
 #define WG(T, A, B, S) GCSSL_LAUNCH((conv_wgrad_kernel<T, A, B, S, 4, MM>), grid, dim3(NT), 0, st, p)
+#define WG8(T, A, B) GCSSL_LAUNCH((conv_wgrad_kernel<T, A, B, false, 4, MM, 4, 2>), grid, dim3(512), 0, st, p)
+    static const int w8 = [] { const char* e = getenv("GCSSL_X3_WGRAD_WAVES"); return e ? atoi(e) : 8; }();   // split-precision forms: 8 waves (A/B: 4)
     GCSSL_DISPATCH_CONV(dtype,
         if (smallc) { if (bm == 128) WG(T, 128, 128, true); else WG(T, 64, 128, true); }
+        else if (MM != 0 && w8 == 16 && bm == 128 && bn == 128) { if constexpr (MM != 0) WG8(T, 128, 128); }   // (A/B only: spills, 68.7 -> 75.8 us)
+        else if (MM != 0 && w8 >= 8 && bm == 128 && bn == 64) { if constexpr (MM != 0) WG8(T, 128, 64); }       // 85.9 -> 81.9 us (D.c2 / G.up4 shapes)
         else if (bm == 128 && bn == 128) WG(T, 128, 128, false); else if (bm == 128) WG(T, 128, 64, false);
         else if (bn == 128) WG(T, 64, 128, false); else WG(T, 64, 64, false));
 #undef WG
+#undef WG8
     return gcssl_launch_status();
 }
 
