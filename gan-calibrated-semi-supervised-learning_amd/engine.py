@@ -46,6 +46,8 @@ _STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
 
 
 def _side_stream(dev, role: str, priority: int = 0) -> "torch.cuda.Stream":
+    if role == "gen" and priority == 0:
+        priority = int(os.environ.get("GCSSL_GEN_PRIO", "0"))       # A/B knob: the generator chain's stream at another priority
     key = (str(dev), role, priority)
     if key not in _STREAMS:
         _STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)

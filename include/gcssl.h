@@ -59,6 +59,12 @@ int gcssl_last_grid(void);
  * present and before capturing entry points into a hipGraph (they also do it lazily on first use, which a capture in
  * progress may refuse). */
 int gcssl_init(void);
+/* gcssl_init also allocates the ONE piece of device memory the library owns: the 16-byte barrier block of the cooperative
+ * spectral-norm chain (with GCSSL_SN_COOP=1 gcssl_sn_power_iter runs a whole chain of power iterations as one launch whose
+ * workgroups synchronise through it; the default is the multi-launch form, which measured faster: csrc/misc.hip).
+ * gcssl_sn_coop_status: 0 fine; 1 a workgroup once gave up waiting at a grid barrier (bounded spin: results of that chain are
+ * invalid -- it never happened in testing and means the grid was not co-resident); -1 not initialised.  Host-synchronous. */
+int gcssl_sn_coop_status(void);
 int gcssl_init_norm(void);
 int gcssl_init_recrop(void);
 

