@@ -2662,7 +2662,154 @@ __global__ __launch_bounds__(256) void conv_fwd_c8_kernel(ConvParams p, int ntil
     }
 #endif
 }
+// The same kernel for the split-precision modes (fp32 tensors, MFMA operands split into 16-bit halves: igemm.hip header): a
+// pixel's 8 fp32 channels are 32 bytes (two 16-byte loads) and become one hi and one lo fragment chunk when the image is
+// written to LDS -- two images; the fp32 packed weight (2^6-scaled, x3_wscale) is split once per workgroup into hi / lo
+// fragment sets that stay in registers; three MFMAs per (tap pair, 32 output channels): A_lo B_hi + A_hi B_lo + A_hi B_hi.
+// The generic split kernel spent 34.7 us on D.c1.fwd[n=768] (K = 128: four steps, all prologue / epilogue) against the
+// 16-bit kernel's 16.
+template <typename H>
+__global__ __launch_bounds__(256) void conv_fwd_c8_x3_kernel(ConvParams p, int ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef typename Frag16<H>::type FragT;
+    constexpr int MT = 128, WROW = 17;
+    extern __shared__ __attribute__((aligned(16))) unsigned char c8_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Wo = p.Wi >> 1, Ho = p.Hi >> 1, R = MT >> p.lgWo, rows = 2 * R + 2, rowpx = p.Wi + 2;
+    const int tiles_per_n = Ho / R;
+    const int npix = rows * rowpx;
+    uint4* img_hi = reinterpret_cast<uint4*>(c8_lds);                    // [rows][Wi + 2] pixels of 8 hi halves
+    uint4* img_lo = img_hi + npix;
+    unsigned char* outt = c8_lds + (size_t)npix * 32;                    // [128][64] fp32 result tile; first: the two weight images
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+    constexpr int NC = 3;
+    const int nchunk = rows * p.Wi;                                      // pixels of the image (<= 3 per thread)
+    u32x4 pre[NC][2];
+    auto fetch = [&](int tile) {
+        const int n = tile / tiles_per_n, iy0 = 2 * (tile - n * tiles_per_n) * R - 1;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c >> (p.lgWo + 1), px = c & (p.Wi - 1), iy = iy0 + row;
+            const bool ok = c < nchunk && (unsigned)iy < (unsigned)p.Hi;
+            const unsigned off = ok ? (unsigned)((((n * p.Hi + iy) * p.Wi + px) * p.ldx) * 4) : OOB;
+            pre[i][0] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+            pre[i][1] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? off + 16u : OOB, 0, 0);
+        }
+    };
+    auto split8 = [](const u32x4& a, const u32x4& b, uint4& hi, uint4& lo) {
+        uint2 h0, l0, h1, l1;
+        split4<H>(__builtin_bit_cast(float4, a), h0, l0);
+        split4<H>(__builtin_bit_cast(float4, b), h1, l1);
+        hi = make_uint4(h0.x, h0.y, h1.x, h1.y); lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    {
+        uint4* whi = reinterpret_cast<uint4*>(outt);
+        uint4* wlo = whi + 64 * WROW;
+        for (int c = tid; c < 64 * 16; c += 256) {                       // c -> (co, 8 consecutive K elements = tap pair half)
+            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)c * 32u, 0, 0);
+            const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)c * 32u + 16u, 0, 0);
+            uint4 hi, lo;
+            split8(a, b, hi, lo);
+            whi[(c >> 4) * WROW + (c & 15)] = hi; wlo[(c >> 4) * WROW + (c & 15)] = lo;
+        }
+        __syncthreads();
+    }
+    FragT bh[2][8], bl[2][8];                                            // lane -> co = 32 j + (lane & 31), tap = 2 ks + (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int e = (32 * j + (lane & 31)) * WROW + 2 * ks + (lane >> 5);
+            bh[j][ks] = __builtin_bit_cast(FragT, reinterpret_cast<const uint4*>(outt)[e]);
+            bl[j][ks] = __builtin_bit_cast(FragT, reinterpret_cast<const uint4*>(outt)[64 * WROW + e]);
+        }
+    const int pl = 32 * wave + (lane & 31), oyl = pl >> p.lgWo, ox = pl & (Wo - 1), h = lane >> 5;
+    unsigned char* yb = static_cast<unsigned char*>(p.y);
+    const bool actb = p.ab_a != nullptr;
+    float dot_acc = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_n, oy0 = (tile - n * tiles_per_n) * R;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = tid + 256 * i;
+            if (c < nchunk) {
+                uint4 hi, lo;
+                split8(pre[i][0], pre[i][1], hi, lo);
+                const int e = (c >> (p.lgWo + 1)) * rowpx + (c & (p.Wi - 1)) + 1;
+                img_hi[e] = hi; img_lo[e] = lo;
+            }
+        }
+        if (tid < 2 * rows) {
+            const int e = (tid >> 1) * rowpx + ((tid & 1) ? p.Wi + 1 : 0);
+            img_hi[e] = make_uint4(0u, 0u, 0u, 0u); img_lo[e] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int tap = 2 * ks + h, ky = tap >> 2, kx = tap & 3;
+            const int e = (2 * oyl + ky) * rowpx + 2 * ox + kx;
+            const FragT ah = __builtin_bit_cast(FragT, img_hi[e]), al = __builtin_bit_cast(FragT, img_lo[e]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[j] = mfma(al, bh[j][ks], acc[j]);
+                acc[j] = mfma(ah, bl[j][ks], acc[j]);
+                acc[j] = mfma(ah, bh[j][ks], acc[j]);
+            }
+        }
+        const float gs = (p.gscale ? p.gscale[n / p.group_n] : 1.f) * p.mm_oscale;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = 32 * j + (lane & 31);
+            const float b = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int prow = 32 * wave + crow(r, lane);
+                float v = acc[j][r] * gs + b;
+                if (p.act == 1) v = lrelu_f(v);
+                reinterpret_cast<float*>(outt)[prow * 64 + co] = v;
+            }
+        }
+        __syncthreads();
+        const size_t m0 = (size_t)(n * Ho + oy0) * Wo;
+        if (actb) {
+            // y = lrelu'(a) * v and the spectral-norm dot <dotx, v> of the same pass (conv_fwd_c8_kernel's ACTB form on fp32 tensors)
+            const unsigned char* ab = static_cast<const unsigned char*>(p.ab_a);
+            const unsigned char* xb = static_cast<const unsigned char*>(p.ab_dotx);
+            for (int c = tid; c < MT * 16; c += 256) {
+                const int px = c >> 4, ch = c & 15;
+                const float4 v = reinterpret_cast<const float4*>(outt)[c];
+                const float4 av = *reinterpret_cast<const float4*>(ab + ((m0 + px) * p.ab_lda) * 4 + ch * 16);
+                float4 o;
+                o.x = av.x > 0.f ? v.x : 0.2f * v.x; o.y = av.y > 0.f ? v.y : 0.2f * v.y;
+                o.z = av.z > 0.f ? v.z : 0.2f * v.z; o.w = av.w > 0.f ? v.w : 0.2f * v.w;
+                if (xb) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xb + ((m0 + px) * p.ab_lddot) * 4 + ch * 16);
+                    dot_acc += (xv.x * v.x + xv.y * v.y) + (xv.z * v.z + xv.w * v.w);
+                }
+                *reinterpret_cast<float4*>(yb + ((m0 + px) * p.ldy) * 4 + ch * 16) = o;
+            }
+            continue;
+        }
+        for (int c = tid; c < MT * 16; c += 256)
+            *reinterpret_cast<uint4*>(yb + ((m0 + (c >> 4)) * p.ldy) * 4 + (c & 15) * 16) = reinterpret_cast<const uint4*>(outt)[c];
+    }
+    if (actb && p.ab_dot_out) {
+        __shared__ float dred[4];
+        const float tot = block_sum<4>(dot_acc, dred);
+        if (tid == 0) atomicAdd(p.ab_dot_out, tot);
+    }
+#endif
+}
 // (A/B knob: GCSSL_C8_FWD=0 sends these shapes back to the generic tiles)
+bool c8_x3_on() { static const bool v = [] { const char* e = getenv("GCSSL_C8_X3"); return !(e && e[0] == '0'); }(); return v; }   // (A/B: the split-precision first-layer kernels)
 bool c8_fwd_on() { static const bool v = [] { const char* e = getenv("GCSSL_C8_FWD"); return !(e && e[0] == '0'); }(); return v; }
 
 // Tile plan of the split-precision forms.  Their operands are fp32 in memory (twice the bytes of a 16-bit tile per K element) and
@@ -2698,6 +2845,20 @@ int dispatch_fwd(ConvParams p, hipStream_t st) {
         const int nk = 16 * p.Cin / 32;
         int ks = 1;
         const int tile = p.Cin < 64 ? 0 : x3_plan(p.M, p.Cout, nk, 1, p.act == 0, &ks);
+        {
+            const int Wo = p.Wi / 2;
+            if (p.Cin == 8 && p.Cout == 64 && (Wo == 16 || Wo == 32 || Wo == 64) && (p.Hi / 2) % (128 / Wo) == 0 && c8_fwd_on() && c8_x3_on() &&
+                !p.split_stride && p.ldx % 4 == 0 && p.ldy % 4 == 0 && aligned16(p.x) && aligned16(p.w) && aligned16(p.y)) {
+                if (p.plan_out) { *p.plan_out = 1; return GCSSL_OK; }
+                const int R = 128 / Wo, rows = 2 * R + 2;
+                const size_t tile_b = (size_t)2 * 64 * 17 * 16;                           // two weight images (> the 32-KB fp32 result tile)
+                const size_t lds = (size_t)rows * (p.Wi + 2) * 32 + tile_b;
+                static const int gmax = [] { const char* e = getenv("GCSSL_C8_GRID"); return e ? atoi(e) : 2 * cu_count(); }();
+                const int ntiles = p.N * ((p.Hi / 2) / R), per = (ntiles + gmax - 1) / gmax, grid = (ntiles + per - 1) / per;
+                GCSSL_LAUNCH((conv_fwd_c8_x3_kernel<typename SplitH<MM>::type>), dim3((unsigned)grid), dim3(256), lds, st, p, ntiles);
+                return gcssl_launch_status();
+            }
+        }
         if (p.Cin >= 64) {
             p.ksplit = ks;
             if (ks > 1) {
@@ -2944,6 +3105,126 @@ __global__ __launch_bounds__(256) void conv_dgrad_c8_kernel(ConvParams p, int nt
     }
 #endif
 }
+// ... and its split-precision form (fp32 dy and Wt, hi / lo images, three MFMAs per step; see conv_fwd_c8_x3_kernel).  The
+// generic split kernel pads the 8 result channels to a 64-column tile in 4096 workgroups: 47.5 us for 0.8 GFLOP.
+template <typename H>
+__global__ __launch_bounds__(256) void conv_dgrad_c8_x3_kernel(ConvParams p, int ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef typename Frag16<H>::type FragT;
+    constexpr int WROW = 129;
+    extern __shared__ __attribute__((aligned(16))) unsigned char c8_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int py = wave >> 1, px = wave & 1;
+    const int Ho = p.Hi >> 1, Wo = p.Wi >> 1, R = 32 >> p.lgWo, rows = R + 2, rowpx = Wo + 2;
+    const int tiles_per_n = Ho / R;
+    const int npix = rows * rowpx;
+    uint4* img_hi = reinterpret_cast<uint4*>(c8_lds);                    // [rows][Wo + 2] pixels x 8 chunks of 8 hi halves
+    uint4* img_lo = img_hi + npix * 8;
+    unsigned char* outt = c8_lds + (size_t)npix * 256;                   // [2R][Wi][8] fp32 result tile; first: the two weight images
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes), wr = make_rsrc(p.w, p.w_bytes);
+    constexpr int NC = 3;
+    const int nchunk = rows * Wo * 8;                                    // 8-channel groups of the image (<= 3 per thread)
+    u32x4 pre[NC][2];
+    auto fetch = [&](int tile) {
+        const int n = tile / tiles_per_n, oy0 = (tile - n * tiles_per_n) * R;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = tid + 256 * i;
+            const int ch = c & 7, pxl = (c >> 3) & (Wo - 1), row = c >> (3 + p.lgWo), oy = oy0 - 1 + row;
+            const bool ok = c < nchunk && (unsigned)oy < (unsigned)Ho;
+            const unsigned off = ok ? (unsigned)((((n * Ho + oy) * Wo + pxl) * p.ldx + ch * 8) * 4) : OOB;
+            pre[i][0] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+            pre[i][1] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? off + 16u : OOB, 0, 0);
+        }
+    };
+    auto split8 = [](const u32x4& a, const u32x4& b, uint4& hi, uint4& lo) {
+        uint2 h0, l0, h1, l1;
+        split4<H>(__builtin_bit_cast(float4, a), h0, l0);
+        split4<H>(__builtin_bit_cast(float4, b), h1, l1);
+        hi = make_uint4(h0.x, h0.y, h1.x, h1.y); lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    {
+        uint4* whi = reinterpret_cast<uint4*>(outt);
+        uint4* wlo = whi + 8 * WROW;
+        for (int c = tid; c < 8 * 128; c += 256) {                       // c -> (ci, 8 consecutive co of a tap)
+            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)c * 32u, 0, 0);
+            const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)c * 32u + 16u, 0, 0);
+            uint4 hi, lo;
+            split8(a, b, hi, lo);
+            whi[(c >> 7) * WROW + (c & 127)] = hi; wlo[(c >> 7) * WROW + (c & 127)] = lo;
+        }
+        __syncthreads();
+    }
+    const int h = lane >> 5, ci = lane & 31;
+    FragT bh[2][2][4], bl[2][2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int tap = (a ? 3 - 3 * py : 1 + py) * 4 + (b ? 3 - 3 * px : 1 + px);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int e = (ci < 8 ? ci : 0) * WROW + tap * 8 + 2 * ks + h;
+                const uint4 wh = reinterpret_cast<const uint4*>(outt)[e], wl = reinterpret_cast<const uint4*>(outt)[8 * WROW + e];
+                bh[a][b][ks] = __builtin_bit_cast(FragT, ci < 8 ? wh : make_uint4(0u, 0u, 0u, 0u));
+                bl[a][b][ks] = __builtin_bit_cast(FragT, ci < 8 ? wl : make_uint4(0u, 0u, 0u, 0u));
+            }
+        }
+    const int r = lane & 31, jyl = r >> p.lgWo, jx = r & (Wo - 1);
+    unsigned char* yb = static_cast<unsigned char*>(p.y);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_n, oy0 = (tile - n * tiles_per_n) * R;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = tid + 256 * i;
+            if (c < nchunk) {
+                const int ch = c & 7, pxl = (c >> 3) & (Wo - 1), row = c >> (3 + p.lgWo);
+                const int pix = row * rowpx + pxl + 1;
+                uint4 hi, lo;
+                split8(pre[i][0], pre[i][1], hi, lo);
+                img_hi[pix * 8 + (ch ^ (pix & 7))] = hi; img_lo[pix * 8 + (ch ^ (pix & 7))] = lo;
+            }
+        }
+        if (tid < 2 * rows * 8) {
+            const int pix = (tid >> 4) * rowpx + (((tid >> 3) & 1) ? Wo + 1 : 0);
+            img_hi[pix * 8 + (tid & 7)] = make_uint4(0u, 0u, 0u, 0u); img_lo[pix * 8 + (tid & 7)] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int row = (a ? jyl - 1 + 2 * py : jyl) + 1, col = (b ? jx - 1 + 2 * px : jx) + 1;
+                const int pix = row * rowpx + col;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int e = pix * 8 + ((2 * ks + h) ^ (pix & 7));
+                    const FragT ah = __builtin_bit_cast(FragT, img_hi[e]), al = __builtin_bit_cast(FragT, img_lo[e]);
+                    acc = mfma(al, bh[a][b][ks], acc);
+                    acc = mfma(ah, bl[a][b][ks], acc);
+                    acc = mfma(ah, bh[a][b][ks], acc);
+                }
+            }
+        const float gs = (p.gscale ? p.gscale[n / p.group_n] : 1.f) * p.mm_oscale;
+        if (ci < 8) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int rr = crow(q, lane), oyl = 2 * (rr >> p.lgWo) + py, oxl = 2 * (rr & (Wo - 1)) + px;
+                reinterpret_cast<float*>(outt)[(oyl * p.Wi + oxl) * 8 + ci] = acc[q] * gs;
+            }
+        }
+        __syncthreads();
+        const size_t pix0 = (size_t)(n * p.Hi + 2 * oy0) * p.Wi;
+        for (int c = tid; c < 2 * R * p.Wi * 2; c += 256)
+            *reinterpret_cast<uint4*>(yb + ((pix0 + (c >> 1)) * p.ldy) * 4 + (c & 1) * 16) = reinterpret_cast<const uint4*>(outt)[c];
+    }
+#endif
+}
 // (A/B knob: GCSSL_C8_DGRAD=0 sends the shape back to the generic tiles)
 bool c8_dgrad_on() { static const bool v = [] { const char* e = getenv("GCSSL_C8_DGRAD"); return !(e && e[0] == '0'); }(); return v; }
 
@@ -2954,6 +3235,21 @@ template <typename T, int MM = 0>
 int dispatch_dgrad(ConvParams p, hipStream_t st) {
     if (MM) set_mm_scales(p, true);
     if constexpr (MM != 0) {
+        {
+            const int Wo = p.Wi / 2;
+            if (p.Cin == 8 && p.Cout == 64 && (Wo == 16 || Wo == 32) && (p.Hi / 2) % (32 / Wo) == 0 && c8_dgrad_on() && c8_x3_on() &&
+                !p.split_stride && !p.ab_a && p.ldx % 4 == 0 && p.ldy % 4 == 0 && aligned16(p.x) && aligned16(p.w) && aligned16(p.y)) {
+                if (p.plan_out) { *p.plan_out = 1; return GCSSL_OK; }
+                const int R = 32 / Wo, rows = R + 2;
+                size_t tile_b = (size_t)2 * R * p.Wi * 8 * 4;
+                if (tile_b < (size_t)2 * 8 * 129 * 16) tile_b = (size_t)2 * 8 * 129 * 16;   // the region first holds the two padded weight images
+                const size_t lds = (size_t)rows * (Wo + 2) * 256 + tile_b;
+                static const int gmax = [] { const char* e = getenv("GCSSL_C8_DGRID"); return e ? atoi(e) : 2 * cu_count(); }();
+                const int ntiles = p.N * ((p.Hi / 2) / R), per = (ntiles + gmax - 1) / gmax, grid = (ntiles + per - 1) / per;
+                GCSSL_LAUNCH((conv_dgrad_c8_x3_kernel<typename SplitH<MM>::type>), dim3((unsigned)grid), dim3(256), lds, st, p, ntiles);
+                return gcssl_launch_status();
+            }
+        }
         if (p.Cin >= 64) {
             const int nk = 4 * p.Cout / 32;
             int ks = 1;
@@ -3566,7 +3862,8 @@ static bool fwd_actb_shape(int N, int Hi, int Wi, int Cin, int Cout) {
 int gcssl_conv4x4s2_fwd_act_bwd_ok(int dtype, int N, int Hi, int Wi, int Cin, int Cout) {
     int rc = check_geom(N, Hi, Wi, Cin, Cout);
     if (rc) return rc;
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (dtype == GCSSL_F32_F16X3 || dtype == GCSSL_F32_BF16X3) return fwd_actb_shape(N, Hi, Wi, Cin, Cout) && c8_x3_on() ? 1 : 0;   // (fp32 tensors)
     return dtype != GCSSL_F32 && fwd_actb_shape(N, Hi, Wi, Cin, Cout) ? 1 : 0;
 }
 
@@ -3576,20 +3873,22 @@ int gcssl_conv4x4s2_fwd_act_bwd(int dtype, const void* x, int ldx, const void* w
     if (!x || !wf || !a || !y) return GCSSL_ENULL;
     int rc = check_geom(N, Hi, Wi, Cin, Cout);
     if (rc) return rc;
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (dtype == GCSSL_F32) return GCSSL_EBADDTYPE;
-    if (!fwd_actb_shape(N, Hi, Wi, Cin, Cout)) return GCSSL_EBADSHAPE;
+    const bool x3 = gcssl_f32_storage(dtype);                            // split-precision modes: every tensor here is fp32
+    if (!fwd_actb_shape(N, Hi, Wi, Cin, Cout) || (x3 && !c8_x3_on())) return GCSSL_EBADSHAPE;
     if ((dotx != nullptr) != (dot_out != nullptr)) return GCSSL_EBADSHAPE;
     if (ldx < Cin || lda < Cout || ldy < Cout || (dotx && lddot < Cout) || (gscale && group_n <= 0)) return GCSSL_EBADSHAPE;
-    if (ldx % 8 || lda % 8 || ldy % 8 || (dotx && lddot % 8) || !aligned16(x) || !aligned16(wf) || !aligned16(a) || !aligned16(y) ||
+    const int kv = x3 ? 4 : 8;
+    if (ldx % kv || lda % kv || ldy % kv || (dotx && lddot % kv) || !aligned16(x) || !aligned16(wf) || !aligned16(a) || !aligned16(y) ||
         (dotx && !aligned16(dotx))) return GCSSL_EALIGN;
     ConvParams p{}; p.x = x; p.w = wf; p.y = y; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
     p.ldx = ldx; p.ldy = ldy;
     p.ab_a = a; p.ab_lda = lda; p.ab_dotx = dotx; p.ab_lddot = lddot; p.ab_dot_out = dot_out; p.ab_sat = sat;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
-    if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)Cout * 16 * Cin, 2)) return GCSSL_EBADSHAPE;
+    if (!fill_bytes(p, (size_t)N * Hi * Wi * ldx, (size_t)Cout * 16 * Cin, x3 ? 4 : 2)) return GCSSL_EBADSHAPE;
     p.y_bytes = 1;
-    GCSSL_DISPATCH(dtype, return dispatch_fwd<T>(p, (hipStream_t)stream));
+    GCSSL_DISPATCH_CONV(dtype, return (dispatch_fwd<T, MM>(p, (hipStream_t)stream)));
     return GCSSL_EBADDTYPE;
 }
 

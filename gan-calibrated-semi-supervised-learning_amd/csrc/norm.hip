@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void in_fwd_lds_kernel(const float* __restrict
         if (mask) keep4(mask + ((size_t)n * HW + p) * C + c, k);
 #pragma unroll
         for (int j = 0; j < VC; ++j) { o[j] = act_fwd((v[j] - mu[j]) * r[j], act) * k[j]; s[j] += o[j]; }
-        st4<T>(ap + (size_t)p * lda, o);
+        if (a) st4<T>(ap + (size_t)p * lda, o);                           // (a == nullptr: only the statistics and the pool sums are wanted)
     }
     if (pool) {                                                         // sum over H*W of the activation (global average pool)
         combine(s, 0);
@@ -970,10 +970,13 @@ int gcssl_init_norm() {
 
 int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean, float* rstd,
                      const uint8_t* mask, float* pool, int nslab, long slab_stride, int N, int HW, int C, int act, void* stream) {
-    if (!z || !a || !mean || !rstd) return GCSSL_ENULL;
+    if (!z || !mean || !rstd) return GCSSL_ENULL;
+    // a == NULL: statistics + pool sums only (the generator's last activation feeds nothing but its global average pool) --
+    // served by the LDS-resident form, where it halves the launch's HBM traffic
+    if (!a && !(pool && HW > MID_HW && HW <= LDS_HW_MAX && C % 32 == 0 && nslab == 1)) return GCSSL_ENULL;
     if (nslab < 1 || (nslab > 1 && (slab_stride <= 0 || slab_stride % 4 || HW > MID_HW || pool))) return GCSSL_EBADSHAPE;
     if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
-    if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || lda < C || ldz % 4 || lda % 4 || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
+    if (N <= 0 || HW < 2 || C <= 0 || C % CW || ldz < C || (a && (lda < C || lda % 4)) || ldz % 4 || (act != 1 && act != 2)) return GCSSL_EBADSHAPE;
     if (!aligned16(z) || (((uintptr_t)a) & 7)) return GCSSL_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     if (HW <= MID_HW && !pool) {

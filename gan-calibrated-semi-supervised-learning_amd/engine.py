@@ -50,6 +50,8 @@ def _side_stream(dev, role: str, priority: int = 0) -> "torch.cuda.Stream":
         priority = int(os.environ.get("GCSSL_GEN_PRIO", "0"))       # A/B knob: the generator chain's stream at another priority
     key = (str(dev), role, priority)
     if key not in _STREAMS:
+        for i in range(int(os.environ.get("GCSSL_SIDE_SKIP", "0"))):  # A/B knob: which hardware queue the side stream lands on
+            _STREAMS[(str(dev), f"skip{i}", priority)] = torch.cuda.Stream(device=dev, priority=priority)
         _STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)
     return _STREAMS[key]
 
@@ -404,7 +406,7 @@ class StepEngine:
         """... and the one-launch first-layer conv + activation backward + dot of the reverse gradient-penalty chain?"""
         key = ("fwd_actb", n, hi, cin, cout)
         if key not in self._fin_cache:
-            self._fin_cache[key] = self.code != _lib.F32 and ops.conv_fwd_act_bwd_ok(self.code, n, hi, cin, cout)
+            self._fin_cache[key] = self.mma != _lib.F32 and ops.conv_fwd_act_bwd_ok(self.mma, n, hi, cin, cout)      # (16-bit and split modes)
         return self._fin_cache[key]
 
     # ------------------------------------------------------------------------------------------ buffers
@@ -734,7 +736,10 @@ class StepEngine:
             ns, st = self._split("dgrad", f.zu[k], n, S >> (3 - k), coutt, cint) if k < 3 else (1, 0)
             self._conv(f"G.up{k + 1}.fwd{tag}", conv_flops(n, S >> (3 - k), coutt, cint), ops.conv_dgrad, ins[k],
                        self.gu_wt[k], f.zu[k], coutt, cint, split_stride=st)
-            ops.in_act_fwd(f.zu[k], outs[k], f.umean[k], f.urstd[k], coutt, RELU,
+            # (up4's activation feeds nothing but the head's average pool and its backward reads z: where the launch can do
+            # without the store -- 32x32 maps -- it is not written)
+            skip_a = k == 3 and ns == 1 and ops.in_act_fwd_pool_only_ok(S * S, coutt)
+            ops.in_act_fwd(f.zu[k], None if skip_a else outs[k], f.umean[k], f.urstd[k], coutt, RELU,
                            mask=mk[k + 1] if k < 2 else None, pool=f.poolsum if k == 3 else None,
                            nslab=ns, slab_stride=st)
             if k == 3:

@@ -155,11 +155,11 @@ def conv_fwd_act_bwd_ok(dt, N, Hi, cin, cout) -> bool:
     return bool(r)
 
 
-def conv_fwd_act_bwd(x, wf, a, y, cin, cout, gscale=None, group_n=0, dotx=None, dot_out=None, sat=None):
+def conv_fwd_act_bwd(x, wf, a, y, cin, cout, gscale=None, group_n=0, dotx=None, dot_out=None, sat=None, dt=None):
     """conv_fwd (fp32 v, first layer 8 -> 64) + act_bwd + the <dotx, v> sum as ONE launch: y = lrelu'(a) v in the compute
-    dtype; x: [N][Hi][Wi][>=cin], a / y / dotx: [N][Hi/2][Wi/2][>=cout]."""
+    dtype; x: [N][Hi][Wi][>=cin], a / y / dotx: [N][Hi/2][Wi/2][>=cout].  dt: a split-precision code (fp32 tensors)."""
     N, Hi, Wi, _ = x.shape
-    call("gcssl_conv4x4s2_fwd_act_bwd", code(x), x, _ld(x), wf, gscale, group_n, a, _ld(a), y, _ld(y), dotx,
+    call("gcssl_conv4x4s2_fwd_act_bwd", code(x) if dt is None else dt, x, _ld(x), wf, gscale, group_n, a, _ld(a), y, _ld(y), dotx,
          _ld(dotx) if dotx is not None else 0, dot_out, sat, N, Hi, Wi, cin, cout)
 
 
@@ -272,10 +272,17 @@ def c5_wgrad(x, dw, C, dout=None, consts=(0.0, 0.0, 0.0), group_n=1):
 # ---- norm / activation
 def in_act_fwd(z, a, mean, rstd, C, act, mask=None, pool=None, nslab=1, slab_stride=0):
     """z: fp32 pre-norm tensor; a: activation output in the compute dtype.  nslab > 1: z is the first of nslab split-K
-    slabs slab_stride floats apart; they are summed on load and the total is written back to z."""
+    slabs slab_stride floats apart; they are summed on load and the total is written back to z.
+    a None (see in_act_fwd_pool_only_ok): only the statistics and the pool sums."""
     N, H, W, _ = z.shape
     assert z.dtype == torch.float32
-    call("gcssl_in_act_fwd", code(a), z, _ld(z), a, _ld(a), mean, rstd, mask, pool, nslab, int(slab_stride), N, H * W, C, act)
+    call("gcssl_in_act_fwd", code(a) if a is not None else _lib.F32, z, _ld(z), a, _ld(a) if a is not None else 0, mean, rstd, mask,
+         pool, nslab, int(slab_stride), N, H * W, C, act)
+
+
+def in_act_fwd_pool_only_ok(HW: int, C: int) -> bool:
+    """may in_act_fwd be called with a=None (statistics + pool sums, no activation store)?  gcssl_in_act_fwd's LDS-resident form."""
+    return 256 < HW <= 1024 and C % 32 == 0
 
 
 def in_act_bwd(z, mean, rstd, dzs, C, act, da=None, da2=None, da_bcast=None, mask=None, zt=None, zt_n0=0,
@@ -504,4 +511,4 @@ def mlp_head_bwd(gdelta, traw, h1, h2, feat, w1, w2, w3, delta_scale, train, dp1
 
 
 #: the wrappers that take the conv dtype keyword `dt` (StepEngine injects its split-precision code into these)
-CONV_FNS = (conv_fwd, conv_dgrad, conv_wgrad, conv3_fwd, conv3_wgrad, conv_in_act_x3_fwd)
+CONV_FNS = (conv_fwd, conv_dgrad, conv_wgrad, conv3_fwd, conv3_wgrad, conv_in_act_x3_fwd, conv_fwd_act_bwd)

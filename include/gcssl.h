@@ -200,7 +200,8 @@ int gcssl_conv4x4s1_c1_wgrad(int dtype, const void* x, int ldx, const float* dou
 int gcssl_in_act_fwd(int dtype, float* z, int ldz, void* a, int lda, float* mean, float* rstd, const uint8_t* mask,
                      float* pool, int nslab, long slab_stride, int N, int HW, int C, int act, void* stream);
 /* pool (nullable): [N][C] fp32, += sum over H*W of the activation output (AdaptiveAvgPool2d(1) of cgan/models.py:118,
- * fused; caller zeroes it and divides by H*W). */
+ * fused; caller zeroes it and divides by H*W).  a may be NULL when pool is given and 256 < HW <= 1024, C % 32 == 0, nslab == 1:
+ * only mean / rstd / pool are produced (GCSSL_ENULL for a NULL a elsewhere). */
 /* first-order backward: dn = act'(xhat) (da + da2 + da_bcast) [*2 keep]; dz = rstd (dn - mean dn - xhat mean(dn xhat))
  * (+ zt for samples n >= zt_n0: the double-backward term); dzs = dz * gscale[n/group_n];
  * dbias[c] += sum dz; cdot[n/group_n] += sum dzs (z - bias[c]) -- the coefficient <dW_sn, W_orig>/sigma^2 of the

@@ -167,7 +167,7 @@ def test_conv_wgrad(ops, dt, tol, N, Hi, Cin, CinP, Cout):
 # Against fp64 on UN-rounded fp32 operands: what is left is the dropped lo*lo term and the halves' own rounding -- fp16x3 keeps
 # 22 mantissa bits per operand (fp32-grade: the bound is the fp32 mode's), bf16x3 16 bits (2^-17 per operand, averaged over K).
 X3 = [("fp16x3", 2e-5), ("bf16x3", 6e-5)]
-X3_CASES = [c for c in CONV_CASES if c[0] <= 768 and c[1] <= 64] + [(768, 16, 64, 64, 128)]
+X3_CASES = [c for c in CONV_CASES if c[0] <= 768 and c[1] <= 64] + [(768, 16, 64, 64, 128), (2, 128, 6, 8, 64)]
 
 
 @pytest.mark.parametrize("mode,tol", X3)
@@ -301,6 +301,11 @@ def test_instance_norm_fwd_bwd_dbl(ops, dt, tol, N, H, C, act):
     assert rel_err(nchw(a2), aref) < tol
     assert rel_err(rstd.cpu(), r.view(N, C)) < 1e-5
     assert rel_err(pool.cpu(), q(aref, dt).sum(dim=(2, 3))) < max(tol, 1e-5)
+    if ops.in_act_fwd_pool_only_ok(H * H, C):                      # a=None: statistics + pool sums, no activation store
+        pool3, mean3, rstd3 = torch.zeros(N, C, device="cuda"), torch.empty(N, C, device="cuda"), torch.empty(N, C, device="cuda")
+        ops.in_act_fwd(zd, None, mean3, rstd3, C, act, mask=maskd, pool=pool3)
+        assert torch.equal(mean3, mean) and torch.equal(rstd3, rstd)
+        assert rel_err(pool3.cpu(), aref.sum(dim=(2, 3))) < 1e-5
     # backward (with dropout mask, group scale, bias/cdot bookkeeping)
     bias = rnd(C, seed=13, scale=0.1)
     gsc = torch.tensor([1.5, 0.5], device="cuda")
@@ -524,6 +529,37 @@ def test_conv_fwd_act_bwd_fused(ops, dt, tol, N, S):
     y2 = torch.empty_like(y)
     ops.conv_fwd_act_bwd(xd, wf, ad, y2, Cin, Cout, gscale=gs, group_n=N)
     assert torch.equal(y2.cpu(), y.cpu())
+
+
+@pytest.mark.parametrize("mode,tol", X3)
+@pytest.mark.parametrize("N,S", [(256, 32), (5, 64), (3, 128)])
+def test_conv_fwd_act_bwd_fused_split_precision(ops, mode, tol, N, S):
+    """The split-precision modes' first-layer kernel in its conv + activation-backward + dot form (all tensors fp32) against fp64."""
+    lib = load_pkg("_lib")
+    code, f32 = lib.mma_code(mode), torch.float32
+    Cin, Cout = 8, 64
+    assert ops.conv_fwd_act_bwd_ok(code, N, S, Cin, Cout)
+    x = rnd(N, Cin, S, S, seed=120)
+    w = rnd(Cout, Cin, 4, 4, seed=121, scale=0.1)
+    a = F.leaky_relu(rnd(N, Cout, S // 2, S // 2, seed=122), 0.2)
+    dx = rnd(N, Cout, S // 2, S // 2, seed=123)
+    wf = torch.empty(Cout, 16, Cin, device="cuda")
+    ops.prep_conv_weight(w.cuda(), wf, None, Cout, Cin, Cin, code)
+    xd, ad, dxd = nhwc(x, f32), nhwc(a, f32), nhwc(dx, f32)
+    gs = torch.tensor([0.75], device="cuda")
+    y = torch.full((N, S // 2, S // 2, Cout), float("nan"), device="cuda")
+    dot = torch.zeros(1, device="cuda")
+    ops.conv_fwd_act_bwd(xd, wf, ad, y, Cin, Cout, gscale=gs, group_n=N, dotx=dxd, dot_out=dot, dt=code)
+    torch.cuda.synchronize()
+    ref = 0.75 * F.conv2d(x.double(), w.double(), None, 2, 1)
+    assert rel_err(dot.cpu().double(), (dx.double() * ref).sum().view(1)) < 1e-4
+    assert rel_err(nchw(y), torch.where(a.double() > 0, ref, 0.2 * ref)) < tol
+    # == the unfused pair (same kernel without the epilogue, then act_bwd)
+    v = torch.empty(N, S // 2, S // 2, Cout, device="cuda")
+    ops.conv_fwd(xd, wf, v, Cin, Cout, gscale=gs, group_n=N, dt=code)
+    y_ref = torch.empty_like(v)
+    ops.act_bwd(v, ad, y_ref, Cout)
+    assert torch.equal(y.cpu(), y_ref.cpu())
 
 
 @pytest.mark.parametrize("dt,tol", DTS)
