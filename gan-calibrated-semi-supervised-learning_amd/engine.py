@@ -263,6 +263,8 @@ class StepEngine:
         self.side_g = _side_stream(dev, "gen") if self.overlap_g else None
         self.side_sn = _side_stream(dev, "sn") if self.overlap_g >= 2 else None
         self.probe = None          # {label: {"events": [(start, stop)...], "flops": f}} when profiling is enabled
+        self.step_log = self.delta_log = None                      # enable_step_log(): per-critic-step scalars / the generator step's delta, kept on the device
+        self._k_cur = 0
         self.probe_repeats = 0
 
     # ------------------------------------------------------------------------------------------ side-stream branches
@@ -291,6 +293,22 @@ class StepEngine:
             ev = torch.cuda.Event()
             ev.record(st)
             torch.cuda.current_stream().wait_event(ev)
+
+    # ------------------------------------------------------------------------------------------ device-side logging
+    def enable_step_log(self) -> None:
+        """Keep what the reference logs per step (cgan/cgan_train_enhanced.py:335-337,372-374) ON THE DEVICE, so that a loop of graph
+        replays needs no host sync per iteration: after an iteration ``step_log[k] = [mean D(real), mean D(fake), mean D(interp),
+        gradient penalty]`` of critic step k and ``delta_log`` = the generator step's predicted deltas (copied out before the
+        pipelined forward of the next iteration overwrites them).  One tiny launch per critic step + one per generator step,
+        part of whatever is captured after this call."""
+        if self.step_log is not None:
+            return
+        f32 = dict(device=self.dev, dtype=torch.float32)
+        self.step_log = torch.zeros(self.c, 4, **f32)
+        self.delta_log = torch.zeros(self.B, 4, **f32)
+        self._log_step = [ops.ReplicaSum([(self.means, self.step_log[k, 0:3], 3, False), (self.gp_sum, self.step_log[k, 3:4], 1, False)], 1, 0)
+                          for k in range(self.c)]
+        self._log_delta = ops.ReplicaSum([(self.g_delta, self.delta_log, 4 * self.B, False)], 1, 0)
 
     # ------------------------------------------------------------------------------------------ in-situ kernel timing
     def enable_probe(self, on: bool = True, repeats: int = 0):
@@ -774,6 +792,8 @@ class StepEngine:
     def generator_delta(self, pred: torch.Tensor, masks=None, train: bool = True) -> torch.Tensor:
         """GeneratorUNet.forward(pred) -> (B,4) delta."""
         self._prep_g()
+        self._gall_valid = False                      # (this forward overwrites group n_critic of a pending batched forward: a
+        #                                                pipelined GraphedIteration re-runs its prologue on the next replay)
         ops.pack_pair(pred, None, self.gt_x)          # gt_x doubles as the NHWC8 staging buffer outside a D step
         if train:
             self._set_masks(masks, 2)
@@ -848,6 +868,7 @@ class StepEngine:
         (cgan/losses.py:199) and the packed fake / interpolated groups."""
         B = self.B
         I = slice(2 * B, 3 * B)
+        self._k_cur = k                                            # (host-side: which critic step the next d_main belongs to)
         if self._gall_valid:                                       # this call was part of the iteration's batched forward
             if k == 0:                                             # (pred and gt are the iteration's: the real group is packed once)
                 ops.pack_pair(pred, gt, self.x0[:B])
@@ -968,6 +989,8 @@ class StepEngine:
         # dW_orig = sum_k G_k / sigma_k - sum_k c_k u_k v_k^T for the four spectrally-normalised layers, one launch -- which also
         # folds the striped sums (bias gradients -> flat gradient; c_k = its GP-chain part in `cdot` + the replicas)
         self._reduce_batches()[0].run()
+        if self.step_log is not None:
+            self._log_step[self._k_cur].run()                     # this step's group means + gradient penalty -> step_log[k]
 
     # ------------------------------------------------------------------------------------------ G step
     def g_step(self, pred, delta_true, pred_box, refine_fn, masks) -> None:
@@ -1025,6 +1048,8 @@ class StepEngine:
         ops.eiou_fwd_bwd(pred_box, self.g_delta, delta_true, self.lambda_iou * self.loss_scale_g, self.g_gdelta, self.g_cal,
                          self.eiou_acc)                                                # :351-355
         self.delta_pred = self.g_delta                  # (alias: valid until the next generator forward; iteration() clones it)
+        if self.delta_log is not None:
+            self._log_delta.run()
         self._refined_g = refine_fn(self.delta_pred, self.c)                           # :358-360
         # ---- backward of lambda_iou * EIoU through G (:365-366)
         if not self.G.grads_zero:

@@ -124,6 +124,44 @@ def test_gpu_batch_equals_host_getitem(tmp_path):
     assert img_idx.dtype == torch.int32 and int(img_idx.max()) < ds.atlas().n
 
 
+def _tiny_dataset(root, n_images=6):
+    from PIL import Image
+    (root / "images").mkdir(parents=True); (root / "labels_gt").mkdir(); (root / "labels_pred").mkdir()
+    rng = np.random.default_rng(0)
+    for i in range(n_images):
+        Image.fromarray(rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)).save(root / "images" / f"im{i}.jpg")
+        gt = [(0.3, 0.35, 0.3, 0.3), (0.7, 0.6, 0.25, 0.4)]
+        (root / "labels_gt" / f"im{i}.txt").write_text("".join(f"0 {a} {b} {c} {d}\n" for a, b, c, d in gt))
+        pr = [(a + 0.02 + 0.003 * i, b - 0.01, c * 1.1, d * 0.9) for a, b, c, d in gt]
+        (root / "labels_pred" / f"im{i}.txt").write_text("".join(f"0 {a} {b} {c} {d} 0.9\n" for a, b, c, d in pr))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", ["synthetic", "dataset"])
+def test_train_harness_graph_mode_logs_what_the_eager_loop_logs(tmp_path, source):
+    """train.py --graph (hipGraph replays, batches staged into static buffers, scalars kept on the device, one read-back per
+    epoch) against the eager loop on the same data with lr = 0 -- the weights never move, so every iteration's logged scalars
+    are comparable (alpha / dropout draws are keyed by the device-side step counts, the same in both): three epochs, the second
+    and third entered through a re-primed pipeline (the validation forward between epochs overwrites the pending one)."""
+    pytest.importorskip("PIL.Image")
+    sys.path.insert(0, str(ROOT))
+    import train
+    common = ["--img_size", "32", "--n_epochs", "3", "--n_critic", "2", "--compute_dtype", "fp32", "--lr", "0", "--patience", "10"]
+    if source == "dataset":
+        root = tmp_path / "data"
+        _tiny_dataset(root, 10)                                    # 20 pairs: 18 train / 2 val at val_split 0.1 -> 4 iterations of 4
+        common += ["--source", "dataset", "--data_dir", str(root), "--batch_size", "4"]
+    else:
+        common += ["--batch_size", "8", "--iters_per_epoch", "5"]
+    he = train.main(common + ["--save_dir", str(tmp_path / "eager")])
+    hg = train.main(common + ["--save_dir", str(tmp_path / "graph"), "--graph"])
+    assert len(he) == len(hg) == 3
+    for e, g in zip(he, hg):
+        for k in ("loss_D", "loss_gp", "wasserstein_distance", "loss_G", "loss_iou", "loss_wgan", "delta_iou"):
+            assert np.isfinite(g[k])
+            assert abs(e[k] - g[k]) <= 2e-4 * max(1.0, abs(e[k])), (k, e[k], g[k])
+
+
 @pytest.mark.gpu
 def test_train_harness_on_a_dataset_directory(tmp_path):
     """train.py --source dataset: YOLO txt + jpg -> HBM atlas -> GPU patches -> engine iterations with the GPU re-crop

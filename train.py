@@ -5,7 +5,8 @@ and the same checkpoint dict keys {'generator','discriminator','epoch','delta_io
 step engine.  Data: `--source synthetic` (default; the tensor contract of SURVEY §8a row I, no files needed) or
 `--source dataset`: CalibratorDataset over --data_dir (YOLO txt + jpg) with the images decoded once into
 an HBM atlas, the pred/gt patches and the per-step re-crop cut on the GPU.  Any iterable yielding
-(pred_patch, gt_patch, delta_true, pred_box, refine_fn) can feed the loop.
+(pred_patch, gt_patch, delta_true, pred_box, refine_fn, extra) can feed the loop (extra: what `--graph` stages into the
+re-crop stage's static buffers -- GraphLoop).
 """
 from __future__ import annotations
 
@@ -49,7 +50,11 @@ def build_parser(config: dict) -> argparse.ArgumentParser:
     p.add_argument("--lambda_gp", type=float, default=config.get("lambda_gp", 10.0))
     p.add_argument("--n_critic", type=int, default=config.get("n_critic", 5))
     # MI355X-specific
-    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp16", "fp32", "fp16x3", "bf16x3"],
+                   help="MFMA operand type; fp16x3 / bf16x3: fp32 tensors, split-precision contraction (fp32-grade results)")
+    p.add_argument("--graph", action="store_true",
+                   help="replay the iteration as captured hipGraphs (engine.GraphedIteration): batches are staged into static "
+                        "buffers, the logged scalars stay on the device and are read back once per epoch")
     p.add_argument("--iters_per_epoch", type=int, default=20, help="synthetic source: iterations per epoch")
     p.add_argument("--source", default="synthetic", choices=["synthetic", "dataset"])
     return p
@@ -92,7 +97,7 @@ def synthetic_source(synth, seed, batch, size, n_critic, device, iters):
         inp = synth.step_inputs(seed + it, batch, size, n_critic, tag="train")
         refined = [T(r).to(device) for r in inp["refined"]]
         yield (T(inp["pred"]).to(device), T(inp["gt"]).to(device), T(inp["delta_true"]).to(device),
-               T(inp["pred_box"]).to(device), lambda delta, k, r=refined: r[k])
+               T(inp["pred_box"]).to(device), lambda delta, k, r=refined: r[k], dict(refined=refined))
 
 
 def dataset_source(ds, refine_mod, indices, batch, size, device, seed):
@@ -105,7 +110,98 @@ def dataset_source(ds, refine_mod, indices, batch, size, device, seed):
         pred_patch, gt_patch, delta_true, pred_box, img_idx = ds.gpu_batch(order[b0:b0 + batch], device)
         refine = lambda delta, k, ii=img_idx, pb=pred_box, fp=pred_patch: refine_mod.get_refined_patch_batch(
             atlas, ii, pb, delta, size, fallback_patches=fp)
-        yield pred_patch, gt_patch, delta_true, pred_box, refine
+        yield pred_patch, gt_patch, delta_true, pred_box, refine, dict(img_idx=img_idx, atlas=atlas)
+
+
+class GraphLoop:
+    """The training loop's inner step as hipGraph replays (``--graph``).  The first batch it sees sizes the static buffers and is
+    what the graphs are captured on; every later batch is copied into them (GraphedIteration.replay(batch=..., next_pred=...):
+    the pipelined generator forward needs the NEXT batch's pred one replay early, so the loop looks one batch ahead).  The
+    re-crop stage is refine.RefineStage on static buffers (dataset source) or the batch's precomputed patches (synthetic
+    source).  Nothing is read back per iteration: one small launch appends the iteration's scalars -- per critic step the three
+    group means and the gradient penalty (StepEngine.step_log), the generator's EIoU sum and WGAN mean, its predicted deltas
+    and the batch's boxes -- to a device-side history that `drain()` turns into the reference's epoch sums
+    (cgan/cgan_train_enhanced.py:335-337,372-374,395-420)."""
+
+    ROWS = 64
+
+    def __init__(self, eng, engine_mod, refine_mod, losses, ops, first, size: int, lambda_gp: float, lambda_iou: float):
+        pred, gt, delta_true, pred_box, _, extra = first
+        self.eng, self.losses, self.ops = eng, losses, ops
+        self.lambda_gp, self.lambda_iou = lambda_gp, lambda_iou
+        eng.enable_step_log()
+        self.inp = tuple(t.detach().float().contiguous().clone() for t in (pred, gt, delta_true, pred_box))
+        self.refined = self.stage = None
+        if "refined" in extra:
+            self.refined = [r.clone() for r in extra["refined"]]
+            refine = lambda delta, k: self.refined[k]
+        else:
+            self.stage = refine_mod.RefineStage(extra["atlas"], extra["img_idx"].clone(), self.inp[3], size, eng.c + 1,
+                                                fallback=self.inp[0])
+            assert self.stage.pred_box.data_ptr() == self.inp[3].data_ptr()         # (staged with the batch: the same buffer)
+            refine = self.stage
+        self.gi = engine_mod.GraphedIteration(eng, *self.inp, refine)
+        B, c = eng.B, eng.c
+        self.width = 4 * c + 2 + 12 * B
+        self.hist = torch.zeros(self.ROWS, self.width, device=pred.device)
+        self._rows = [None] * self.ROWS
+        self.n = 0
+        self.sums = None
+
+    def _append(self):
+        j = self.n % self.ROWS
+        if self._rows[j] is None:
+            eng, B, c, h = self.eng, self.eng.B, self.eng.c, self.hist[j]
+            o = 4 * c + 2
+            self._rows[j] = self.ops.ReplicaSum(
+                [(eng.step_log, h[0:4 * c], 4 * c, False), (eng.eiou_acc, h[4 * c:4 * c + 1], 1, False),
+                 (eng.wgan_mean, h[4 * c + 1:o], 1, False), (eng.delta_log, h[o:o + 4 * B], 4 * B, False),
+                 (self.inp[3], h[o + 4 * B:o + 8 * B], 4 * B, False), (self.inp[2], h[o + 8 * B:o + 12 * B], 4 * B, False)], 1, 0)
+        self._rows[j].run()
+        self.n += 1
+        if self.n % self.ROWS == 0:
+            self._fold(self.ROWS)
+
+    def step(self, batch, nxt):
+        """one iteration on `batch`; nxt: the batch after it (or None)"""
+        extra = batch[5]
+        if self.refined is not None:
+            for dst, src in zip(self.refined, extra["refined"]):
+                dst.copy_(src, non_blocking=True)
+        else:
+            self.stage.img_idx.copy_(extra["img_idx"].to(torch.int32), non_blocking=True)
+        self.gi.replay(batch=batch[:4], next_pred=None if nxt is None else nxt[0])
+        self._append()
+
+    def _fold(self, rows: int):
+        """history rows -> running sums of the epoch (one host sync)"""
+        if rows == 0:
+            return
+        eng, L = self.eng, self.losses
+        B, c = eng.B, eng.c
+        h = self.hist[:rows]
+        sl = h[:, :4 * c].view(rows, c, 4).double()
+        wd = sl[:, :, 0] - sl[:, :, 1]
+        gp = sl[:, :, 3]
+        loss_iou = 1.0 + h[:, 4 * c].double()
+        loss_wgan = -h[:, 4 * c + 1].double()
+        o = 4 * c + 2
+        delta, pb, dt = (h[:, o + 4 * B * i:o + 4 * B * (i + 1)].reshape(rows * B, 4) for i in range(3))
+        gtb = L.apply_delta_to_bbox(pb, dt, training=False)
+        cal = L.apply_delta_to_bbox(pb, delta, training=False)
+        iou_b = L.iou_metric(pb, gtb).view(rows, B).double().mean(1).sum()
+        iou_a = L.iou_metric(cal, gtb).view(rows, B).double().mean(1).sum()
+        vals = torch.stack([(-wd + self.lambda_gp * gp).mean(1).sum(), gp.mean(1).sum(), wd.mean(1).sum(),
+                            (self.lambda_iou * loss_iou + loss_wgan).sum(), loss_iou.sum(), loss_wgan.sum(), iou_b, iou_a]).tolist()
+        self.sums = vals if self.sums is None else [a + b for a, b in zip(self.sums, vals)]
+
+    def drain(self):
+        """-> (dict of the epoch's sums, iterations) and reset"""
+        self._fold(self.n % self.ROWS)
+        keys = ("loss_D", "loss_gp", "wasserstein_distance", "loss_G", "loss_iou", "loss_wgan", "iou_before", "iou_after")
+        out = dict(zip(keys, self.sums if self.sums is not None else [0.0] * len(keys)))
+        n, self.n, self.sums = self.n, 0, None
+        return out, n
 
 
 def main(argv=None):
@@ -162,6 +258,7 @@ def main(argv=None):
     out_root = Path(args.save_dir); out_root.mkdir(parents=True, exist_ok=True)
     ckpt_best = out_root / "G_best.pth"
     best, history, epochs_no_improve = -1.0, [], 0
+    loop = None                                                      # --graph: the captured iteration + its static buffers (built on the first batch)
     for epoch in range(1, args.n_epochs + 1):
         stats = dict(loss_G=0.0, loss_D=0.0, loss_iou=0.0, loss_wgan=0.0, loss_gp=0.0, wasserstein_distance=0.0)
         n = 0
@@ -171,7 +268,16 @@ def main(argv=None):
         else:
             source = synthetic_source(synth, args.seed + 1000 * epoch + rank, args.batch_size // world, args.img_size,
                                       args.n_critic, device, args.iters_per_epoch)
-        for pred, gt, delta_true, pred_box, refine in source:
+        if args.graph:
+            # the first iteration of the run is eager (it also finishes the library's lazy set-up, which must not happen inside a
+            # capture); from the second on, graph replays with a one-batch look-ahead
+            it = iter(source)
+            cur = next(it, None)
+            if cur is not None and loop is None:
+                source = [cur]                                     # (the eager loop below takes this one batch)
+            else:
+                source = []
+        for pred, gt, delta_true, pred_box, refine, _extra in source:
             log = eng.iteration(pred, gt, delta_true, pred_box, refine)
             stats["loss_D"] += sum(log["d_loss"]) / args.n_critic
             stats["loss_gp"] += sum(log["gp"]) / args.n_critic
@@ -182,6 +288,20 @@ def main(argv=None):
             gtb = losses.apply_delta_to_bbox(pred_box, delta_true, training=False)
             cal = losses.apply_delta_to_bbox(pred_box, log["delta_pred"], training=False)
             iou_b += float(losses.iou_metric(pred_box, gtb).mean()); iou_a += float(losses.iou_metric(cal, gtb).mean())
+        if args.graph:
+            if loop is None and cur is not None:
+                loop = GraphLoop(eng, engine, importlib.import_module(PKG + ".refine"), losses, importlib.import_module(PKG + ".ops"),
+                                 cur, args.img_size, args.lambda_gp, args.lambda_iou)
+                cur = next(it, None)                               # (the first batch went through the eager iteration above)
+            while cur is not None:
+                nxt = next(it, None)
+                loop.step(cur, nxt)
+                cur = nxt
+            if loop is not None:
+                sums, ng = loop.drain()
+                for k in stats:
+                    stats[k] += sums[k]
+                iou_b += sums["iou_before"]; iou_a += sums["iou_after"]; n += ng
         for k in stats:
             stats[k] /= max(n, 1)
         delta_iou = (iou_a - iou_b) / max(n, 1)
