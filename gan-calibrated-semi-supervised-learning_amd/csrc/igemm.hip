@@ -757,6 +757,75 @@ __global__ __launch_bounds__(WM * WN * 64, MM ? (WM * WN >= 8 ? 4 : 2) : 1) void
             }
     }
     float* y32 = static_cast<float*>(p.y);
+    if constexpr (MM != 0) {
+        if (p.ab_a) {
+            // split-precision modes, the data gradient into a NORM-LESS layer: that layer's LeakyReLU backward in this epilogue
+            // (gcssl_conv4x4s2_dgrad_act_bwd on fp32 tensors; norm.hip act_bwd_kernel's arithmetic): d = the conv result,
+            // dz = lrelu'(a) d, y = dz * gscale[group];  dbias[ci] += sum dz,  cdot[group] += sum y (z - bias[ci]), z = lrelu^-1(a).
+            // A tile's rows belong to one group (host check); no K split (the epilogue is not linear).
+            const float* ab = static_cast<const float*>(p.ab_a);
+            const int mg = min(m0, p.M - 1);
+            const int grp = (int)(((float)(mg >> p.lgHoWo) + 0.5f) * p.inv_group_n);
+            const float gsv = p.gscale ? p.gscale[grp] : 1.f;
+            float bj[TN], sbj[TN], sd = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ci = n0 + wn0 + 32 * j + (lane & 31);
+                bj[j] = (p.ab_bias && ci < p.Cin) ? p.ab_bias[ci] : 0.f;
+                sbj[j] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm0 + 32 * i + crow(r, lane);
+                    if (m >= p.M) continue;
+                    const int n = m >> p.lgHoWo, rem = m & ((1 << p.lgHoWo) - 1);
+                    const int iy = 2 * (rem >> p.lgWo) + py, ix = 2 * (rem & (Wo - 1)) + px;
+                    const size_t pix = (size_t)(n * p.Hi + iy) * p.Wi + ix;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int ci = n0 + wn0 + 32 * j + (lane & 31);
+                        if (ci >= p.Cin) continue;
+                        const float d = acc[i][j][r] * osc;
+                        const float av = ab[pix * p.ab_lda + ci];
+                        const float dz = av > 0.f ? d : 0.2f * d;
+                        const float zv = av > 0.f ? av : av * 5.0f;
+                        const float o = dz * gsv;
+                        sbj[j] += dz; sd += o * (zv - bj[j]);
+                        y32[pix * p.ldy + ci] = o;
+                    }
+                }
+            if (p.ab_dbias || p.ab_cdot) {
+                float* red = reinterpret_cast<float*>(&As[0]);                     // [wave][TN * 32 + 1]
+                constexpr int RW = TN * 32 + 1;
+                __syncthreads();                                                   // (every wave is done with the operand tiles)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float t = sbj[j] + __shfl_xor(sbj[j], 32, 64);
+                    if (lane < 32) red[wave * RW + j * 32 + lane] = t;
+                }
+                const float ts = wave_sum(sd);
+                if (lane == 0) red[wave * RW + TN * 32] = ts;
+                __syncthreads();
+                const int rep = p.ab_nrep > 1 ? (int)(blockIdx.x % (unsigned)p.ab_nrep) * p.ab_rep_stride : 0;
+                if (p.ab_dbias && tid < BN) {                                      // column tid of the tile
+                    const int wc = tid / (BN / WN), cj = tid % (BN / WN);
+                    float t = 0.f;
+#pragma unroll
+                    for (int wr = 0; wr < WM; ++wr) t += red[(wr * WN + wc) * RW + cj];
+                    if (n0 + tid < p.Cin) atomicAdd(p.ab_dbias + rep + n0 + tid, t);
+                }
+                if (p.ab_cdot && tid == 0) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM * WN; ++w) t += red[w * RW + TN * 32];
+                    if (t != 0.f) atomicAdd(p.ab_cdot + rep + grp, t);
+                }
+            }
+            return;
+        }
+    }
     float* yk = y32 + (p.ksplit > 1 ? (size_t)ks * p.split_stride : 0);
     const bool f32o = p.out_f32 || std::is_same<T, float>::value;
 #pragma unroll
@@ -3253,7 +3322,7 @@ int dispatch_dgrad(ConvParams p, hipStream_t st) {
         if (p.Cin >= 64) {
             const int nk = 4 * p.Cout / 32;
             int ks = 1;
-            const int tile = x3_plan(p.M, p.Cin, nk, 4, true, &ks);
+            const int tile = x3_plan(p.M, p.Cin, nk, 4, !p.ab_a, &ks);              // (the activation-backward epilogue is not linear)
             p.ksplit = ks;
             if (ks > 1) {
                 p.ktiles_per_split = (nk + ks - 1) / ks;
@@ -3811,12 +3880,19 @@ int gcssl_conv4x4s2_dgrad(int dtype, const void* dy, int lddy, const void* wt, c
     return GCSSL_EBADDTYPE;
 }
 
+// the split-precision modes' form of gcssl_conv4x4s2_dgrad_act_bwd: conv_dgrad_kernel's own epilogue, any shape its 64-channel-wide
+// tiles serve without a K split (GCSSL_X3_ACTB=0: off, A/B)
+static bool actb_x3_shape(int N, int Hi, int Wi, int Cin, int Cout) {
+    static const bool on = [] { const char* e = getenv("GCSSL_X3_ACTB"); return !(e && e[0] == '0'); }();
+    return on && Cin >= 64 && Cout >= 64 && (long)N * (Hi / 2) * (Wi / 2) >= 128;
+}
 // 1 if gcssl_conv4x4s2_dgrad_act_bwd serves these shapes (with_sums: dbias / cdot requested), else 0
 int gcssl_conv4x4s2_dgrad_act_bwd_ok(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int with_sums) {
     int rc = check_geom(N, Hi, Wi, Cin, Cout);
     if (rc) return rc;
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (dtype == GCSSL_F32) return 0;
+    if (gcssl_f32_storage(dtype)) return actb_x3_shape(N, Hi, Wi, Cin, Cout) ? 1 : 0;       // split-precision modes (fp32 tensors)
     ConvParams p{}; p.y_bytes = 1;
     fill_geom(p, N, Hi, Wi, Cin, Cout);
     return actb_form(p, with_sums != 0) ? 1 : 0;
@@ -3828,12 +3904,25 @@ int gcssl_conv4x4s2_dgrad_act_bwd(int dtype, const void* dy, int lddy, const voi
     if (!dy || !wt || !a || !dzs) return GCSSL_ENULL;
     int rc = check_geom(N, Hi, Wi, Cin, Cout);
     if (rc) return rc;
-    if (gcssl_bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
     if (dtype == GCSSL_F32) return GCSSL_EBADDTYPE;
+    const bool x3 = gcssl_f32_storage(dtype);                            // split-precision modes: every tensor here is fp32
     if (lddy < Cout || lda < Cin || lddz < Cin || ((gscale || cdot) && group_n <= 0)) return GCSSL_EBADSHAPE;
     if (nrep < 1 || (nrep > 1 && rep_stride < Cin)) return GCSSL_EBADSHAPE;
     if ((gscale || cdot) && (group_n * (Hi / 2) * (Wi / 2)) % 128) return GCSSL_EBADSHAPE;      // a 128-row tile must not straddle groups
-    if (lddy % 8 || lda % 8 || lddz % 8 || !aligned16(dy) || !aligned16(wt) || !aligned16(a) || !aligned16(dzs)) return GCSSL_EALIGN;
+    const int kv = x3 ? 4 : 8;
+    if (lddy % kv || lda % kv || lddz % kv || !aligned16(dy) || !aligned16(wt) || !aligned16(a) || !aligned16(dzs)) return GCSSL_EALIGN;
+    if (x3) {
+        if (!actb_x3_shape(N, Hi, Wi, Cin, Cout)) return GCSSL_EBADSHAPE;
+        ConvParams q{}; q.x = dy; q.w = wt; q.y = dzs; q.gscale = gscale; q.group_n = group_n; q.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
+        q.ldx = lddy; q.ldy = lddz;
+        q.ab_a = a; q.ab_lda = lda; q.ab_bias = bias; q.ab_dbias = dbias; q.ab_cdot = cdot; q.ab_nrep = nrep; q.ab_rep_stride = rep_stride;
+        fill_geom(q, N, Hi, Wi, Cin, Cout);
+        if (!fill_bytes(q, (size_t)N * (Hi / 2) * (Wi / 2) * lddy, (size_t)Cin * 16 * Cout, 4)) return GCSSL_EBADSHAPE;
+        q.y_bytes = 1;
+        GCSSL_DISPATCH_CONV(dtype, return (dispatch_dgrad<T, MM>(q, (hipStream_t)stream)));
+        return GCSSL_EBADDTYPE;
+    }
     ConvParams p{}; p.x = dy; p.w = wt; p.y = dzs; p.gscale = gscale; p.group_n = group_n; p.inv_group_n = group_n > 0 ? 1.0f / (float)group_n : 0.f;
     p.ldx = lddy; p.ldy = lddz;
     p.ab_a = a; p.ab_lda = lda; p.ab_bias = bias; p.ab_dbias = dbias; p.ab_cdot = cdot; p.ab_nrep = nrep; p.ab_rep_stride = rep_stride;

@@ -417,7 +417,7 @@ class StepEngine:
         """does the one-launch dgrad + activation-backward form serve a data gradient of these shapes?"""
         key = ("actb", n, hi, cin, cout, with_sums)
         if key not in self._fin_cache:
-            self._fin_cache[key] = self.code != _lib.F32 and ops.conv_dgrad_act_bwd_ok(self.code, n, hi, cin, cout, with_sums)
+            self._fin_cache[key] = self.mma != _lib.F32 and ops.conv_dgrad_act_bwd_ok(self.mma, n, hi, cin, cout, with_sums)     # (16-bit and split modes)
         return self._fin_cache[key]
 
     def _fwd_actb(self, n: int, hi: int, cin: int, cout: int) -> bool:

@@ -140,11 +140,11 @@ def conv_dgrad_act_bwd_ok(dt, N, Hi, cin, cout, with_sums) -> bool:
 
 
 def conv_dgrad_act_bwd(dy, wt, a, dzs, cin, cout, gscale=None, group_n=0, bias=None, dbias=None, cdot=None, nrep=1, rep_stride=0,
-                       sat=None):
+                       sat=None, dt=None):
     """conv_dgrad (fp32 dx) + act_bwd of the norm-less layer in front of the conv as ONE launch: dzs = lrelu'(a) dx gscale in the
-    compute dtype; dzs / a: [N][Hi][Wi][>=cin], dy: [N][Hi/2][Wi/2][>=cout]."""
+    compute dtype; dzs / a: [N][Hi][Wi][>=cin], dy: [N][Hi/2][Wi/2][>=cout].  dt: a split-precision code (fp32 tensors)."""
     N, Hi, Wi, _ = dzs.shape
-    call("gcssl_conv4x4s2_dgrad_act_bwd", code(dy), dy, _ld(dy), wt, a, _ld(a), gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot,
+    call("gcssl_conv4x4s2_dgrad_act_bwd", code(dy) if dt is None else dt, dy, _ld(dy), wt, a, _ld(a), gscale, group_n, bias, dzs, _ld(dzs), dbias, cdot,
          nrep, rep_stride, sat, N, Hi, Wi, cin, cout)
 
 
@@ -511,4 +511,4 @@ def mlp_head_bwd(gdelta, traw, h1, h2, feat, w1, w2, w3, delta_scale, train, dp1
 
 
 #: the wrappers that take the conv dtype keyword `dt` (StepEngine injects its split-precision code into these)
-CONV_FNS = (conv_fwd, conv_dgrad, conv_wgrad, conv3_fwd, conv3_wgrad, conv_in_act_x3_fwd, conv_fwd_act_bwd)
+CONV_FNS = (conv_fwd, conv_dgrad, conv_wgrad, conv3_fwd, conv3_wgrad, conv_in_act_x3_fwd, conv_fwd_act_bwd, conv_dgrad_act_bwd)

@@ -490,6 +490,51 @@ def test_conv_dgrad_act_bwd_fused(ops, dt, tol, N, with_sums):
         assert rel_err(sc, sc_ref) < 1e-4
 
 
+@pytest.mark.parametrize("mode,tol", X3)
+@pytest.mark.parametrize("N,with_sums", [(768, True), (256, False), (770, False), (24, True)])      # 770: ragged last tile, no groups
+def test_conv_dgrad_act_bwd_fused_split_precision(ops, mode, tol, N, with_sums):
+    """The split-precision modes' data gradient with the norm-less layer's LeakyReLU backward (+ bias-gradient and spectral-norm
+    sums) in its epilogue, all tensors fp32: against the fp64 definition and against the unfused pair."""
+    lib = load_pkg("_lib")
+    code, f32 = lib.mma_code(mode), torch.float32
+    Hi, Cin, Cout = 16, 64, 128
+    grouped = N % 3 == 0
+    group_n = N // 3 if grouped else 0
+    assert ops.conv_dgrad_act_bwd_ok(code, N, Hi, Cin, Cout, with_sums)
+    dy = rnd(N, Cout, Hi // 2, Hi // 2, seed=110)
+    w = rnd(Cout, Cin, 4, 4, seed=111, scale=0.05)
+    a = F.leaky_relu(rnd(N, Cin, Hi, Hi, seed=112), 0.2)
+    bias = rnd(Cin, seed=113, scale=0.1)
+    wt = torch.empty(Cin, 16, Cout, device="cuda")
+    ops.prep_conv_weight(w.cuda(), None, wt, Cout, Cin, Cin, code)
+    dyd, ad = nhwc(dy, f32), nhwc(a, f32)
+    gs = torch.tensor([1.5, 0.5, 2.0], device="cuda") if grouped else None
+    nrep, stride = 4, 128
+    dz = torch.full((N, Hi, Hi, Cin), float("nan"), device="cuda")
+    db = torch.zeros(nrep, stride, device="cuda"); cd = torch.zeros(nrep, stride, device="cuda")
+    kw = dict(gscale=gs, group_n=group_n)
+    if with_sums:
+        kw.update(bias=bias.cuda(), dbias=db[0, :Cin], cdot=cd[0, 64:67], nrep=nrep, rep_stride=stride)
+    ops.conv_dgrad_act_bwd(dyd, wt, ad, dz, Cin, Cout, dt=code, **kw)
+    torch.cuda.synchronize()
+    d = F.conv_transpose2d(dy.double(), w.double(), None, 2, 1)
+    dzr = torch.where(a.double() > 0, d, 0.2 * d)
+    grp = torch.arange(N) // group_n if grouped else None
+    ref = dzr * gs.cpu().double()[grp].view(-1, 1, 1, 1) if grouped else dzr
+    assert rel_err(nchw(dz), ref) < tol
+    if with_sums:
+        assert rel_err(db.sum(0)[:Cin].cpu(), dzr.sum(dim=(0, 2, 3))) < 1e-4
+        z = torch.where(a.double() > 0, a.double(), 5.0 * a.double())
+        cdr = torch.stack([(ref[grp == g] * (z[grp == g] - bias.double().view(1, -1, 1, 1))).sum() for g in range(3)])
+        assert rel_err(cd.sum(0)[64:67].cpu(), cdr) < 1e-4
+    # == the unfused pair (same conv kernel, then act_bwd)
+    dx = torch.empty(N, Hi, Hi, Cin, device="cuda")
+    ops.conv_dgrad(dyd, wt, dx, Cin, Cout, dt=code)
+    dz2 = torch.empty_like(dx)
+    ops.act_bwd(dx, ad, dz2, Cin, gscale=gs, group_n=group_n)
+    assert rel_err(dz.cpu(), dz2.cpu()) < 1e-6
+
+
 @pytest.mark.parametrize("dt,tol", DTS[1:])
 @pytest.mark.parametrize("N,S", [(256, 32), (5, 64), (3, 128)])
 def test_conv_fwd_act_bwd_fused(ops, dt, tol, N, S):
