@@ -1335,14 +1335,36 @@ class GraphedIteration:
                     self.g_a = capture(lambda: eng.g_main(pred, delta_true, pred_box, refine_fn, None))
                     pool_g, pool = pool, pool_main
 
-                    def seg_a():
+                    # GCSSL_HEAD_SPLIT=1 (A/B knob, default OFF): the first and the last critic step's spectral-norm chain + weight
+                    # re-pack -- eight 7-us launches, each depending on the one before -- as graphs of their own (c_a0, c_b0), with
+                    # the generator's segments started BEHIND them (g_a after c_a0, g_b after c_b0).  The idea: started together,
+                    # the generator's chain of one-workgroup-per-CU launches gets the CUs first at every launch boundary and the
+                    # critic's tiny launches wait for them (92 / 129 us for a chain that takes 39 us alone, plus a 220-us idle
+                    # head: tools/graph_gaps.sh), while the generator's chain has ~0.5 ms of slack.  MEASURED (same box): bf16
+                    # 135.06k vs 135.05-135.59k without, fp16x3 66.6k vs 68.2k -- what the critic's heads gain, the co-residency
+                    # of the big launches that now coincide loses.  The chip's throughput is shared, not idle.
+                    self.head_split = os.environ.get("GCSSL_HEAD_SPLIT", "0") != "0"
+
+                    def seg_a(sn_done=False):
                         eng._d_dirty = True
                         for k in range(c):
-                            eng.d_pre(pred, gt, refine_fn, k, None, None)
+                            if not (sn_done and k == 0):
+                                eng.d_pre(pred, gt, refine_fn, k, None, None)
                             if k < c - 1:
-                                eng.d_main(); eng.d_update()
-                    self.c_a = capture(seg_a)
-                    self.c_b = capture(lambda: (eng.d_main(), eng.d_update(), eng.g_critic(pred)))
+                                eng.d_main(sn_done=sn_done and k == 0); eng.d_update()
+                    if self.head_split and c >= 2:
+                        def head_a():
+                            eng._d_dirty = True
+                            eng.d_pre(pred, gt, refine_fn, 0, None, None)
+                            eng._sn_and_prep()
+                        self.c_a0 = capture(head_a)
+                        self.c_a = capture(lambda: seg_a(True))
+                        self.c_b0 = capture(lambda: (setattr(eng, "_d_dirty", True), eng._sn_and_prep()))
+                        self.c_b = capture(lambda: (eng.d_main(sn_done=True), eng.d_update(), eng.g_critic(pred)))
+                    else:
+                        self.head_split = False
+                        self.c_a = capture(seg_a)
+                        self.c_b = capture(lambda: (eng.d_main(), eng.d_update(), eng.g_critic(pred)))
                     pool = pool_g
                     self.g_b = capture(lambda: (eng.g_update(), eng.g_forward_all(self.pred_next, None)))
                 finally:
@@ -1487,12 +1509,16 @@ class GraphedIteration:
                 self.prologue.replay()                            # this iteration's batched generator forward (first replay / re-prime)
                 self._primed = True
             eng._gall_valid = True                                # (host flag: every replay leaves the next iteration's forward pending)
+            if self.head_split:
+                self.c_a0.replay()                                # d_pre(0) + the first critic step's spectral-norm chain and re-pack
             ev0 = torch.cuda.Event(); ev0.record(main)            # (Gb(i-1) and Cb(i-1) are ordered in front of this: see the tail)
             side.wait_event(ev0)
             with torch.cuda.stream(side):
                 self.g_a.replay()
                 ev_ga = torch.cuda.Event(); ev_ga.record(side)
             self.c_a.replay()
+            if self.head_split:
+                self.c_b0.replay()                                # the last critic step's chain (Gb starts behind it)
             ev_ca = torch.cuda.Event(); ev_ca.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ev_ca)

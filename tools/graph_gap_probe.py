@@ -37,10 +37,19 @@ if mode in ("critic_fused", "critic_steps"):
 for _ in range(20): gi.replay()
 torch.cuda.synchronize()
 main, side = torch.cuda.current_stream(), gi.side
+hs = getattr(gi, "head_split", False)
+
+
+def ca():                                                       # the critic's first segment (with its head graph, if split off)
+    if hs: gi.c_a0.replay()
+    gi.c_a.replay()
+    if hs: gi.c_b0.replay()
+
+
 t0 = time.perf_counter()
 for _ in range(iters):
     if mode == "critic_only":
-        gi.c_a.replay(); gi.c_b.replay()
+        ca(); gi.c_b.replay()
     elif mode in ("critic_fused", "critic_steps"):
         for g in extra: g.replay()
     elif mode == "gen_only":                       # the generator's chain alone (results are garbage after the first: timing only)
@@ -50,10 +59,10 @@ for _ in range(iters):
     elif mode == "no_events":                      # both chains free-running (results are garbage: timing only)
         with torch.cuda.stream(side):
             gi.g_a.replay(); gi.g_b.replay()
-        gi.c_a.replay(); gi.c_b.replay()
+        ca(); gi.c_b.replay()
     elif mode == "critic_first":
         ev0 = torch.cuda.Event(); ev0.record(main)
-        gi.c_a.replay()
+        ca()
         ev_ca = torch.cuda.Event(); ev_ca.record(main)
         side.wait_event(ev0)
         with torch.cuda.stream(side):

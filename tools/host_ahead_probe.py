@@ -14,7 +14,7 @@ order = sys.argv[2] if len(sys.argv) > 2 else "ga_first"
 dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
 run = bench.Runner(engine, synth, dist_mod, dev, 0, 1, 256, 32, 2, "bf16", "unet", 3)
 gi = run.graphed
-assert gi.two_stream
+assert gi.two_stream and not gi.head_split, "this probe replays the four-graph form by hand (GCSSL_HEAD_SPLIT must be off)"
 for _ in range(30): gi.replay()
 torch.cuda.synchronize()
 main, side = torch.cuda.current_stream(), gi.side
