@@ -627,8 +627,11 @@ __global__ __launch_bounds__(WM * WN * 64, MM ? (WM * WN >= 8 ? 4 : 2) : 1) void
 // One launch z-slice per output parity class (py,px); per class M = N*Ho*Wo, N = Cin, K = 4*Cout.
 //   ky = 1-py+2ty, oy = iy' + py - ty   (iy = 2 iy' + py), same in x.
 // ------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int MM = 0, int WM = 2, int WN = 2>
-__global__ __launch_bounds__(WM * WN * 64, MM ? (WM * WN >= 8 ? 4 : 2) : 1) void conv_dgrad_kernel(ConvParams p) {
+// ACTB (split-precision modes only): the activation-backward epilogue of gcssl_conv4x4s2_dgrad_act_bwd.  A template parameter and
+// not a run-time branch: with the branch in it the plain instantiation went from 168 to 176 registers -- from three waves per SIMD
+// to two -- and EVERY data gradient of the split modes from 72 to 91 us.
+template <typename T, int BM, int BN, int MM = 0, int WM = 2, int WN = 2, bool ACTB = false>
+__global__ __launch_bounds__(WM * WN * 64, MM ? (WM * WN >= 8 ? 4 : (ACTB ? 3 : 2)) : 1) void conv_dgrad_kernel(ConvParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BK = BKOf<T>::v;
     constexpr int KV = Elem<T>::KV, CH = BK / KV, RPT = NT / CH;
@@ -757,8 +760,8 @@ __global__ __launch_bounds__(WM * WN * 64, MM ? (WM * WN >= 8 ? 4 : 2) : 1) void
             }
     }
     float* y32 = static_cast<float*>(p.y);
-    if constexpr (MM != 0) {
-        if (p.ab_a) {
+    if constexpr (MM != 0 && ACTB) {
+        {
             // split-precision modes, the data gradient into a NORM-LESS layer: that layer's LeakyReLU backward in this epilogue
             // (gcssl_conv4x4s2_dgrad_act_bwd on fp32 tensors; norm.hip act_bwd_kernel's arithmetic): d = the conv result,
             // dz = lrelu'(a) d, y = dz * gscale[group];  dbias[ci] += sum dz,  cdot[group] += sum y (z - bias[ci]), z = lrelu^-1(a).
@@ -2420,7 +2423,10 @@ int launch_dgrad(const ConvParams& p, hipStream_t st) {
     if (p.plan_out) { *p.plan_out = p.ksplit > 1 ? p.ksplit : 1; return GCSSL_OK; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cin + BN - 1) / BN, 4 * (p.ksplit > 1 ? p.ksplit : 1));
     if constexpr (MM != 0 && BM == 128 && BN == 64) {
-        if (x3_waves() == 16) { GCSSL_LAUNCH((conv_dgrad_kernel<T, BM, BN, MM, 4, 2>), grid, dim3(512), 0, st, p); return gcssl_launch_status(); }   // (A/B only: neutral)
+        if (x3_waves() == 16 && !p.ab_a) { GCSSL_LAUNCH((conv_dgrad_kernel<T, BM, BN, MM, 4, 2>), grid, dim3(512), 0, st, p); return gcssl_launch_status(); }   // (A/B only: neutral)
+    }
+    if constexpr (MM != 0) {
+        if (p.ab_a) { GCSSL_LAUNCH((conv_dgrad_kernel<T, BM, BN, MM, 2, 2, true>), grid, dim3(NT), 0, st, p); return gcssl_launch_status(); }
     }
     if (Is16<T>::v && use_dma()) launch_dma<typename Op16<T>::type, BM, BN, 1>(p, grid, false, st);
     else GCSSL_LAUNCH((conv_dgrad_kernel<T, BM, BN, MM>), grid, dim3(NT), 0, st, p);
