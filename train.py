@@ -15,6 +15,7 @@ import importlib
 import json
 import os
 import sys
+import time
 from pathlib import Path
 
 import torch
@@ -57,6 +58,8 @@ def build_parser(config: dict) -> argparse.ArgumentParser:
                         "buffers, the logged scalars stay on the device and are read back once per epoch")
     p.add_argument("--iters_per_epoch", type=int, default=20, help="synthetic source: iterations per epoch")
     p.add_argument("--source", default="synthetic", choices=["synthetic", "dataset"])
+    p.add_argument("--synthetic_pool", type=int, default=0,
+                   help="synthetic source: generate this many batches once, keep them in HBM and cycle (0: a fresh batch per iteration, built on the host)")
     return p
 
 
@@ -91,13 +94,28 @@ def allreduce_mean(values, device):
     return (t / torch.distributed.get_world_size()).tolist()
 
 
-def synthetic_source(synth, seed, batch, size, n_critic, device, iters):
+_SYNTH_POOL = {}
+
+
+def synthetic_source(synth, seed, batch, size, n_critic, device, iters, pool=0):
+    """pool > 0: `pool` batches are generated once, kept on the device and cycled (the generator below builds every batch with
+    numpy on the host, ~0.1 s per batch of 256: fine for a smoke run, 50x slower than the step it feeds)."""
     T = torch.from_numpy
-    for it in range(iters):
-        inp = synth.step_inputs(seed + it, batch, size, n_critic, tag="train")
+
+    def make(s):
+        inp = synth.step_inputs(s, batch, size, n_critic, tag="train")
         refined = [T(r).to(device) for r in inp["refined"]]
-        yield (T(inp["pred"]).to(device), T(inp["gt"]).to(device), T(inp["delta_true"]).to(device),
-               T(inp["pred_box"]).to(device), lambda delta, k, r=refined: r[k], dict(refined=refined))
+        return (T(inp["pred"]).to(device), T(inp["gt"]).to(device), T(inp["delta_true"]).to(device),
+                T(inp["pred_box"]).to(device), lambda delta, k, r=refined: r[k], dict(refined=refined))
+    if pool > 0:
+        key = (batch, size, n_critic, str(device), pool)
+        if key not in _SYNTH_POOL:
+            _SYNTH_POOL[key] = [make(seed + j) for j in range(pool)]
+        for it in range(iters):
+            yield _SYNTH_POOL[key][(seed + it) % pool]
+        return
+    for it in range(iters):
+        yield make(seed + it)
 
 
 def dataset_source(ds, refine_mod, indices, batch, size, device, seed):
@@ -262,12 +280,13 @@ def main(argv=None):
     for epoch in range(1, args.n_epochs + 1):
         stats = dict(loss_G=0.0, loss_D=0.0, loss_iou=0.0, loss_wgan=0.0, loss_gp=0.0, wasserstein_distance=0.0)
         n = 0
+        t_epoch = time.perf_counter()
         iou_b = iou_a = 0.0
         if train_idx is not None:
             source = dataset_source(ds, refine_mod, train_idx, args.batch_size // world, args.img_size, device, args.seed + epoch)
         else:
             source = synthetic_source(synth, args.seed + 1000 * epoch + rank, args.batch_size // world, args.img_size,
-                                      args.n_critic, device, args.iters_per_epoch)
+                                      args.n_critic, device, args.iters_per_epoch, pool=args.synthetic_pool)
         if args.graph:
             # the first iteration of the run is eager (it also finishes the library's lazy set-up, which must not happen inside a
             # capture); from the second on, graph replays with a one-batch look-ahead
@@ -302,6 +321,8 @@ def main(argv=None):
                 for k in stats:
                     stats[k] += sums[k]
                 iou_b += sums["iou_before"]; iou_a += sums["iou_after"]; n += ng
+        torch.cuda.synchronize()
+        train_seconds = time.perf_counter() - t_epoch               # the training iterations of the epoch (validation not included)
         for k in stats:
             stats[k] /= max(n, 1)
         delta_iou = (iou_a - iou_b) / max(n, 1)
@@ -331,7 +352,7 @@ def main(argv=None):
         for sc in sched:
             sc.step(delta_iou)
         eng.set_lr(lr_g=sched[0].optimizer.param_groups[0]["lr"], lr_d=sched[1].optimizer.param_groups[0]["lr"])
-        history.append(dict(epoch=epoch, delta_iou=delta_iou, **stats))
+        history.append(dict(epoch=epoch, delta_iou=delta_iou, train_seconds=train_seconds, iterations=n, **stats))
         if rank == 0:
             print(f"[Epoch {epoch}/{args.n_epochs}] G: {stats['loss_G']:.3f} D: {stats['loss_D']:.3f} EIoU: {stats['loss_iou']:.3f} "
                   f"WGAN: {stats['loss_wgan']:.3f} GP: {stats['loss_gp']:.3f} WD: {stats['wasserstein_distance']:.3f} "
