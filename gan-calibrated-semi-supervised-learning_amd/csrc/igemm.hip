@@ -1869,8 +1869,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_persist_kernel(ConvPara
 //       (swaps the 64-B halves of k rows 2, 3 mod 4: the four k rows a 32-lane half reads then cover the four 64-B phases of
 //        a 256-B bank row)
 // ------------------------------------------------------------------------------------------
-template <typename T, int LW = 0>
-__global__ __launch_bounds__(512 + LW * 64) void conv_wgrad_dma_kernel(ConvParams p) {
+// (the body is a device function: conv_wgrad_dma_kernel runs it for one layer, conv_wgrad_dma_batch_kernel for up to three
+// layers in ONE launch -- the weight gradients of a backward pass do not depend on each other)
+template <typename T, int LW>
+__device__ __forceinline__ void wgrad_dma_body(const ConvParams& p, int bx, int by, int bz, const int gdx, const int gdy, const int gdz) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef typename Frag16<T>::type FragT;
     // LW = 8: the 8 waves of the tile only read fragments and run MFMAs, 8 more waves own the LDS-DMA (a piece costs ~105
@@ -1882,10 +1884,9 @@ __global__ __launch_bounds__(512 + LW * 64) void conv_wgrad_dma_kernel(ConvParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = LW > 0 && wave >= 8;
     const int fwave = LW ? wave - 8 : wave;                             // index among the fetching waves
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (p.xcd_remap) {                                                  // a K split's workgroups on one XCD (see conv_wgrad_kernel)
-        const int gx = gridDim.x, per = gx * gridDim.y, ns = gridDim.z;
-        const int L = bx + gx * (by + (int)gridDim.y * bz), full = (ns >> 3) * 8 * per;
+        const int gx = gdx, per = gx * gdy, ns = gdz;
+        const int L = bx + gx * (by + gdy * bz), full = (ns >> 3) * 8 * per;
         int t;
         if (L < full) { const int j = L >> 3; bz = (j / per) * 8 + (L & 7); t = j % per; }
         else { const int r = L - full; bz = (ns & ~7) + r / per; t = r % per; }
@@ -2034,6 +2035,20 @@ __global__ __launch_bounds__(512 + LW * 64) void conv_wgrad_dma_kernel(ConvParam
                 slab[((size_t)co * 16 + tap) * p.Cin + ci0 + 32 * j + (lane & 31)] = acc[i][j][r];
         }
 #endif
+}
+template <typename T, int LW = 0>
+__global__ __launch_bounds__(512 + LW * 64) void conv_wgrad_dma_kernel(ConvParams p) {
+    wgrad_dma_body<T, LW>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
+}
+struct WgradBatch { ConvParams p[3]; int first[4]; int gx[3], gy[3], gz[3]; int n; };
+template <typename T, int LW = 0>
+__global__ __launch_bounds__(512 + LW * 64) void conv_wgrad_dma_batch_kernel(WgradBatch b) {
+    const int L0 = blockIdx.x;
+    const int l = (b.n > 2 && L0 >= b.first[2]) ? 2 : ((b.n > 1 && L0 >= b.first[1]) ? 1 : 0);     // (workgroup-uniform)
+    const int L = L0 - b.first[l], gx = b.gx[l], gy = b.gy[l];
+    if (l == 0) wgrad_dma_body<T, LW>(b.p[0], L % gx, (L / gx) % gy, L / (gx * gy), gx, gy, b.gz[0]);
+    else if (l == 1) wgrad_dma_body<T, LW>(b.p[1], L % gx, (L / gx) % gy, L / (gx * gy), gx, gy, b.gz[1]);
+    else wgrad_dma_body<T, LW>(b.p[2], L % gx, (L / gx) % gy, L / (gx * gy), gx, gy, b.gz[2]);
 }
 
 // sum the split-K slabs, apply the spectral-norm rank-1 corrections, write PyTorch layout
@@ -4068,6 +4083,51 @@ int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int
         else if (bn == 128) WG(T, 64, 128, false); else WG(T, 64, 64, false));
 #undef WG
 #undef WG8
+    return gcssl_launch_status();
+}
+
+// The weight gradients of up to three layers in ONE launch (they do not depend on each other): served when every layer takes the
+// filter-row LDS-DMA kernel (16-bit dtype, wgrad_dma_shape) -- then the workgroups of all layers are one grid; otherwise the
+// layers are launched one by one exactly as gcssl_conv4x4s2_wgrad would.  Arguments per layer as gcssl_conv4x4s2_wgrad's.
+int gcssl_conv4x4s2_wgrad_batch(int dtype, int nl, const void* const* x, const int* ldx, const void* const* dy, const int* lddy,
+                                float* const* slab, const int* N, const int* Hi, const int* Wi, const int* Cin, const int* Cout,
+                                void* stream) {
+    if (!x || !ldx || !dy || !lddy || !slab || !N || !Hi || !Wi || !Cin || !Cout) return GCSSL_ENULL;
+    if (nl < 1 || nl > 3) return GCSSL_EBADSHAPE;
+    if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
+    static const bool on = [] { const char* e = getenv("GCSSL_WGRAD_BATCH"); return !(e && e[0] == '0'); }();
+    bool all_dma = on && !gcssl_f32_storage(dtype) && nl > 1;
+    for (int i = 0; i < nl && all_dma; ++i)
+        all_dma = x[i] && dy[i] && slab[i] && check_geom(N[i], Hi[i], Wi[i], Cin[i], Cout[i]) == 0 && wgrad_dma_shape(N[i], Hi[i], Wi[i], Cin[i], Cout[i]) &&
+                  ldx[i] >= Cin[i] && lddy[i] >= Cout[i] && ldx[i] % 8 == 0 && lddy[i] % 8 == 0 && aligned16(x[i]) && aligned16(dy[i]);
+    static const int lw = [] { const char* e = getenv("GCSSL_WGRAD_LW"); return e ? atoi(e) : 8; }();
+    if (!all_dma || !lw) {
+        for (int i = 0; i < nl; ++i) {
+            const int rc = gcssl_conv4x4s2_wgrad(dtype, x[i], ldx[i], dy[i], lddy[i], slab[i], N[i], Hi[i], Wi[i], Cin[i], Cout[i], stream);
+            if (rc) return rc;
+        }
+        return GCSSL_OK;
+    }
+    WgradBatch b{};
+    int total = 0;
+    for (int i = 0; i < nl; ++i) {
+        const int nsplit = gcssl_conv4x4s2_wgrad_splits(N[i], Hi[i], Wi[i], Cin[i], Cout[i]);
+        if (nsplit <= 0) return GCSSL_EBADSHAPE;
+        ConvParams& p = b.p[i];
+        p.x = x[i]; p.w = dy[i]; p.y = slab[i]; p.ldx = ldx[i]; p.ldw = lddy[i];
+        p.xcd_remap = wgrad_xcd();
+        fill_geom(p, N[i], Hi[i], Wi[i], Cin[i], Cout[i]);
+        if (!fill_bytes(p, (size_t)N[i] * Hi[i] * Wi[i] * ldx[i], (size_t)N[i] * (Hi[i] / 2) * (Wi[i] / 2) * lddy[i], 2)) return GCSSL_EBADSHAPE;
+        const int nkt = (p.M + 63) / 64;
+        p.ktiles_per_split = ((nkt + nsplit - 1) / nsplit) * (64 / BKOf<bf16_t>::v);
+        set_mm_scales(p, false);
+        b.gx[i] = Cout[i] / 128; b.gy[i] = 4 * (Cin[i] / 64); b.gz[i] = nsplit;
+        b.first[i] = total; total += b.gx[i] * b.gy[i] * b.gz[i];
+    }
+    b.first[nl] = total; b.n = nl;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GCSSL_F16) GCSSL_LAUNCH((conv_wgrad_dma_batch_kernel<f16_t, 8>), dim3((unsigned)total), dim3(1024), 0, st, b);
+    else GCSSL_LAUNCH((conv_wgrad_dma_batch_kernel<bf16_t, 8>), dim3((unsigned)total), dim3(1024), 0, st, b);
     return gcssl_launch_status();
 }
 

@@ -1314,6 +1314,6 @@ int gcssl_uncast(int dtype, const void* x, float* y, long n, void* stream) {
 const char* gcssl_version(void) { return "gcssl-hip 0.4 (gfx950)"; }
 // ABI revision: bumped whenever an existing entry point's argument list or a constant's meaning changes (a ctypes / C caller
 // built against another revision of include/gcssl.h must refuse to run: _lib.py checks it against GCSSL_ABI_REVISION)
-int gcssl_abi_revision(void) { return 4; }
+int gcssl_abi_revision(void) { return 5; }
 
 }  // extern "C"

@@ -263,6 +263,8 @@ class StepEngine:
         self.side_g = _side_stream(dev, "gen") if self.overlap_g else None
         self.side_sn = _side_stream(dev, "sn") if self.overlap_g >= 2 else None
         self.probe = None          # {label: {"events": [(start, stop)...], "flops": f}} when profiling is enabled
+        self._wgrad_batch_on = os.environ.get("GCSSL_WGRAD_BATCH", "1") != "0"
+        self._wgrad_d = self._wgrad_gu = None
         self.step_log = self.delta_log = None                      # enable_step_log(): per-critic-step scalars / the generator step's delta, kept on the device
         self._k_cur = 0
         self.probe_repeats = 0
@@ -955,6 +957,10 @@ class StepEngine:
         # the reverse GP chain's adjoint activations gt_a (the derivative of the first-order seed w5 * 1)
         ops.c5_wgrad(self.d_a4[3], gw5, 512, consts=(seeds[0], seeds[1], seeds[2], 1.0), group_n=B)
         c1_done = False
+        # the weight gradients of c2-c4 as ONE launch behind the dgrad chain (they depend on nothing but their layer's dzs / x;
+        # GCSSL_WGRAD_BATCH=0: one launch per layer, beside the chain as before)
+        wgrad_batch = self._wgrad_batch_on
+        wgrad_last, deferred = os.environ.get("GCSSL_WGRAD_LAST", "0") != "0", []
         for l in (3, 2, 1, 0):
             cin, cout = D_CH[l]
             cp = _pad8(cin)
@@ -973,7 +979,12 @@ class StepEngine:
 
             def wgrad_branch(l=l, cout=cout, cp=cp, fl4=conv_flops(4 * B, S >> l, cin, cout)):
                 self._conv(f"D.c{l + 1}.wgrad", fl4, ops.conv_wgrad, self.d_x4[l], self.d_dzs4[l], self.d_slab[l], cp, cout)
-            self._on_side(wgrad_branch)                           # beside the dgrad -> norm-backward chain
+            if wgrad_batch and l >= 1:
+                pass                                              # (c2-c4: the batched launch behind the chain)
+            elif wgrad_last:
+                deferred.append(wgrad_branch)                     # (A/B: all weight gradients behind the dgrad chain)
+            else:
+                self._on_side(wgrad_branch)                       # beside the dgrad -> norm-backward chain
             if l == 1 and self._actb(N3, S >> 1, cin, cout, True):
                 # c2's data gradient with c1's LeakyReLU backward (+ its bias-gradient and spectral-norm sums) in the epilogue:
                 # d_dzs[0] directly; the 3B x 16x16x64 fp32 d_da[0] is neither written nor read back
@@ -985,6 +996,17 @@ class StepEngine:
                 c1_done = True
             elif l > 0:
                 self._conv(f"D.c{l + 1}.dgrad", fl, ops.conv_dgrad, self.d_dzs[l], self.d_wt[l], self.d_da[l - 1], cin, cout)
+        for fn in deferred:
+            fn()
+        if wgrad_batch:
+            if self._wgrad_d is None:
+                lay = [(self.d_x4[l], self.d_dzs4[l], self.d_slab[l], _pad8(D_CH[l][0]), D_CH[l][1]) for l in (3, 2, 1)]
+                self._wgrad_d = ops.WgradBatch(lay)
+                es = 4 if self.code == _lib.F32 else 2             # (bytes as engine._algorithmic_bytes counts a weight gradient)
+                self._wgrad_d_bytes = (sum((x.numel() + dy.numel() + sl.numel() // sl.shape[0]) * es for x, dy, sl, _, _ in lay),
+                                       sum(x.numel() * x.element_size() + dy.numel() * dy.element_size() + sl.numel() * 4 for x, dy, sl, _, _ in lay))
+            self._conv("D.c2-4.wgrad", sum(conv_flops(4 * B, S >> l, *D_CH[l]) for l in (1, 2, 3)), ops.conv_wgrad_batch, self._wgrad_d,
+                       _bytes=self._wgrad_d_bytes)
         self._join_side()                                         # all gradient branches are in before the segment ends
         # dW_orig = sum_k G_k / sigma_k - sum_k c_k u_k v_k^T for the four spectrally-normalised layers, one launch -- which also
         # folds the striped sums (bias gradients -> flat gradient; c_k = its GP-chain part in `cdot` + the replicas)
@@ -1080,11 +1102,21 @@ class StepEngine:
             def up_wgrad(k=k, cint=cint, coutt=coutt, fl=fl):
                 self._conv(f"G.up{k + 1}.wgrad", fl, ops.conv_wgrad, self.g_dzu[k], ins[k], self.g_slab_u[k], coutt,
                            cint)                                                        # roles swapped (ConvTranspose)
-            self._on_side(up_wgrad)
+            if not (self._wgrad_batch_on and k >= 1):              # (up2-up4: one batched launch behind the chain, as the critic's)
+                self._on_side(up_wgrad)
             ns4, st4 = self._split("fwd", self.g_dd4, B, S >> 3, coutt, cint, grad=True) if k == 0 else (1, 0)
             self._conv(f"G.up{k + 1}.dgrad", fl, ops.conv_fwd, self.g_dzu[k], self.gu_wf[k], dcat[k], coutt, cint,
                        split_stride=st4)
         self._g_dd4_slabs = (ns4, st4)
+        if self._wgrad_batch_on:
+            if self._wgrad_gu is None:
+                lay = [(self.g_dzu[k], ins[k], self.g_slab_u[k], G_UP[k][1], G_UP[k][0]) for k in (3, 2, 1)]
+                self._wgrad_gu = ops.WgradBatch(lay)
+                es = 4 if self.code == _lib.F32 else 2
+                self._wgrad_gu_bytes = (sum((x.numel() + dy.numel() + sl.numel() // sl.shape[0]) * es for x, dy, sl, _, _ in lay),
+                                        sum(x.numel() * x.element_size() + dy.numel() * dy.element_size() + sl.numel() * 4 for x, dy, sl, _, _ in lay))
+            self._conv("G.up2-4.wgrad", sum(conv_flops(B, S >> (3 - k), G_UP[k][1], G_UP[k][0]) for k in (1, 2, 3)), ops.conv_wgrad_batch,
+                       self._wgrad_gu, _bytes=self._wgrad_gu_bytes)
         self._join_side()
 
     def g_main_b(self) -> None:

@@ -190,6 +190,33 @@ def conv_wgrad(x, dy, slab, cin, cout, dt=None):
     call("gcssl_conv4x4s2_wgrad", code(x) if dt is None else dt, x, _ld(x), dy, _ld(dy), slab, N, Hi, Wi, cin, cout)
 
 
+class WgradBatch:
+    """Argument block for gcssl_conv4x4s2_wgrad_batch: layers = [(x, dy, slab, cin, cout), ...] (<= 3; x: [N][Hi][Wi][>=cin],
+    dy: [N][Hi/2][Wi/2][>=cout]).  One launch when every layer takes the filter-row LDS-DMA kernel, else one per layer."""
+
+    def __init__(self, layers, dt=None):
+        self._keep = layers
+        self.n = len(layers)
+        self.dt = code(layers[0][0]) if dt is None else dt
+        self._x = _lib.ptr_array([l[0] for l in layers]); self._dy = _lib.ptr_array([l[1] for l in layers])
+        self._slab = _lib.ptr_array([l[2] for l in layers])
+        self._ldx = _lib.int_array([_ld(l[0]) for l in layers]); self._lddy = _lib.int_array([_ld(l[1]) for l in layers])
+        self._N = _lib.int_array([l[0].shape[0] for l in layers]); self._H = _lib.int_array([l[0].shape[1] for l in layers])
+        self._W = _lib.int_array([l[0].shape[2] for l in layers])
+        self._ci = _lib.int_array([l[3] for l in layers]); self._co = _lib.int_array([l[4] for l in layers])
+
+    def run(self):
+        call("gcssl_conv4x4s2_wgrad_batch", self.dt, self.n, self._x, self._ldx, self._dy, self._lddy, self._slab, self._N, self._H,
+             self._W, self._ci, self._co)
+
+
+def conv_wgrad_batch(batch: "WgradBatch", dt=None):
+    """(the engine's launch wrapper passes dt for the split-precision modes: then the layers go out one by one)"""
+    if dt is not None:
+        batch.dt = dt
+    batch.run()
+
+
 def wgrad_reduce(slab, nsplit, dw, cout, cin, cin_real, coef=None, cscale=None, u=None, v=None, nrank=0,
                  accumulate=False):
     """u, v: 2-D [nrank][>=cout] / [nrank][>=cin_real*16] (row strides are taken from the tensors)."""
@@ -511,4 +538,5 @@ def mlp_head_bwd(gdelta, traw, h1, h2, feat, w1, w2, w3, delta_scale, train, dp1
 
 
 #: the wrappers that take the conv dtype keyword `dt` (StepEngine injects its split-precision code into these)
-CONV_FNS = (conv_fwd, conv_dgrad, conv_wgrad, conv3_fwd, conv3_wgrad, conv_in_act_x3_fwd, conv_fwd_act_bwd, conv_dgrad_act_bwd)
+CONV_FNS = (conv_fwd, conv_dgrad, conv_wgrad, conv3_fwd, conv3_wgrad, conv_in_act_x3_fwd, conv_fwd_act_bwd, conv_dgrad_act_bwd,
+            conv_wgrad_batch)

@@ -45,7 +45,7 @@ extern "C" {
 
 /* Revision of THIS header's contract: argument lists and constants.  gcssl_abi_revision() of the loaded library must equal
  * it (round 3 changed a dozen argument lists in place under an unchanged version string: ADVICE r3). */
-#define GCSSL_ABI_REVISION 4
+#define GCSSL_ABI_REVISION 5
 int gcssl_abi_revision(void);
 const char* gcssl_version(void);
 /* The kernel template expression the most recent conv entry point of THIS process launched (as written at its launch site:
@@ -161,6 +161,12 @@ int gcssl_conv4x4s2_fwd_act_bwd(int dtype, const void* x, int ldx, const void* w
 int gcssl_conv4x4s2_wgrad_splits(int N, int Hi, int Wi, int Cin, int Cout);
 int gcssl_conv4x4s2_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, float* slab, int N, int Hi,
                           int Wi, int Cin, int Cout, void* stream);
+/* Up to three layers' weight gradients as ONE launch (a backward pass's weight gradients do not depend on each other; arguments
+ * per layer as gcssl_conv4x4s2_wgrad's, nl in 1..3).  One grid when every layer takes the filter-row LDS-DMA kernel (16-bit
+ * dtypes, the critic's c2-c4 / the generator's up2-up4 at the bench batch); otherwise identical to nl single calls. */
+int gcssl_conv4x4s2_wgrad_batch(int dtype, int nl, const void* const* x, const int* ldx, const void* const* dy, const int* lddy,
+                                float* const* slab, const int* N, const int* Hi, const int* Wi, const int* Cin, const int* Cout,
+                                void* stream);
 /* dw[Cout][Cin_real][4][4] (=|+=) sum_s slab[s] - sum_k coef[k]*cscale[k] u_k[co] v_k[ci*16+tap]: split-K reduction
  * fused with the spectral-norm quotient rule d(W/sigma) (sigma = u^T W v; cgan/models.py:237-238).
  * u: nrank rows of stride ustride (>= Cout); v: nrank rows of stride vstride (>= Cin_real*16); cscale nullable.

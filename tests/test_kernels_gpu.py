@@ -170,6 +170,27 @@ X3 = [("fp16x3", 2e-5), ("bf16x3", 6e-5)]
 X3_CASES = [c for c in CONV_CASES if c[0] <= 768 and c[1] <= 64] + [(768, 16, 64, 64, 128), (2, 128, 6, 8, 64)]
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+def test_conv_wgrad_batch(ops, dt):
+    """gcssl_conv4x4s2_wgrad_batch (the critic's three big layers' weight gradients as one launch) == three single calls, slab for
+    slab (same kernel body, same K ranges): bit-equal in the 16-bit dtypes, and a plain loop over the layers in fp32."""
+    shapes = [(1024, 16, 64, 128), (1024, 8, 128, 256), (1024, 4, 256, 512)]            # D.c2 / c3 / c4 at the bench batch (4B samples)
+    lay, single = [], []
+    for i, (N, Hi, Cin, Cout) in enumerate(shapes):
+        x = nhwc(q(rnd(N, Cin, Hi, Hi, seed=200 + i), dt), dt)
+        dy = nhwc(q(rnd(N, Cout, Hi // 2, Hi // 2, seed=210 + i), dt), dt)
+        ns = ops.wgrad_splits(N, Hi, Hi, Cin, Cout)
+        s1 = torch.full((ns, Cout, 16, Cin), float("nan"), device="cuda")
+        s2 = torch.full((ns, Cout, 16, Cin), float("nan"), device="cuda")
+        ops.conv_wgrad(x, dy, s1, Cin, Cout)
+        lay.append((x, dy, s2, Cin, Cout)); single.append(s1)
+    ops.WgradBatch(lay).run()
+    torch.cuda.synchronize()
+    for (x, dy, s2, _, _), s1 in zip(lay, single):
+        assert bool(torch.isfinite(s2).all())
+        assert torch.equal(s1, s2)
+
+
 @pytest.mark.parametrize("mode,tol", X3)
 @pytest.mark.parametrize("N,Hi,Cin,CinP,Cout", X3_CASES)
 def test_conv_split_precision(ops, mode, tol, N, Hi, Cin, CinP, Cout):
