@@ -17,6 +17,7 @@ CASES=(
  "D.c2.fwd[n=768]|tools/conv_bench.py fwd_in 768 16 64 128 $DT 5"
  "D.c3.fwd[n=768]|tools/conv_bench.py fwd_in 768 8 128 256 $DT 5"
  "D.c4.fwd[n=768]|tools/conv_bench.py fwd_in 768 4 256 512 $DT 5"
+ "D.c2-4.wgrad|tools/wgrad_batch_bench.py 256 32 $DT 5"
  "D.c2.wgrad|tools/conv_bench.py wgrad 1024 16 64 128 $DT 5"
  "D.c4.wgrad|tools/conv_bench.py wgrad 1024 4 256 512 $DT 5"
  "D.c3.dgrad|tools/conv_bench.py dgrad 768 8 128 256 $DT 5"

@@ -9,7 +9,7 @@ from collections import defaultdict
 out_dir, dt = sys.argv[1], sys.argv[2]
 out_name = sys.argv[3] if len(sys.argv) > 3 else "round4_pmc_dominant.json"
 script = sys.argv[4] if len(sys.argv) > 4 else "tools/pmc_round4.sh"
-CASES = {"D.c2.fwd[n=768]": "conv_dma", "D.c3.fwd[n=768]": "conv_dma", "D.c4.fwd[n=768]": "conv_dma", "D.c2.wgrad": "conv_wgrad",
+CASES = {"D.c2-4.wgrad": "conv_wgrad_dma_batch", "D.c2.fwd[n=768]": "conv_dma", "D.c3.fwd[n=768]": "conv_dma", "D.c4.fwd[n=768]": "conv_dma", "D.c2.wgrad": "conv_wgrad",
          "D.c3.wgrad": "conv_wgrad", "D.c4.wgrad": "conv_wgrad", "D.c2.dgrad": "dgrad_img", "D.c3.dgrad": "conv_dma", "D.c4.dgrad": "conv_dma", "D.c1.fwd[n=768]": "conv_",
          "D.c1.gp_dgrad": "conv_", "G.up4.fwd[n=768]": "convt_in_relu",
          # the split-precision mode's leading launches (fp16x3: recorded under their own tags) and the re-crop stage
