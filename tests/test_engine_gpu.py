@@ -454,7 +454,7 @@ def test_graph_replay_matches_eager_at_bench_config(synth, dtype, form, monkeypa
                               float(fe.gviews[k].norm()), float(fg.gviews[k].norm())) for k in fe.keys), reverse=True)[:3]
             # measured: bf16 1.5e-2..2.7e-2 on the critic (its first layer's gradient, behind four InstanceNorms and the
             # double backward), fp16 ~3e-3, for graph-vs-eager and eager-vs-eager alike; stale accumulation would be ~1.0
-            assert err < max(2e-2, 3.0 * floor) and err < 0.1, (it, name, err, floor, per_key)
+            assert err < max(4e-2, 3.0 * floor) and err < 0.1, (it, name, err, floor, per_key)       # (headroom over the 2.7e-2 seen)
         scal = lambda e: (float(e.gp_sum), float(e.eiou_acc), float(e.D.state[2]), float(e.G.state[2]))
         # penalty, box loss, the two total gradient norms.  Two eager runs launched the same way are nearly deterministic
         # (same atomic orders: 3e-6 apart), a replayed graph has other timings and sits at the mode's chaos level --
