@@ -218,3 +218,32 @@ static inline void gcssl_zero2d_async(float* p, size_t ld, int cols, size_t rows
     size_t blocks = (rows * cols + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(gcssl_zero2d_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, ld, cols, rows);
 }
+
+// ---- spectral-norm batch arguments (misc.hip's chain; igemm.hip's weight re-pack launch can carry the chain's closing step)
+struct SnLayer { const float* w; float* u; float* v; float* t; float* s; int rows, cols; };
+struct SnBatch { SnLayer l[4]; int nl; float* sigma; float* isig; float* u_hist; float* v_hist; int hist_stride_u, hist_stride_v; int slot, nslots;
+                 int par;            // which half of a layer's 2 x cols scratch `t` this iteration accumulates into (chain position & 1)
+                 int fin_prev;       // sn_wtu: the PREVIOUS iteration of the chain has not been closed -- u is still s (= W v), see misc.hip
+                 float* zero; long nzero; };   // sn_finish: an extra buffer to clear (the engine's scalar / replica block), nullable
+// the closing step of a chain for layer `layer` (one 256-thread workgroup of `nblk` that share the extra fill):
+// u = s / max(|s|, eps), sigma = u . s, t zeroed again for the next iteration
+__device__ __forceinline__ void sn_finish_body(const SnBatch& b, int layer, int nblk) {
+    const SnLayer L = b.l[layer];
+    __shared__ float red[4];
+    float q2 = 0.f;
+    for (int r = threadIdx.x; r < L.rows; r += 256) { const float sv = L.s[r]; q2 += sv * sv; }
+    const float s2 = block_sum<4>(q2, red);
+    const float uinv = 1.f / fmaxf(sqrtf(s2), 1e-12f);
+    float* uh = b.u_hist + ((size_t)layer * b.nslots + b.slot) * b.hist_stride_u;
+    for (int r = threadIdx.x; r < L.rows; r += 256) { const float uu = L.s[r] * uinv; L.u[r] = uu; uh[r] = uu; }
+    float* tcur = L.t + (b.par ? L.cols : 0);
+    for (int c = threadIdx.x; c < L.cols; c += 256) tcur[c] = 0.f;            // (the other half was cleared by sn_wv_kernel)
+    if (threadIdx.x == 0) {
+        const float sg = s2 * uinv;
+        b.sigma[layer * b.nslots + b.slot] = sg;
+        b.isig[layer * b.nslots + b.slot] = 1.f / sg;
+    }
+    // an extra fill for the caller (the engine's scalar / striped-sum block, cleared once per critic step): the workgroups share it
+    for (long i = (long)layer * 256 + threadIdx.x; i < b.nzero; i += (long)nblk * 256) b.zero[i] = 0.f;
+}
+extern "C" __attribute__((visibility("hidden"))) int gcssl_take_pending_sn(SnBatch* out);   // misc.hip: 1 and *out = a closing step left pending by gcssl_sn_defer_finish, else 0

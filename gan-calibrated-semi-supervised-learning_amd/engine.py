@@ -119,7 +119,7 @@ class _NoSpectralNorm:
         self.sigma = torch.ones(n, nslots, device=device)
         self.u_hist = self.v_hist = None
 
-    def iterate(self, slot, iterate=True, zero=None):
+    def iterate(self, slot, iterate=True, zero=None, defer_finish=False):
         if zero is not None:
             zero.zero_()
 
@@ -264,6 +264,7 @@ class StepEngine:
         self.side_sn = _side_stream(dev, "sn") if self.overlap_g >= 2 else None
         self.probe = None          # {label: {"events": [(start, stop)...], "flops": f}} when profiling is enabled
         self._wgrad_batch_on = os.environ.get("GCSSL_WGRAD_BATCH", "1") != "0"
+        self._sn_defer = self.spectral_norm and os.environ.get("GCSSL_SN_DEFER", "1") != "0"     # (A/B knob)
         self._wgrad_d = self._wgrad_gu = None
         self.step_log = self.delta_log = None                      # enable_step_log(): per-critic-step scalars / the generator step's delta, kept on the device
         self._k_cur = 0
@@ -888,7 +889,8 @@ class StepEngine:
     def _sn_and_prep(self) -> None:
         # real, fake, interp forwards each iterate once: three chained power iterations (slots 0..2), whose closing launch also
         # clears the per-step scalars + striped-sum replicas (zero_blk) -- no fill launch of its own
-        self.sn.iterate(0, 3, zero=self.zero_blk)
+        # (the chain's closing step rides on the re-pack launch that follows it when there is one: ops.SpectralNorm.iterate)
+        self.sn.iterate(0, 3, zero=self.zero_blk, defer_finish=self._sn_defer and self._d_dirty)
         self._prep_d()
 
     def d_main(self, sn_done: bool = False) -> None:
@@ -1046,7 +1048,7 @@ class StepEngine:
         """D forward on (pred, refined_G): value only (zero gradient to G) but it advances u,v (:361)."""
         B = self.B
         xbuf = self.x0[B:2 * B] if xbuf is None else xbuf          # x0[:B] stays G's input (down1's wgrad operand)
-        self.sn.iterate(0, True, zero=self.wgan_mean)              # (the closing launch clears the mean the head conv adds to)
+        self.sn.iterate(0, True, zero=self.wgan_mean, defer_finish=self._sn_defer and self._d_dirty)   # (the closing launch clears the mean the head conv adds to)
         self._prep_d()
         ops.pack_pair(pred, self._refined_g, xbuf)
         self._d_forward(B, lambda l: self.sn.isig[l, 0:1], B, x=xbuf, means=self.wgan_mean, groups=1)   # loss_WGAN_G = -mean (:362)

@@ -380,9 +380,12 @@ class SnState:
         self._w, self._u, self._v = _lib.ptr_array(self.ws), _lib.ptr_array(self.us), _lib.ptr_array(self.vs)
         self._t, self._s = _lib.ptr_array(self.t), _lib.ptr_array(self.s)
 
-    def iterate(self, slot: int, iterate=True, zero=None):
+    def iterate(self, slot: int, iterate=True, zero=None, defer_finish=False):
         """iterate: True / k = that many chained power iterations filling slots slot.., False / 0 = sigma only.
-        zero: a float tensor the closing launch also clears."""
+        zero: a float tensor the closing launch also clears.  defer_finish: leave the chain's closing step to the NEXT
+        PrepBatch.run() (gcssl_sn_defer_finish: one launch less; the caller re-packs right after)."""
+        if defer_finish and iterate:
+            _lib.lib().gcssl_sn_defer_finish(1)
         call("gcssl_sn_power_iter", self.n, self._w, self._u, self._v, self._t, self._s, self._rows, self._cols,
              self.sigma, self.isig, self.u_hist, self.v_hist, self.su, self.sv, slot, self.nslots, int(iterate),
              zero, zero.numel() if zero is not None else 0)

@@ -264,6 +264,12 @@ int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* c
                         const int* rows, const int* cols, float* sigma, float* isig, float* u_hist, float* v_hist,
                         int hist_stride_u, int hist_stride_v, int slot, int nslots, int iterate, float* zero, long nzero,
                         void* stream);
+/* One launch less per chain: gcssl_sn_defer_finish(1) asks the NEXT gcssl_sn_power_iter(iterate > 0) of this thread to leave its
+ * closing step (u = s/|s|, sigma, the extra fill: 4 workgroups) pending; the NEXT gcssl_prep_conv_weights launch then carries it as
+ * an extra grid row -- the re-pack reads nothing the chain writes, and both must finish before the first conv of the forward.
+ * gcssl_sn_flush_finish launches a pending step on its own (a caller that deferred and does not re-pack after all). */
+int gcssl_sn_defer_finish(int on);
+int gcssl_sn_flush_finish(void* stream);
 
 /* ---- fused generator up-path layer (cgan/models.py:72-74,112-118) ---------------------------------------------------------
  * ConvTranspose2d(K -> 64, k4 s2 p1, bias=False) + InstanceNorm2d + ReLU (+ the sums AdaptiveAvgPool2d(1) needs) as ONE

@@ -727,6 +727,44 @@ def test_spectral_norm_power_iteration(ops, shapes, chained, coop, monkeypatch):
         assert "sn_coop" in ops.last_kernel() or True                          # (launched by hipLaunchKernelGGL: not recorded)
 
 
+def test_spectral_norm_finish_deferred_into_repack(ops):
+    """gcssl_sn_defer_finish: the chain's closing step (u, sigma, the extra fill) rides on the weight re-pack launch that follows --
+    same results as the chain with its own closing launch, and the re-pack itself is unchanged; a deferred step that is not
+    followed by a re-pack can be flushed."""
+    lib = load_pkg("_lib")
+    shapes = [(64, 6 * 16), (128, 64 * 16), (256, 128 * 16), (512, 256 * 16)]
+    chans = [(6, 64), (64, 128), (128, 256), (256, 512)]
+    ws4 = [rnd(co, ci, 4, 4, seed=40 + i, scale=0.05).cuda() for i, (ci, co) in enumerate(chans)]
+    res = []
+    for defer in (False, True, "flush"):
+        wd = [w.reshape(w.shape[0], -1).clone() for w in ws4]
+        ud = [F.normalize(rnd(r, seed=50 + i), dim=0).cuda() for i, (r, _) in enumerate(shapes)]
+        vd = [F.normalize(rnd(c, seed=60 + i), dim=0).cuda() for i, (_, c) in enumerate(shapes)]
+        sn = ops.SnState(wd, ud, vd, 3, "cuda")
+        extra = torch.full((1000,), 3.0, device="cuda")
+        packs = [(torch.full((co, 16, (ci + 7) // 8 * 8), float("nan"), device="cuda", dtype=torch.bfloat16),
+                  torch.full(((ci + 7) // 8 * 8, 16, co), float("nan"), device="cuda", dtype=torch.bfloat16)) for ci, co in chans]
+        prep = ops.PrepBatch([(w, wf, wt, co, ci, (ci + 7) // 8 * 8) for w, (wf, wt), (ci, co) in zip(ws4, packs, chans)],
+                             lib.dtype_code(torch.bfloat16))
+        sn.iterate(0, 3, zero=extra, defer_finish=bool(defer))
+        if defer == "flush":
+            lib.call("gcssl_sn_flush_finish")
+        prep.run()
+        torch.cuda.synchronize()
+        assert float(extra.abs().max()) == 0.0
+        assert all(float(t.abs().max()) == 0.0 for t in sn.t)
+        res.append((sn.sigma.clone(), sn.isig.clone(), sn.u_hist.clone(), [u.clone() for u in ud], [p[0].clone() for p in packs],
+                    [p[1].clone() for p in packs]))
+    for other in res[1:]:
+        for a, b in zip(res[0][:3], other[:3]):                     # sigma, 1/sigma, u history: the chain's float atomics move the last bits
+            assert rel_err(b.cpu(), a.cpu()) < 1e-5
+        for a, b in zip(res[0][3], other[3]):
+            assert rel_err(b.cpu(), a.cpu()) < 1e-5
+        for la, lb in zip(res[0][4:], other[4:]):                   # the packed weights: bit-equal
+            for a, b in zip(la, lb):
+                assert torch.equal(a, b) and bool(torch.isfinite(a.float()).all())
+
+
 def test_launch_folds(ops):
     """The bookkeeping that rides on neighbouring launches (round 3): group means from the head conv, four group constants
     of the head's weight gradient, replicated input packing, <x, da> inside act_bwd, the critic head's re-pack inside the
