@@ -246,4 +246,35 @@ __device__ __forceinline__ void sn_finish_body(const SnBatch& b, int layer, int 
     // an extra fill for the caller (the engine's scalar / striped-sum block, cleared once per critic step): the workgroups share it
     for (long i = (long)layer * 256 + threadIdx.x; i < b.nzero; i += (long)nblk * 256) b.zero[i] = 0.f;
 }
-extern "C" __attribute__((visibility("hidden"))) int gcssl_take_pending_sn(SnBatch* out);   // misc.hip: 1 and *out = a closing step left pending by gcssl_sn_defer_finish, else 0
+extern "C" __attribute__((visibility("hidden"))) int gcssl_take_pending_sn(SnBatch* out);
+// ---- the head conv's data gradient with per-group CONSTANT dout (misc.hip c5_dgrad_const_kernel) as a rider of the weight
+// re-pack launch: dx[n, p, :] = g(n) * tab[p][:], tab[p][c] = sum of w[c][tap] over the taps through which pixel p reaches an
+// output.  It reads the RAW weight [512][16] (the packed copy is being written by the same launch) and writes fp32.
+struct C5DgradRider { float g[4]; int group_n; const float* w; float* dx; int lddx, N, Hi, Wi, per, nblk; };
+__device__ __forceinline__ void c5_dgrad_rider_body(const C5DgradRider& r, int blk) {
+    constexpr int C = 512;
+    const int Ho = r.Hi - 1, Wo = r.Wi - 1, P = r.Hi * r.Wi;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane * 8;
+    const int nb = blk * r.per, ne = min(r.N, nb + r.per);
+    for (int p = wave; p < P; p += 4) {
+        const int iy = p / r.Wi, ix = p - iy * r.Wi;
+        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < 4; ++ky) {
+            if ((unsigned)(iy + 1 - ky) >= (unsigned)Ho) continue;
+            for (int kx = 0; kx < 4; ++kx) {
+                if ((unsigned)(ix + 1 - kx) >= (unsigned)Wo) continue;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] += r.w[(size_t)(c + j) * 16 + ky * 4 + kx];
+            }
+        }
+        for (int n = nb; n < ne; ++n) {
+            const int g = n / r.group_n;
+            const float gc = g == 0 ? r.g[0] : (g == 1 ? r.g[1] : (g == 2 ? r.g[2] : r.g[3]));
+            float* o = r.dx + ((size_t)n * P + p) * r.lddx + c;
+            reinterpret_cast<float4*>(o)[0] = make_float4(gc * t[0], gc * t[1], gc * t[2], gc * t[3]);
+            reinterpret_cast<float4*>(o)[1] = make_float4(gc * t[4], gc * t[5], gc * t[6], gc * t[7]);
+        }
+    }
+}
+extern "C" __attribute__((visibility("hidden"))) int gcssl_take_pending_c5(C5DgradRider* out);   // misc.hip, as gcssl_take_pending_sn
+   // misc.hip: 1 and *out = a closing step left pending by gcssl_sn_defer_finish, else 0

@@ -2357,9 +2357,13 @@ template <> __device__ __forceinline__ void store16<f16_t>(f16_t* dst, const flo
 // form below (2-byte writes 16*Cout elements apart for Wt) ran at <1 TB/s.  Layers whose channel counts are not
 // multiples of 64, or padded (the first layers), keep the element-wise form: they are tiny.
 template <typename T>
-__global__ __launch_bounds__(256) void prep_weight_batch_kernel(PrepBatch b, SnBatch sn, int sn_row) {
+__global__ __launch_bounds__(256) void prep_weight_batch_kernel(PrepBatch b, SnBatch sn, int sn_row, C5DgradRider c5r, int c5_row) {
     if ((int)blockIdx.y == sn_row) {                         // one more grid row: a spectral-norm chain's closing step (gcssl_sn_defer_finish)
         if (blockIdx.z == 0 && (int)blockIdx.x < sn.nl) sn_finish_body(sn, blockIdx.x, sn.nl);
+        return;
+    }
+    if ((int)blockIdx.y == c5_row) {                         // ... and one for the head conv's constant-seed data gradient (gcssl_conv4x4s1_c1_dgrad_defer)
+        if (blockIdx.z == 0) for (int blk = blockIdx.x; blk < c5r.nblk; blk += gridDim.x) c5_dgrad_rider_body(c5r, blk);
         return;
     }
     if ((int)blockIdx.y == b.nl) {                           // the extra grid row: the 512 -> 1 head conv's weight (gcssl_prep_c5_weight)
@@ -4206,9 +4210,13 @@ int gcssl_prep_conv_weights(int dtype, int nl, const float* const* w, void* cons
     if (gcssl_bad_conv_dtype(dtype)) return GCSSL_EBADDTYPE;
     SnBatch sn{};
     int sn_row = -1;                                         // a spectral-norm closing step left pending for this launch?
-    if (gcssl_take_pending_sn(&sn)) { sn_row = nl + (w5 ? 1 : 0); if (gx < (unsigned)sn.nl) gx = (unsigned)sn.nl; }
-    dim3 grid(gx, nl + (w5 ? 1 : 0) + (sn_row >= 0 ? 1 : 0), 2);
-    GCSSL_DISPATCH_CONV(dtype, GCSSL_LAUNCH(prep_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b, sn, sn_row));
+    int rows = nl + (w5 ? 1 : 0);
+    if (gcssl_take_pending_sn(&sn)) { sn_row = rows++; if (gx < (unsigned)sn.nl) gx = (unsigned)sn.nl; }
+    C5DgradRider c5r{};
+    int c5_row = -1;                                         // ... a deferred head-conv data gradient?
+    if (gcssl_take_pending_c5(&c5r)) c5_row = rows++;
+    dim3 grid(gx, rows, 2);
+    GCSSL_DISPATCH_CONV(dtype, GCSSL_LAUNCH(prep_weight_batch_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, b, sn, sn_row, c5r, c5_row));
     return gcssl_launch_status();
 }
 

@@ -963,6 +963,7 @@ __global__ void uncast_kernel(const T* __restrict__ x, float* __restrict__ y, si
     if (i < n) y[i] = Elem<T>::ld(x + i);
 }
 
+__global__ __launch_bounds__(256) void c5_dgrad_rider_kernel(C5DgradRider r) { c5_dgrad_rider_body(r, blockIdx.x); }
 }  // namespace
 
 #define GRID1(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256), 0, (hipStream_t)stream
@@ -1083,7 +1084,27 @@ thread_local bool g_sn_defer = false, g_sn_pending_valid = false;
 thread_local SnBatch g_sn_pending;
 int gcssl_sn_defer_finish(int on) { g_sn_defer = on != 0; return GCSSL_OK; }
 __attribute__((visibility("hidden"))) int gcssl_take_pending_sn(SnBatch* out) { if (!g_sn_pending_valid) return 0; *out = g_sn_pending; g_sn_pending_valid = false; return 1; }
+thread_local bool g_c5_pending_valid = false;
+thread_local C5DgradRider g_c5_pending;
+__attribute__((visibility("hidden"))) int gcssl_take_pending_c5(C5DgradRider* out) { if (!g_c5_pending_valid) return 0; *out = g_c5_pending; g_c5_pending_valid = false; return 1; }
+// gcssl_conv4x4s1_c1_dgrad's constant-dout form, NOT launched: the next gcssl_prep_conv_weights launch of this thread carries it as
+// an extra grid row (it reads the raw head weight w [1][512][4][4], so it does not depend on that launch's re-pack); dx: fp32.
+// The caller issues it where the re-pack of the same weights follows and nothing reads dx in between.
+int gcssl_conv4x4s1_c1_dgrad_defer(float g0, float g1, float g2, float g3, int group_n, const float* w, float* dx, int lddx,
+                                   int N, int Hi, int Wi, int C) {
+    if (!w || !dx) return GCSSL_ENULL;
+    if (N <= 0 || Hi < 2 || Wi < 2 || C != 512 || lddx < C || lddx % 4 || group_n <= 0 || (((uintptr_t)dx) & 15)) return GCSSL_EBADSHAPE;
+    C5DgradRider r{};
+    r.g[0] = g0; r.g[1] = g1; r.g[2] = g2; r.g[3] = g3; r.group_n = group_n; r.w = w; r.dx = dx; r.lddx = lddx;
+    r.N = N; r.Hi = Hi; r.Wi = Wi; r.per = 8; r.nblk = (N + r.per - 1) / r.per;
+    g_c5_pending = r; g_c5_pending_valid = true;
+    return GCSSL_OK;
+}
 int gcssl_sn_flush_finish(void* stream) {
+    if (g_c5_pending_valid) {
+        g_c5_pending_valid = false;
+        hipLaunchKernelGGL(c5_dgrad_rider_kernel, dim3(g_c5_pending.nblk), dim3(256), 0, (hipStream_t)stream, g_c5_pending);
+    }
     if (!g_sn_pending_valid) return GCSSL_OK;
     g_sn_pending_valid = false;
     hipLaunchKernelGGL(sn_finish_kernel, dim3(g_sn_pending.nl), dim3(256), 0, (hipStream_t)stream, g_sn_pending);

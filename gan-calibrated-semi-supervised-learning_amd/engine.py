@@ -265,6 +265,9 @@ class StepEngine:
         self.probe = None          # {label: {"events": [(start, stop)...], "flops": f}} when profiling is enabled
         self._wgrad_batch_on = os.environ.get("GCSSL_WGRAD_BATCH", "1") != "0"
         self._sn_defer = self.spectral_norm and os.environ.get("GCSSL_SN_DEFER", "1") != "0"     # (A/B knob)
+        # (A/B knob, default OFF: measured 135.2 / 135.4k with it against 135.8 / 136.3k without -- the rider builds its tap table from
+        #  the RAW weight with strided scalar loads and makes the re-pack launch longer than the launch it saves)
+        self._c5_defer = os.environ.get("GCSSL_C5_DEFER", "0") != "0"
         self._wgrad_d = self._wgrad_gu = None
         self.step_log = self.delta_log = None                      # enable_step_log(): per-critic-step scalars / the generator step's delta, kept on the device
         self._k_cur = 0
@@ -898,6 +901,14 @@ class StepEngine:
         B, S, N3 = self.B, self.S, 3 * self.B
         I = slice(2 * B, 3 * B)
         isig = self.sn.isig
+        hw = self.h5 * self.h5
+        ls = self.loss_scale_d
+        seeds = (-ls / (B * hw), ls / (B * hw), 0.0)
+        # the head conv's data gradient for the constant seeds depends on nothing but the head's weight: where this call re-packs the
+        # weights it rides on that launch (gcssl_conv4x4s1_c1_dgrad_defer), else it is launched behind the forward as before
+        c5_rides = (not sn_done) and self._d_dirty and self._c5_defer and self.d_da4_3.dtype == torch.float32
+        if c5_rides:
+            ops.c5_dgrad_defer(self.d_da4_3, self.D.views["model.11.weight"], consts=(seeds[0], seeds[1], seeds[2], 1.0), group_n=B)
         if not sn_done:
             self._sn_and_prep()
         if not self.D.grads_zero:                                 # optimizer.zero_grad() (:305) unless the last update did it
@@ -907,10 +918,8 @@ class StepEngine:
         self._d_forward(N3, lambda l: isig[l], B, means=self.means, groups=3)      # (+ the three batch means, :327)
         # ---- GP first-order chain on the interpolated group (cgan/losses.py:213-220); its seed (1 per score) and the seeds of
         # the batched backward of the three forwards, -1/(B hw), +1/(B hw), 0 (:327-330), leave the head conv in one launch
-        hw = self.h5 * self.h5
-        ls = self.loss_scale_d
-        seeds = (-ls / (B * hw), ls / (B * hw), 0.0)
-        ops.c5_dgrad(self.d_da4_3, self.d_w5p, consts=(seeds[0], seeds[1], seeds[2], 1.0), group_n=B)
+        if not c5_rides:
+            ops.c5_dgrad(self.d_da4_3, self.d_w5p, consts=(seeds[0], seeds[1], seeds[2], 1.0), group_n=B)
         ns, st = 1, 0                                             # K-split slabs of the conv that produced gb_a[l]
         gp_c1_done = False
         for l in (3, 2, 1):

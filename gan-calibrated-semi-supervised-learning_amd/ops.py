@@ -290,6 +290,16 @@ def c5_dgrad(dx, wp, dout=None, consts=(0.0, 0.0, 0.0), group_n=1):
     call("gcssl_conv4x4s1_c1_dgrad", code(dx), dout, *_c4(consts), group_n, wp, dx, _ld(dx), N, Hi, Wi, wp.shape[1])
 
 
+def c5_dgrad_defer(dx, w_raw, consts=(0.0, 0.0, 0.0), group_n=1):
+    """c5_dgrad's constant form, recorded instead of launched: the NEXT PrepBatch.run() of this thread carries it (one launch
+    less).  w_raw: the head conv's own weight [1][C][4][4] (fp32); dx fp32.  The caller re-packs right after and reads dx later."""
+    N, Hi, Wi, _ = dx.shape
+    assert dx.dtype == torch.float32
+    r = _lib.call_nostream("gcssl_conv4x4s1_c1_dgrad_defer", *_c4(consts), group_n, w_raw, dx, _ld(dx), N, Hi, Wi, w_raw.shape[1])
+    if r != 0:
+        raise RuntimeError(f"gcssl_conv4x4s1_c1_dgrad_defer -> {_lib.ERRORS.get(r, r)}")
+
+
 def c5_wgrad(x, dw, C, dout=None, consts=(0.0, 0.0, 0.0), group_n=1):
     """dw: fp32 [C][16] (PyTorch layout of the [1][C][4][4] weight), accumulated atomically."""
     N, Hi, Wi, _ = x.shape

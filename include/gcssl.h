@@ -270,6 +270,11 @@ int gcssl_sn_power_iter(int nl, const float* const* w, float* const* u, float* c
  * gcssl_sn_flush_finish launches a pending step on its own (a caller that deferred and does not re-pack after all). */
 int gcssl_sn_defer_finish(int on);
 int gcssl_sn_flush_finish(void* stream);
+/* The same for gcssl_conv4x4s1_c1_dgrad's constant-dout form (the only one the step engine launches): recorded, not launched; the next
+ * gcssl_prep_conv_weights launch of this thread carries it (it reads the RAW head weight w [1][512][4][4], not the packed copy that
+ * launch writes; dx fp32, C = 512).  gcssl_sn_flush_finish launches a pending one on its own. */
+int gcssl_conv4x4s1_c1_dgrad_defer(float g0, float g1, float g2, float g3, int group_n, const float* w, float* dx, int lddx,
+                                   int N, int Hi, int Wi, int C);
 
 /* ---- fused generator up-path layer (cgan/models.py:72-74,112-118) ---------------------------------------------------------
  * ConvTranspose2d(K -> 64, k4 s2 p1, bias=False) + InstanceNorm2d + ReLU (+ the sums AdaptiveAvgPool2d(1) needs) as ONE

@@ -765,6 +765,35 @@ def test_spectral_norm_finish_deferred_into_repack(ops):
                 assert torch.equal(a, b) and bool(torch.isfinite(a.float()).all())
 
 
+@pytest.mark.parametrize("N,H", [(1024, 2), (96, 4), (13, 2)])
+def test_head_conv_dgrad_rides_on_the_repack(ops, N, H):
+    """gcssl_conv4x4s1_c1_dgrad_defer: the head conv's constant-seed data gradient carried by the next weight re-pack launch (it reads the
+    raw head weight) == the stand-alone launch on the packed weight, bit for bit; the re-pack's own outputs are unchanged; a
+    deferred gradient that no re-pack follows can be flushed."""
+    lib = load_pkg("_lib")
+    C = 512
+    w5 = rnd(1, C, 4, 4, seed=31, scale=0.05).cuda()
+    wp = torch.empty(16, C, device="cuda")
+    ops.prep_c5_weight(w5, wp)
+    consts, group_n = (-0.25, 0.25, 0.0, 1.0), (N + 3) // 4
+    ref = torch.full((N, H, H, C), float("nan"), device="cuda")
+    ops.c5_dgrad(ref, wp, consts=consts, group_n=group_n)
+    w = rnd(128, 64, 4, 4, seed=2, scale=0.05).cuda()
+    for how in ("prep", "flush"):
+        dx = torch.full((N, H, H, C), float("nan"), device="cuda")
+        wf = torch.full((128, 16, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+        wt = torch.full((64, 16, 128), float("nan"), device="cuda", dtype=torch.bfloat16)
+        wp2 = torch.full((16, C), float("nan"), device="cuda")
+        prep = ops.PrepBatch([(w, wf, wt, 128, 64, 64)], lib.dtype_code(torch.bfloat16), c5=(w5, wp2))
+        ops.c5_dgrad_defer(dx, w5, consts=consts, group_n=group_n)
+        if how == "flush":
+            lib.call("gcssl_sn_flush_finish")
+        prep.run()
+        torch.cuda.synchronize()
+        assert torch.equal(dx, ref)
+        assert torch.equal(wp2, wp) and bool(torch.isfinite(wf.float()).all()) and bool(torch.isfinite(wt.float()).all())
+
+
 def test_launch_folds(ops):
     """The bookkeeping that rides on neighbouring launches (round 3): group means from the head conv, four group constants
     of the head's weight gradient, replicated input packing, <x, da> inside act_bwd, the critic head's re-pack inside the
