@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256) void c5_wgrad_const_kernel(const T* __restrict
 template <typename T>
 __global__ void pack_fake_interp_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
                                         const float* __restrict__ refined, const float* __restrict__ alpha, uint64_t seed,
-                                        const double* counter, T* __restrict__ out_fake, T* __restrict__ out_interp, int B, int HW) {
+                                        const double* counter, T* __restrict__ out_fake, T* __restrict__ out_interp, int B, int HW,
+                                        T* __restrict__ out_real = nullptr) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * HW) return;
     const int n = idx / HW, p = idx % HW;
@@ -360,6 +361,15 @@ __global__ void pack_fake_interp_kernel(const float* __restrict__ pred, const fl
     T* of = out_fake + idx * 8; T* oi = out_interp + idx * 8;
 #pragma unroll
     for (int c = 0; c < 8; ++c) { Elem<T>::st(of + c, f[c]); Elem<T>::st(oi + c, v[c]); }
+    if (out_real) {                                          // the real group (pred, gt) of the same step: pack_pair_kernel's output
+        T* orl = out_real + idx * 8;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            Elem<T>::st(orl + c, f[c]);
+            Elem<T>::st(orl + 3 + c, gt[((size_t)n * 3 + c) * HW + p]);
+        }
+        Elem<T>::st(orl + 6, 0.f); Elem<T>::st(orl + 7, 0.f);
+    }
 }
 
 // =========================================================================================
@@ -1000,6 +1010,19 @@ int gcssl_pack_fake_interp(int dtype, const float* pred, const float* gt, const 
     if (B <= 0 || S <= 0) return GCSSL_EBADSHAPE;
     const size_t n = (size_t)B * S * S;
     GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(pack_fake_interp_kernel<T>, GRID1(n), pred, gt, refined, alpha, (uint64_t)seed, counter, (T*)out_fake, (T*)out_interp, B, S * S));
+    return gcssl_launch_status();
+}
+
+// gcssl_pack_fake_interp + gcssl_pack_pair(pred, gt) of the same critic step in one launch (out_real nullable: then exactly
+// gcssl_pack_fake_interp)
+int gcssl_pack_groups(int dtype, const float* pred, const float* gt, const float* refined, const float* alpha,
+                      unsigned long long seed, const double* counter, void* out_real, void* out_fake, void* out_interp, int B, int S,
+                      void* stream) {
+    if (!pred || !gt || !refined || !out_fake || !out_interp) return GCSSL_ENULL;
+    if (bad_dtype(dtype)) return GCSSL_EBADDTYPE;
+    if (B <= 0 || S <= 0) return GCSSL_EBADSHAPE;
+    const size_t n = (size_t)B * S * S;
+    GCSSL_DISPATCH(dtype, hipLaunchKernelGGL(pack_fake_interp_kernel<T>, GRID1(n), pred, gt, refined, alpha, (uint64_t)seed, counter, (T*)out_fake, (T*)out_interp, B, S * S, (T*)out_real));
     return gcssl_launch_status();
 }
 

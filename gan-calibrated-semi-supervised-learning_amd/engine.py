@@ -875,9 +875,10 @@ class StepEngine:
         B = self.B
         I = slice(2 * B, 3 * B)
         self._k_cur = k                                            # (host-side: which critic step the next d_main belongs to)
+        real_out = None
         if self._gall_valid:                                       # this call was part of the iteration's batched forward
-            if k == 0:                                             # (pred and gt are the iteration's: the real group is packed once)
-                ops.pack_pair(pred, gt, self.x0[:B])
+            if k == 0:                                             # (pred and gt are the iteration's: the real group is packed once,
+                real_out = self.x0[:B]                             #  in the launch that packs the fake and interpolated groups)
             delta_det = self.gfa.delta[k * B:(k + 1) * B]
         else:
             ops.pack_pair(pred, gt, self.x0[:B])                   # real group; channels 0-2 = pred are G's input too
@@ -887,7 +888,7 @@ class StepEngine:
         refined = refine_fn(delta_det, k)                          # :313-315
         # fake (pred, refined) and interpolated groups in one pass; alpha given (parity runs) or drawn in the kernel
         ops.pack_fake_interp(pred, gt, refined, alpha, self.x0[B:2 * B], self.x0[I], seed=self.seed * 131 + 7 + 16 * k,
-                             counter=self.G.state)
+                             counter=self.G.state, out_real=real_out)
 
     def _sn_and_prep(self) -> None:
         # real, fake, interp forwards each iterate once: three chained power iterations (slots 0..2), whose closing launch also

@@ -402,10 +402,14 @@ class SnState:
 
 
 # ---- GP, optimiser, heads
-def pack_fake_interp(pred, gt, refined, alpha, out_fake, out_interp, seed=0, counter=None):
-    """alpha None: drawn on the device from (seed, counter[0], sample)."""
+def pack_fake_interp(pred, gt, refined, alpha, out_fake, out_interp, seed=0, counter=None, out_real=None):
+    """alpha None: drawn on the device from (seed, counter[0], sample).  out_real: also pack the real group (pred, gt) -- pack_pair
+    in the same launch."""
     B, _, S, _ = pred.shape
-    call("gcssl_pack_fake_interp", code(out_fake), pred, gt, refined, alpha, int(seed), counter, out_fake, out_interp, B, S)
+    if out_real is None:
+        call("gcssl_pack_fake_interp", code(out_fake), pred, gt, refined, alpha, int(seed), counter, out_fake, out_interp, B, S)
+    else:
+        call("gcssl_pack_groups", code(out_fake), pred, gt, refined, alpha, int(seed), counter, out_real, out_fake, out_interp, B, S)
 
 
 def gp_norm(g, B, lambda_gp, nrm, coef, gp_sum, scaled=None, sat=None):

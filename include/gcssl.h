@@ -82,6 +82,10 @@ int gcssl_pack_interp(int dtype, const float* pred, const float* gt, const float
 int gcssl_pack_fake_interp(int dtype, const float* pred, const float* gt, const float* refined, const float* alpha,
                            unsigned long long seed, const double* counter, void* out_fake, void* out_interp, int B, int S,
                            void* stream);
+/* gcssl_pack_fake_interp + gcssl_pack_pair(pred, gt -> out_real) of the same critic step as ONE launch; out_real nullable. */
+int gcssl_pack_groups(int dtype, const float* pred, const float* gt, const float* refined, const float* alpha,
+                      unsigned long long seed, const double* counter, void* out_real, void* out_fake, void* out_interp, int B, int S,
+                      void* stream);
 /* NHWC8 fp32 input-gradient -> the two NCHW (B,3,S,S) gradients torch.autograd.grad returns (cgan/losses.py:213). */
 int gcssl_unpack_grad(const float* g, float* ga, float* gb, int B, int S, void* stream);
 

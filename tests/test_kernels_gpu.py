@@ -794,6 +794,21 @@ def test_head_conv_dgrad_rides_on_the_repack(ops, N, H):
         assert torch.equal(wp2, wp) and bool(torch.isfinite(wf.float()).all()) and bool(torch.isfinite(wt.float()).all())
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_pack_groups_one_launch(ops, dt):
+    """gcssl_pack_groups: the real group (pack_pair) written by the launch that packs the fake and interpolated groups."""
+    B, S = 6, 32
+    pred, gt, refined = rnd(B, 3, S, S, seed=1).cuda(), rnd(B, 3, S, S, seed=2).cuda(), rnd(B, 3, S, S, seed=3).cuda()
+    alpha = torch.rand(B, device="cuda")
+    r0, f0, i0 = (torch.full((B, S, S, 8), float("nan"), device="cuda", dtype=dt) for _ in range(3))
+    ops.pack_pair(pred, gt, r0)
+    ops.pack_fake_interp(pred, gt, refined, alpha, f0, i0)
+    r1, f1, i1 = (torch.full((B, S, S, 8), float("nan"), device="cuda", dtype=dt) for _ in range(3))
+    ops.pack_fake_interp(pred, gt, refined, alpha, f1, i1, out_real=r1)
+    torch.cuda.synchronize()
+    assert torch.equal(r0, r1) and torch.equal(f0, f1) and torch.equal(i0, i1)
+
+
 def test_launch_folds(ops):
     """The bookkeeping that rides on neighbouring launches (round 3): group means from the head conv, four group constants
     of the head's weight gradient, replicated input packing, <x, da> inside act_bwd, the critic head's re-pack inside the
