@@ -185,7 +185,9 @@ class Runner:
         if not no_graph:
             # a failed capture is an ERROR (the caller exits non-zero): an eager number under a line that says "hipGraph replay"
             # by default would be a silent downgrade.  --no-graph asks for the eager form explicitly.
-            self.graphed = engine.GraphedIteration(self.eng, *self.call)
+            # batch_g_critic: iteration i's value-only critic forward as a fourth group of iteration i+1's first critic forward
+            # (GraphedIteration docstring; every replay still runs exactly one such forward -- the previous iteration's)
+            self.graphed = engine.GraphedIteration(self.eng, *self.call, batch_g_critic=True)
             self.graphed.replay(); torch.cuda.synchronize()
         self.step = self.graphed.replay if self.graphed is not None else (lambda: self.eng.run_iteration(*self.call))
 
@@ -211,6 +213,8 @@ class Runner:
     def finite(self):
         """sanity of the state the timed replays left behind: finite weights, finite last critic loss"""
         eng = self.eng
+        if self.graphed is not None:
+            self.graphed.finish()                                  # (the value-only forward the last replay still owes)
         m = eng.means.tolist()
         d_loss_last = -(m[0] - m[1]) + eng.lambda_gp * float(eng.gp_sum)
         ok = bool(torch.isfinite(eng.D.p).all()) and bool(torch.isfinite(eng.G.p).all()) and math.isfinite(d_loss_last)
@@ -228,6 +232,8 @@ class Runner:
         what it is inside the replayed graph (rocprofv3's per-kernel durations of the graph replay agree with this one).
         The table's `t` / the aggregates use the chained time; the lone-launch time rides along as *_single."""
         eng = self.eng
+        if self.graphed is not None:
+            self.graphed.finish()
         eng.enable_probe(True, repeats=PROBE_REPEATS)
         for _ in range(probe_steps):
             eng.run_iteration(*self.call)

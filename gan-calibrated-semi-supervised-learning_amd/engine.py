@@ -214,10 +214,10 @@ class StepEngine:
         if self.spectral_norm:
             self.u = [sd_d[f"model.{i}.weight_u"].to(dev, torch.float32).clone() for i in D_IDX]
             self.v = [sd_d[f"model.{i}.weight_v"].to(dev, torch.float32).clone() for i in D_IDX]
-            self.sn = ops.SnState([self.D.views[self.d_wkey(i)] for i in D_IDX], self.u, self.v, 3, dev)
+            self.sn = ops.SnState([self.D.views[self.d_wkey(i)] for i in D_IDX], self.u, self.v, 4, dev)   # slots 0-2: a critic step's three forwards; 3: the value-only forward
         else:
             self.u, self.v = [], []
-            self.sn = _NoSpectralNorm(len(D_IDX), 3, dev)
+            self.sn = _NoSpectralNorm(len(D_IDX), 4, dev)
         self._zcap, self._zkeep, self._splits = {}, [], {}
         self.grad_slabs = os.environ.get("GCSSL_GRAD_SLABS", "1") != "0"
         # one batched generator forward per iteration (g_forward_all); GCSSL_BATCH_G=0: one forward per call, for A/B runs
@@ -464,6 +464,8 @@ class StepEngine:
         # split-K slabs to reduce.
         N4 = 4 * B
         x4 = act(N4, S, 8)
+        x4.zero_()
+        self.x4 = x4                                               # (all four groups: the critic forward with the value-only group batched in)
         self.x0, self.gt_x = x4[:N3], x4[N3:]
         sizes = [S // 2, S // 4, S // 8, S // 16]
         self.d_a4 = [act(N4, s, c) for s, (_, c) in zip(sizes, D_CH)]
@@ -473,10 +475,13 @@ class StepEngine:
         # (each holds the K-split slabs of its producing conv when that conv splits: _zbuf)
         self.d_z = [None] + [self._zbuf("fwd", (N3, B), S >> l, D_CH[l][0], D_CH[l][1], N3) for l in (1, 2, 3)]
         self._d_zsrc = list(self.d_z)          # what the norm backward kernels read per layer: d_z (fp32) or, after a fused forward, d_a
-        self.d_mean = [None] + [torch.empty(N3, c, **f32) for _, c in D_CH[1:]]
-        self.d_rstd = [None] + [torch.empty(N3, c, **f32) for _, c in D_CH[1:]]
+        self.d_mean4 = [None] + [torch.empty(N4, c, **f32) for _, c in D_CH[1:]]
+        self.d_rstd4 = [None] + [torch.empty(N4, c, **f32) for _, c in D_CH[1:]]
+        self.d_mean = [None] + [t[:N3] for t in self.d_mean4[1:]]
+        self.d_rstd = [None] + [t[:N3] for t in self.d_rstd4[1:]]
         self.h5 = sizes[3] - 1
-        self.d_out = torch.empty(N3, self.h5, self.h5, **f32)
+        self.d_out4 = torch.empty(N4, self.h5, self.h5, **f32)
+        self.d_out = self.d_out4[:N3]
         # GP chain (B samples)
         # gradient tensors that feed a norm/activation backward kernel are fp32 (norm.hip header); those that feed an
         # MFMA (gb_zs, gt_a, dzs) are in the compute dtype
@@ -505,15 +510,19 @@ class StepEngine:
         # cdot entries): hundreds of workgroups adding to one 256-byte bias vector serialise (70 us on a 17-us pass), so
         # each adds to replica (workgroup % NREP) and one gcssl_sum_replicas launch folds them.  One fill zeroes it all.
         self.NREP, self.REP_STRIDE = 32, 1024
-        self.zero_blk = torch.zeros(32 + self.NREP * self.REP_STRIDE, **f32)
+        # (the three group means of a critic step's forward are the LAST three floats of the block and the value-only forward's mean
+        #  the float behind it: one head-conv launch over four groups adds to all four -- StepEngine.d_main(with_g=True) -- and the
+        #  per-step fill, which ends in front of that float, leaves it alone)
+        self._zero_all = torch.zeros(32 + self.NREP * self.REP_STRIDE + 4, **f32)
+        self.zero_blk = self._zero_all[:-1]
         self.scal = self.zero_blk[:32]
-        self.rep = self.zero_blk[32:].view(self.NREP, self.REP_STRIDE)
+        self.rep = self.zero_blk[32:32 + self.NREP * self.REP_STRIDE].view(self.NREP, self.REP_STRIDE)
         self.rep_bias_off = [0, 64, 192, 448]                      # c1..c4 bias (64, 128, 256, 512 floats); cdot at 960
         self.cdot = self.scal[0:12].view(4, 3)
         self.gp_sum = self.scal[12:13]
         self.eiou_acc = torch.zeros(1, **f32)      # (its own tensor: the generator step's first half may run between two critic steps, whose d_main clears zero_blk)
-        self.means = self.scal[14:17]
-        self.wgan_mean = self.scal[17:18]
+        self.means = self._zero_all[-4:-1]
+        self.wgan_mean = self._zero_all[-1:]
         # wgrad slabs: per D layer [chain splits + forward splits]
         self.d_slab, self.d_ns = [], []
         for l, (cin, cout) in enumerate(D_CH):
@@ -646,18 +655,23 @@ class StepEngine:
         """conv stack over the first n rows of the 3B buffers (input: x, default the first n rows of x0).  means (zeroed by
         the caller): += the mean score of each of `groups` equal sample groups, from the head conv's own launch."""
         x = self.x0[:n] if x is None else x
+        wide = n > 3 * self.B                                      # four groups (d_main(with_g=True)): the 4B-sample buffers, fused layers only
+        d_a = self.d_a4 if wide else self.d_a
+        d_mean, d_rstd, d_out = (self.d_mean4, self.d_rstd4, self.d_out4) if wide else (self.d_mean, self.d_rstd, self.d_out)
         for l, ((cin, cout), i) in enumerate(zip(D_CH, D_IDX)):
             bias = self.D.views[f"model.{i}.bias"]
             fl = conv_flops(n, self.S >> l, cin, cout)
             if l == 0:
-                self._conv(f"D.c1.fwd[n={n}]", fl, ops.conv_fwd, x, self.d_wf[0], self.d_a[0][:n], 8, cout, bias=bias,
+                self._conv(f"D.c1.fwd[n={n}]", fl, ops.conv_fwd, x, self.d_wf[0], d_a[0][:n], 8, cout, bias=bias,
                            gscale=gscale_of_layer(0), group_n=group_n, act=LRELU)
             elif self._fin(n, self.S >> l, cin, cout):
                 # conv + InstanceNorm + LeakyReLU in one launch; the backward reads the activation instead of z
-                self._conv(f"D.c{l + 1}.fwd[n={n}]", fl, ops.conv_in_act_fwd, self.d_a[l - 1][:n], self.d_wf[l],
-                           self.d_a[l][:n], self.d_mean[l][:n], self.d_rstd[l][:n], cin, cout, bias=bias,
+                self._conv(f"D.c{l + 1}.fwd[n={n}]", fl, ops.conv_in_act_fwd, d_a[l - 1][:n], self.d_wf[l],
+                           d_a[l][:n], d_mean[l][:n], d_rstd[l][:n], cin, cout, bias=bias,
                            gscale=gscale_of_layer(l), group_n=group_n)
                 self._d_zsrc[l] = self.d_a[l]
+            elif wide:
+                raise RuntimeError("the four-group critic forward needs the fused conv + InstanceNorm launches (gbatch_ok)")
             elif self._fin_x3(n, self.S >> l, cin, cout):
                 # split-precision modes: the same fusion on fp32 tensors; z is still stored (the fp32 backward kernels read it)
                 self._conv(f"D.c{l + 1}.fwd[n={n}]", fl, ops.conv_in_act_x3_fwd, self.d_a[l - 1][:n], self.d_wf[l], self.d_z[l][:n],
@@ -671,7 +685,12 @@ class StepEngine:
                 ops.in_act_fwd(self.d_z[l][:n], self.d_a[l][:n], self.d_mean[l][:n], self.d_rstd[l][:n], cout, LRELU,
                                nslab=ns, slab_stride=st)
                 self._d_zsrc[l] = self.d_z[l]
-        ops.c5_fwd(self.d_a[3][:n], self.d_w5p, self.d_out[:n], group_mean=means, groups=groups)
+        ops.c5_fwd(d_a[3][:n], self.d_w5p, d_out[:n], group_mean=means, groups=groups)
+
+    def gbatch_ok(self) -> bool:
+        """can the generator step's value-only critic forward be a fourth group of the next critic forward (d_main(with_g=True))?
+        Every normalised layer must take the fused conv + InstanceNorm launch at 4B samples (the 16-bit modes at the bench shapes)."""
+        return self.spectral_norm and all(self._fin(4 * self.B, self.S >> l, *D_CH[l]) for l in (1, 2, 3))
 
     def critic_scores(self, pred: torch.Tensor, other: torch.Tensor, train: bool = True) -> torch.Tensor:
         """Discriminator.forward(pred, other) (cgan/models.py:255-258) for one (B,3,S,S) pair -> (B,1,h,w).
@@ -890,16 +909,25 @@ class StepEngine:
         ops.pack_fake_interp(pred, gt, refined, alpha, self.x0[B:2 * B], self.x0[I], seed=self.seed * 131 + 7 + 16 * k,
                              counter=self.G.state, out_real=real_out)
 
-    def _sn_and_prep(self) -> None:
+    def _sn_and_prep(self, zero_wgan: bool = False) -> None:
         # real, fake, interp forwards each iterate once: three chained power iterations (slots 0..2), whose closing launch also
         # clears the per-step scalars + striped-sum replicas (zero_blk) -- no fill launch of its own
         # (the chain's closing step rides on the re-pack launch that follows it when there is one: ops.SpectralNorm.iterate)
-        self.sn.iterate(0, 3, zero=self.zero_blk, defer_finish=self._sn_defer and self._d_dirty)
+        # zero_wgan: the fill also covers wgan_mean (the float behind the block): a four-group forward follows
+        self.sn.iterate(0, 3, zero=self._zero_all if zero_wgan else self.zero_blk, defer_finish=self._sn_defer and self._d_dirty)
         self._prep_d()
 
-    def d_main(self, sn_done: bool = False) -> None:
-        """The critic side: spectral-norm iterations, the 3B-sample forward, gradient penalty, all gradients."""
+    def d_main(self, sn_done: bool = False, with_g: bool = False) -> None:
+        """The critic side: spectral-norm iterations, the 3B-sample forward, gradient penalty, all gradients.
+        with_g (GraphedIteration, batch_g_critic): the PREVIOUS iteration's value-only forward (g_critic: train-mode D on (pred,
+        refined_G), cgan/cgan_train_enhanced.py:361-362) rides on this step's forward as a fourth group -- x4[3B:] holds its packed
+        input.  The critic's weights have not changed since that iteration's last update, so its power iteration (slot 3) and this
+        step's three (slots 0-2) are consecutive iterations on the same W, exactly the reference's sequence; its mean lands in
+        wgan_mean, next to the three group means."""
         B, S, N3 = self.B, self.S, 3 * self.B
+        assert not (with_g and sn_done)
+        if with_g:
+            self.sn.iterate(3, True)                              # the value-only forward's power iteration comes first
         I = slice(2 * B, 3 * B)
         isig = self.sn.isig
         hw = self.h5 * self.h5
@@ -911,12 +939,15 @@ class StepEngine:
         if c5_rides:
             ops.c5_dgrad_defer(self.d_da4_3, self.D.views["model.11.weight"], consts=(seeds[0], seeds[1], seeds[2], 1.0), group_n=B)
         if not sn_done:
-            self._sn_and_prep()
+            self._sn_and_prep(zero_wgan=with_g)
         if not self.D.grads_zero:                                 # optimizer.zero_grad() (:305) unless the last update did it
             self.D.g.zero_()
         self.D.grads_zero = False
         self._join_side()                                         # sigma, u/v history, packed weights ready; zero_blk cleared
-        self._d_forward(N3, lambda l: isig[l], B, means=self.means, groups=3)      # (+ the three batch means, :327)
+        if with_g:
+            self._d_forward(4 * B, lambda l: isig[l], B, x=self.x4, means=self._zero_all[-4:], groups=4)
+        else:
+            self._d_forward(N3, lambda l: isig[l, :3], B, means=self.means, groups=3)      # (+ the three batch means, :327)
         # ---- GP first-order chain on the interpolated group (cgan/losses.py:213-220); its seed (1 per score) and the seeds of
         # the batched backward of the three forwards, -1/(B hw), +1/(B hw), 0 (:327-330), leave the head conv in one launch
         if not c5_rides:
@@ -1315,9 +1346,15 @@ class GraphedIteration:
     batch (the prologue graph), which is correct and costs one generator forward.  GCSSL_CHECK_STAGING=1 verifies (host sync)
     that a batch's `pred` is what the previous replay was given as `next_pred`."""
 
-    def __init__(self, eng: "StepEngine", pred, gt, delta_true, pred_box, refine_fn):
+    def __init__(self, eng: "StepEngine", pred, gt, delta_true, pred_box, refine_fn, batch_g_critic: bool = False):
+        """batch_g_critic (two-stream form only): iteration i's value-only critic forward (cgan/cgan_train_enhanced.py:361-362) runs
+        as a fourth group of iteration i+1's first critic forward (StepEngine.d_main(with_g=True)) instead of as a segment of small
+        launches at the end of iteration i -- same arithmetic, same order of power iterations; `loss_wgan` of iteration i (wgan_mean)
+        is then available after replay i+1, and after the LAST replay `finish()` runs the one forward that is still owed."""
         self.eng = eng
         self.inputs = (pred, gt, delta_true, pred_box)
+        self.batch_g = False
+        self._g_owed = False
         self.pred_next = pred.clone()                              # what the pipelined forms' trailing generator forward reads
         self._staged = False                                       # did the previous replay get its successor's input?
         self._primed, self.pipelined = False, False
@@ -1396,7 +1433,20 @@ class GraphedIteration:
                                 eng.d_pre(pred, gt, refine_fn, k, None, None)
                             if k < c - 1:
                                 eng.d_main(sn_done=sn_done and k == 0); eng.d_update()
-                    if self.head_split and c >= 2:
+                    self.batch_g = bool(batch_g_critic) and c >= 2 and eng.gbatch_ok() and os.environ.get("GCSSL_GCRITIC_BATCH", "1") != "0"
+                    if self.batch_g:
+                        def seg_a_g():
+                            eng._d_dirty = True
+                            for k in range(c):
+                                eng.d_pre(pred, gt, refine_fn, k, None, None)
+                                if k < c - 1:
+                                    eng.d_main(with_g=(k == 0)); eng.d_update()
+                        self.c_a_g = capture(seg_a_g)             # ... with the previous iteration's value-only forward as a fourth group
+                        self.c_a = capture(seg_a)                  # (first replay / after finish(): nothing owed)
+                        # the last critic step, then only the PACK of this iteration's value-only forward: the next replay runs it
+                        self.c_b = capture(lambda: (eng.d_main(), eng.d_update(), ops.pack_pair(pred, eng._refined_g, eng.x4[3 * eng.B:])))
+                        self.head_split = False
+                    elif self.head_split and c >= 2:
                         def head_a():
                             eng._d_dirty = True
                             eng.d_pre(pred, gt, refine_fn, 0, None, None)
@@ -1542,6 +1592,13 @@ class GraphedIteration:
         self._staged = next_pred is not None
         self._primed = ok
 
+    def finish(self) -> None:
+        """batch_g_critic: run the value-only critic forward the last replay left owed (no-op otherwise).  Call it after the last
+        replay of a run, and before anything else touches the engine (an eager iteration, a checkpoint of u / v, reading wgan_mean)."""
+        if self._g_owed:
+            self.eng.g_critic(self.inputs[0])
+            self._g_owed = False
+
     def replay(self, batch=None, next_pred=None):
         """One iteration.  batch: optional (pred, gt, delta_true, pred_box) for this iteration; next_pred: the NEXT iteration's
         generator input, for the pipelined forms (class docstring)."""
@@ -1560,7 +1617,11 @@ class GraphedIteration:
             with torch.cuda.stream(side):
                 self.g_a.replay()
                 ev_ga = torch.cuda.Event(); ev_ga.record(side)
-            self.c_a.replay()
+            if self.batch_g and self._g_owed:
+                self.c_a_g.replay()                               # (with the previous iteration's value-only forward)
+            else:
+                self.c_a.replay()
+            self._g_owed = self.batch_g
             if self.head_split:
                 self.c_b0.replay()                                # the last critic step's chain (Gb starts behind it)
             ev_ca = torch.cuda.Event(); ev_ca.record(main)

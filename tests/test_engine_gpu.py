@@ -549,6 +549,53 @@ def test_graph_replay_with_recrop_stage_in_the_loop(synth):
     assert float(st_g.out[c].abs().max()) > 0.1                              # (not an all-grey / all-zero patch)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_graph_replay_with_batched_value_forward(synth, dtype):
+    """GraphedIteration(batch_g_critic=True): iteration i's value-only critic forward runs as a fourth group of iteration i+1's first
+    critic forward, finish() runs the one the last replay owes.  With lr = 0 (weights fixed; alpha / dropout keyed by the device-side
+    step counts) every replay is comparable with an eager iteration: the spectral-norm vectors after the same number of power
+    iterations, the critic's scalars of the last step, and -- one replay late -- the generator's WGAN term."""
+    engine = load_pkg("engine")
+    B, S, c = 256, 32, 2
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench as bench_mod
+    g, d = bench_mod.initial_state(synth, "unet")
+    kw = dict(batch=B, size=S, n_critic=c, dtype=dtype, device="cuda", seed=5, lr=0.0)
+    eng_e, eng_g = engine.StepEngine(g, d, **kw), engine.StepEngine(g, d, **kw)
+    data, _ = bench_mod.synthetic_inputs(synth, 5, B, S, c, torch.device("cuda"), "unet")
+    refine = lambda delta, k: data["refined"][k]
+    call = (data["pred"], data["gt"], data["delta_true"], data["pred_box"], refine)
+    assert eng_g.gbatch_ok()
+    gi = engine.GraphedIteration(eng_g, *call, batch_g_critic=True)
+    assert gi.batch_g
+    wg_e, wg_g = [], []
+    for it in range(4):
+        eng_e.run_iteration(*call)
+        wg_e.append(float(eng_e.wgan_mean))
+        gi.replay()
+        torch.cuda.synchronize()
+        wg_g.append(float(eng_g.wgan_mean))                   # the PREVIOUS iteration's (0 after the first replay: nothing owed yet)
+        m_e, m_g = eng_e.means.tolist(), eng_g.means.tolist()
+        tol = 2e-2 if dtype == "bf16" else 5e-3              # (float-atomic order through 16-bit roundings, as the other graph tests)
+        assert all(abs(a - b) <= tol * max(1e-3, abs(a)) for a, b in zip(m_e, m_g)), (it, m_e, m_g)
+        assert abs(float(eng_e.gp_sum) - float(eng_g.gp_sum)) <= 5 * tol * max(1e-3, abs(float(eng_e.gp_sum)))
+    gi.finish()
+    torch.cuda.synchronize()
+    wg_g.append(float(eng_g.wgan_mean))
+    assert wg_g[0] == 0.0
+    for it in range(4):
+        assert abs(wg_e[it] - wg_g[it + 1]) <= tol * max(1e-3, abs(wg_e[it])), (it, wg_e, wg_g)
+    for l in range(4):                                       # the same number of power iterations on the same weights
+        assert rel_err(eng_g.u[l].cpu(), eng_e.u[l].cpu()) < 1e-5
+        assert rel_err(eng_g.v[l].cpu(), eng_e.v[l].cpu()) < 1e-5
+    assert float(eng_g.D.state[0]) == float(eng_e.D.state[0]) == 4 * c
+    gi.finish()                                              # (idempotent)
+    assert float(eng_g.wgan_mean) == wg_g[-1]
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_graph_replay_trains_like_eager(synth, dtype):
     """The same pair with the real learning rate: after the FIRST iteration (three optimiser updates of ~lr*sign(g) per element)

@@ -42,7 +42,7 @@ hs = getattr(gi, "head_split", False)
 
 def ca():                                                       # the critic's first segment (with its head graph, if split off)
     if hs: gi.c_a0.replay()
-    gi.c_a.replay()
+    (gi.c_a_g if getattr(gi, "batch_g", False) else gi.c_a).replay()      # (with the value-only forward's group where the iteration has it)
     if hs: gi.c_b0.replay()
 
 

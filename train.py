@@ -158,7 +158,7 @@ class GraphLoop:
                                                 fallback=self.inp[0])
             assert self.stage.pred_box.data_ptr() == self.inp[3].data_ptr()         # (staged with the batch: the same buffer)
             refine = self.stage
-        self.gi = engine_mod.GraphedIteration(eng, *self.inp, refine)
+        self.gi = engine_mod.GraphedIteration(eng, *self.inp, refine, batch_g_critic=True)
         B, c = eng.B, eng.c
         self.width = 4 * c + 2 + 12 * B
         self.hist = torch.zeros(self.ROWS, self.width, device=pred.device)
@@ -218,6 +218,12 @@ class GraphLoop:
         self._fold(self.n % self.ROWS)
         keys = ("loss_D", "loss_gp", "wasserstein_distance", "loss_G", "loss_iou", "loss_wgan", "iou_before", "iou_after")
         out = dict(zip(keys, self.sums if self.sums is not None else [0.0] * len(keys)))
+        if self.gi._g_owed:
+            # batch_g_critic: a replay's history row carries the PREVIOUS iteration's WGAN term (0 in the first row after a
+            # finish()); the last iteration's arrives with the forward finish() runs.  Only the epoch sums are used, so:
+            self.gi.finish()
+            w = -float(self.eng.wgan_mean)
+            out["loss_wgan"] += w; out["loss_G"] += w
         n, self.n, self.sums = self.n, 0, None
         return out, n
 
