@@ -448,7 +448,11 @@ def main():
                            global_batch=B * world, img_size=S, n_critic=c, parallelism=f"dp{world}",
                            launch=("hipGraph replay" + (" (software-pipelined across iterations: the replayed graph ends with the next "
                                                         "iteration's batched generator forward; DESIGN.md 2)"
-                                                        if getattr(run.graphed, "pipelined", False) else ""))
+                                                        if getattr(run.graphed, "pipelined", False) else "")
+                                   + ("; the generator step's value-only critic forward of replay i runs as a fourth group of replay "
+                                      "i+1's first critic forward: every timed replay runs exactly one (the previous replay's), the last "
+                                      "one's is run after the timed region (GraphedIteration.finish)"
+                                      if getattr(run.graphed, "batch_g", False) else ""))
                            if run.graphed is not None else "eager",
                            algorithmic_tflops=round(flop_iter / (ms * 1e-3) / 1e12, 2) if flop_iter else None),
                roofline=roofline, labels=labels)
