@@ -218,7 +218,7 @@ class StepEngine:
         else:
             self.u, self.v = [], []
             self.sn = _NoSpectralNorm(len(D_IDX), 4, dev)
-        self._zcap, self._zkeep, self._splits = {}, [], {}
+        self._zcap, self._zkeep, self._splits, self._zfull = {}, [], {}, {}
         self.grad_slabs = os.environ.get("GCSSL_GRAD_SLABS", "1") != "0"
         # one batched generator forward per iteration (g_forward_all); GCSSL_BATCH_G=0: one forward per call, for A/B runs
         self.batch_g = os.environ.get("GCSSL_BATCH_G", "1") != "0"
@@ -385,6 +385,7 @@ class StepEngine:
         buf = torch.empty(need, ho, ho, c, device=self.dev, dtype=torch.float32)
         z = buf[:n_full]
         self._zcap[z.data_ptr()] = (buf.numel(), n_full)
+        self._zfull[z.data_ptr()] = buf                            # (the whole allocation: the four-group critic forward writes 4B rows of it)
         self._zkeep.append(buf)
         return z
 
@@ -473,7 +474,7 @@ class StepEngine:
         self.d_x4 = [x4] + self.d_a4[:3]                                      # wgrad x operand of layer l
         # pre-InstanceNorm tensors are fp32 in both modes (z - mean(z) over 4..64 elements cancels a bf16 mantissa)
         # (each holds the K-split slabs of its producing conv when that conv splits: _zbuf)
-        self.d_z = [None] + [self._zbuf("fwd", (N3, B), S >> l, D_CH[l][0], D_CH[l][1], N3) for l in (1, 2, 3)]
+        self.d_z = [None] + [self._zbuf("fwd", (N3, B, N4), S >> l, D_CH[l][0], D_CH[l][1], N3) for l in (1, 2, 3)]   # (N4: room for the four-group forward)
         self._d_zsrc = list(self.d_z)          # what the norm backward kernels read per layer: d_z (fp32) or, after a fused forward, d_a
         self.d_mean4 = [None] + [torch.empty(N4, c, **f32) for _, c in D_CH[1:]]
         self.d_rstd4 = [None] + [torch.empty(N4, c, **f32) for _, c in D_CH[1:]]
@@ -670,6 +671,11 @@ class StepEngine:
                            d_a[l][:n], d_mean[l][:n], d_rstd[l][:n], cin, cout, bias=bias,
                            gscale=gscale_of_layer(l), group_n=group_n)
                 self._d_zsrc[l] = self.d_a[l]
+            elif wide and self._fin_x3(n, self.S >> l, cin, cout):
+                zfull = self._zfull[self.d_z[l].data_ptr()]         # (d_z[l] is its first 3B rows: what the backward reads)
+                self._conv(f"D.c{l + 1}.fwd[n={n}]", fl, ops.conv_in_act_x3_fwd, d_a[l - 1][:n], self.d_wf[l], zfull[:n],
+                           d_a[l][:n], d_mean[l][:n], d_rstd[l][:n], cin, cout, bias=bias, gscale=gscale_of_layer(l), group_n=group_n)
+                self._d_zsrc[l] = self.d_z[l]
             elif wide:
                 raise RuntimeError("the four-group critic forward needs the fused conv + InstanceNorm launches (gbatch_ok)")
             elif self._fin_x3(n, self.S >> l, cin, cout):
@@ -690,7 +696,10 @@ class StepEngine:
     def gbatch_ok(self) -> bool:
         """can the generator step's value-only critic forward be a fourth group of the next critic forward (d_main(with_g=True))?
         Every normalised layer must take the fused conv + InstanceNorm launch at 4B samples (the 16-bit modes at the bench shapes)."""
-        return self.spectral_norm and all(self._fin(4 * self.B, self.S >> l, *D_CH[l]) for l in (1, 2, 3))
+        n4 = 4 * self.B
+        return self.spectral_norm and all(
+            self._fin(n4, self.S >> l, *D_CH[l]) or
+            (self._fin_x3(n4, self.S >> l, *D_CH[l]) and self._zfull[self.d_z[l].data_ptr()].shape[0] >= n4) for l in (1, 2, 3))
 
     def critic_scores(self, pred: torch.Tensor, other: torch.Tensor, train: bool = True) -> torch.Tensor:
         """Discriminator.forward(pred, other) (cgan/models.py:255-258) for one (B,3,S,S) pair -> (B,1,h,w).
