@@ -677,7 +677,13 @@ class StepEngine:
                            d_a[l][:n], d_mean[l][:n], d_rstd[l][:n], cin, cout, bias=bias, gscale=gscale_of_layer(l), group_n=group_n)
                 self._d_zsrc[l] = self.d_z[l]
             elif wide:
-                raise RuntimeError("the four-group critic forward needs the fused conv + InstanceNorm launches (gbatch_ok)")
+                # an unfused layer of the four-group forward (the split modes' fourth layer at the bench shape): the conv adds its K
+                # splits into z atomically (no slab room is registered for 4B rows), then the norm pass -- on the whole allocation
+                zfull = self._zfull[self.d_z[l].data_ptr()]
+                self._conv(f"D.c{l + 1}.fwd[n={n}]", fl, ops.conv_fwd, d_a[l - 1][:n], self.d_wf[l], zfull[:n], cin, cout, bias=bias,
+                           gscale=gscale_of_layer(l), group_n=group_n, split_stride=0)
+                ops.in_act_fwd(zfull[:n], d_a[l][:n], d_mean[l][:n], d_rstd[l][:n], cout, LRELU)
+                self._d_zsrc[l] = self.d_z[l]
             elif self._fin_x3(n, self.S >> l, cin, cout):
                 # split-precision modes: the same fusion on fp32 tensors; z is still stored (the fp32 backward kernels read it)
                 self._conv(f"D.c{l + 1}.fwd[n={n}]", fl, ops.conv_in_act_x3_fwd, self.d_a[l - 1][:n], self.d_wf[l], self.d_z[l][:n],
@@ -695,11 +701,10 @@ class StepEngine:
 
     def gbatch_ok(self) -> bool:
         """can the generator step's value-only critic forward be a fourth group of the next critic forward (d_main(with_g=True))?
-        Every normalised layer must take the fused conv + InstanceNorm launch at 4B samples (the 16-bit modes at the bench shapes)."""
+        Every normalised layer takes the fused conv + InstanceNorm launch at 4B samples or has an fp32 pre-norm buffer of 4B rows."""
         n4 = 4 * self.B
         return self.spectral_norm and all(
-            self._fin(n4, self.S >> l, *D_CH[l]) or
-            (self._fin_x3(n4, self.S >> l, *D_CH[l]) and self._zfull[self.d_z[l].data_ptr()].shape[0] >= n4) for l in (1, 2, 3))
+            self._fin(n4, self.S >> l, *D_CH[l]) or self._zfull[self.d_z[l].data_ptr()].shape[0] >= n4 for l in (1, 2, 3))
 
     def critic_scores(self, pred: torch.Tensor, other: torch.Tensor, train: bool = True) -> torch.Tensor:
         """Discriminator.forward(pred, other) (cgan/models.py:255-258) for one (B,3,S,S) pair -> (B,1,h,w).

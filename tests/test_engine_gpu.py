@@ -550,7 +550,7 @@ def test_graph_replay_with_recrop_stage_in_the_loop(synth):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp16x3", "fp32"])
 def test_graph_replay_with_batched_value_forward(synth, dtype):
     """GraphedIteration(batch_g_critic=True): iteration i's value-only critic forward runs as a fourth group of iteration i+1's first
     critic forward, finish() runs the one the last replay owes.  With lr = 0 (weights fixed; alpha / dropout keyed by the device-side
@@ -579,7 +579,7 @@ def test_graph_replay_with_batched_value_forward(synth, dtype):
         torch.cuda.synchronize()
         wg_g.append(float(eng_g.wgan_mean))                   # the PREVIOUS iteration's (0 after the first replay: nothing owed yet)
         m_e, m_g = eng_e.means.tolist(), eng_g.means.tolist()
-        tol = 2e-2 if dtype == "bf16" else (5e-3 if dtype == "fp16" else 1e-3)   # (float-atomic order through the mode's roundings, as the other graph tests)
+        tol = {"bf16": 2e-2, "fp16": 5e-3}.get(dtype, 1e-3)   # (float-atomic order through the mode's roundings, as the other graph tests)
         assert all(abs(a - b) <= tol * max(1e-3, abs(a)) for a, b in zip(m_e, m_g)), (it, m_e, m_g)
         assert abs(float(eng_e.gp_sum) - float(eng_g.gp_sum)) <= 5 * tol * max(1e-3, abs(float(eng_e.gp_sum)))
     gi.finish()
