@@ -931,7 +931,7 @@ class StepEngine:
         self.sn.iterate(0, 3, zero=self._zero_all if zero_wgan else self.zero_blk, defer_finish=self._sn_defer and self._d_dirty)
         self._prep_d()
 
-    def d_main(self, sn_done: bool = False, with_g: bool = False) -> None:
+    def d_main(self, sn_done: bool = False, with_g: bool = False, zero_wgan: bool = False) -> None:
         """The critic side: spectral-norm iterations, the 3B-sample forward, gradient penalty, all gradients.
         with_g (GraphedIteration, batch_g_critic): the PREVIOUS iteration's value-only forward (g_critic: train-mode D on (pred,
         refined_G), cgan/cgan_train_enhanced.py:361-362) rides on this step's forward as a fourth group -- x4[3B:] holds its packed
@@ -953,7 +953,7 @@ class StepEngine:
         if c5_rides:
             ops.c5_dgrad_defer(self.d_da4_3, self.D.views["model.11.weight"], consts=(seeds[0], seeds[1], seeds[2], 1.0), group_n=B)
         if not sn_done:
-            self._sn_and_prep(zero_wgan=with_g)
+            self._sn_and_prep(zero_wgan=with_g or zero_wgan)      # (zero_wgan: a replay with nothing owed leaves wgan_mean at 0, not stale)
         if not self.D.grads_zero:                                 # optimizer.zero_grad() (:305) unless the last update did it
             self.D.g.zero_()
         self.D.grads_zero = False
@@ -1456,7 +1456,14 @@ class GraphedIteration:
                                 if k < c - 1:
                                     eng.d_main(with_g=(k == 0)); eng.d_update()
                         self.c_a_g = capture(seg_a_g)             # ... with the previous iteration's value-only forward as a fourth group
-                        self.c_a = capture(seg_a)                  # (first replay / after finish(): nothing owed)
+
+                        def seg_a_0():                            # (first replay / after finish(): nothing owed; wgan_mean reads 0)
+                            eng._d_dirty = True
+                            for k in range(c):
+                                eng.d_pre(pred, gt, refine_fn, k, None, None)
+                                if k < c - 1:
+                                    eng.d_main(zero_wgan=(k == 0)); eng.d_update()
+                        self.c_a = capture(seg_a_0)
                         # the last critic step, then only the PACK of this iteration's value-only forward: the next replay runs it
                         self.c_b = capture(lambda: (eng.d_main(), eng.d_update(), ops.pack_pair(pred, eng._refined_g, eng.x4[3 * eng.B:])))
                         self.head_split = False

@@ -594,6 +594,9 @@ def test_graph_replay_with_batched_value_forward(synth, dtype):
     assert float(eng_g.D.state[0]) == float(eng_e.D.state[0]) == 4 * c
     gi.finish()                                              # (idempotent)
     assert float(eng_g.wgan_mean) == wg_g[-1]
+    gi.replay(); torch.cuda.synchronize()
+    assert float(eng_g.wgan_mean) == 0.0                     # a replay with nothing owed leaves no stale value behind
+    gi.finish()
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
